@@ -1,0 +1,253 @@
+// Dense feature transforms of the hot path (torch_geometric.nn.Linear inside
+// GraphConv / GCNConv / GATConv and the HSCN head; reference model/hscn.py:51,54,
+// 99-100,112-113).  Widths are 9..128, so W lives in LDS and rows stream from HBM
+// once; weight gradients reduce in two ordered stages (no float atomics).
+#include "hscn_common.h"
+
+namespace {
+
+constexpr int LIN_THREADS = 256;
+
+// y[r, og*VEC .. +VEC) for lane (rl, og); LPR lanes per row.
+template <int VEC>
+__global__ void __launch_bounds__(LIN_THREADS)
+k_linear(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+         const float* __restrict__ x2, const float* __restrict__ W2, const float* __restrict__ att,
+         float* __restrict__ a_out, float* __restrict__ y, int64_t rows, int I, int O, int w_layout,
+         int act, int LPR, int RPB) {
+  extern __shared__ __align__(16) float lds[];
+  float* Wt = lds;                      // [I][O]
+  float* W2t = lds + (size_t)I * O;     // [I][O] if x2
+  for (int idx = threadIdx.x; idx < I * O; idx += LIN_THREADS) {
+    int i = idx / O, o = idx - i * O;
+    Wt[idx] = w_layout ? W[idx] : W[(size_t)o * I + i];
+    if (x2) W2t[idx] = w_layout ? W2[idx] : W2[(size_t)o * I + i];
+  }
+  __syncthreads();
+  const int rl = threadIdx.x / LPR;
+  const int og = threadIdx.x - rl * LPR;
+  const int o0 = og * VEC;
+  if (rl >= RPB) return;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rl; r < rows; r += (int64_t)gridDim.x * RPB) {
+    float acc[VEC], acc2[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { acc[v] = 0.f; acc2[v] = 0.f; }
+    const float* xr = x + r * I;
+    const float* x2r = x2 ? x2 + r * I : nullptr;
+    for (int i = 0; i < I; ++i) {
+      float xv = xr[i];
+      const float* wrow = Wt + (size_t)i * O + o0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = fmaf(xv, wrow[v], acc[v]);
+      if (x2r) {
+        float x2v = x2r[i];
+        const float* w2row = W2t + (size_t)i * O + o0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc2[v] = fmaf(x2v, w2row[v], acc2[v]);
+      }
+    }
+    if (att) {  // host guarantees LPR is a power of two <= 64 here
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) d = fmaf(acc[v], att[o0 + v], d);
+      for (int off = LPR >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      if (og == 0) a_out[r] = d;
+    }
+    float out[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float t = acc[v];
+      if (bias) t += bias[o0 + v];
+      if (x2r) t += acc2[v];
+      out[v] = apply_act(t, act);
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(y + r * O + o0) = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) y[r * O + o0 + v] = out[v];
+    }
+  }
+}
+
+// a[r] = sum_o y[r,o]*att[o]   (fallback when the fused row-dot is not possible)
+__global__ void k_rowdot(const float* __restrict__ y, const float* __restrict__ att, float* __restrict__ a,
+                         int64_t rows, int O) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float d = 0.f;
+  for (int o = 0; o < O; ++o) d = fmaf(y[r * O + o], att[o], d);
+  a[r] = d;
+}
+
+// ---- weight / bias gradient: partial[g][p] over row chunk g, pair p = o*(I+1)+i ----
+constexpr int BW_T = 32;       // rows per LDS tile
+constexpr int BW_PPT = 16;     // pairs per thread per pass
+constexpr int BW_PAIRS = LIN_THREADS * BW_PPT;
+
+__global__ void __launch_bounds__(LIN_THREADS)
+k_linear_bwd_w_partial(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ partial,
+                       int64_t rows, int I, int O, int64_t rows_per_chunk, int P) {
+  extern __shared__ __align__(16) float lds[];
+  float* gy_t = lds;                       // [BW_T][O]
+  float* x_t = lds + (size_t)BW_T * O;     // [BW_T][I+1]  (last column = 1 for the bias)
+  const int I1 = I + 1;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
+  int64_t r_end = r_begin + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  const int pbase = blockIdx.y * BW_PAIRS;
+  int po[BW_PPT], pi[BW_PPT];
+  float acc[BW_PPT];
+#pragma unroll
+  for (int k = 0; k < BW_PPT; ++k) {
+    int p = pbase + k * LIN_THREADS + threadIdx.x;
+    if (p < P) { po[k] = p / I1; pi[k] = p - po[k] * I1; } else { po[k] = -1; pi[k] = 0; }
+    acc[k] = 0.f;
+  }
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += BW_T) {
+    int nt = (int)((r_end - r0) < BW_T ? (r_end - r0) : BW_T);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nt * O; idx += LIN_THREADS) gy_t[idx] = gy[r0 * O + idx];
+    for (int idx = threadIdx.x; idx < nt * I1; idx += LIN_THREADS) {
+      int t = idx / I1, i = idx - t * I1;
+      x_t[idx] = i < I ? x[(r0 + t) * I + i] : 1.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BW_PPT; ++k) {
+      if (po[k] < 0) continue;
+      float a = acc[k];
+      for (int t = 0; t < nt; ++t) a = fmaf(gy_t[t * O + po[k]], x_t[t * I1 + pi[k]], a);
+      acc[k] = a;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < BW_PPT; ++k) {
+    int p = pbase + k * LIN_THREADS + threadIdx.x;
+    if (p < P) partial[(size_t)blockIdx.x * P + p] = acc[k];
+  }
+}
+
+__global__ void k_linear_bwd_w_reduce(const float* __restrict__ partial, float* __restrict__ gW,
+                                      float* __restrict__ gb, int G, int I, int O, int P, int accumulate) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += partial[(size_t)g * P + p];
+  int I1 = I + 1;
+  int o = p / I1, i = p - o * I1;
+  if (i < I) {
+    if (gW) gW[(size_t)o * I + i] = accumulate ? gW[(size_t)o * I + i] + s : s;
+  } else if (gb) {
+    gb[o] = accumulate ? gb[o] + s : s;
+  }
+}
+
+__global__ void k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ g,
+                          int64_t n, int act) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) g[i] = gy[i] * act_grad_from_output(y[i], act);
+}
+
+__global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = apply_act(x[i], act);
+}
+
+inline int chunks_for(int64_t rows) {
+  int64_t g = (rows + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 512) g = 512;
+  return (int)g;
+}
+
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int hscn_linear_fwd(const float* x, const float* W, const float* bias, const float* x2, const float* W2,
+                    const float* att, float* a_out, float* y, int64_t rows, int I, int O, int w_layout,
+                    int act, void* stream_) {
+  if (rows < 0 || I < 1 || O < 1 || !W || (rows > 0 && (!x || !y))) return HSCN_E_BADARG;
+  if ((x2 == nullptr) != (W2 == nullptr) || (att == nullptr) != (a_out == nullptr)) return HSCN_E_BADARG;
+  if (rows == 0) return 0;
+  hipStream_t st = hscn_stream(stream_);
+  const int VEC = (O % 4 == 0) ? 4 : 1;
+  const int LPR = O / VEC;
+  if (LPR > LIN_THREADS) return HSCN_E_UNSUPPORTED;
+  const int RPB = LIN_THREADS / LPR;
+  size_t lds = (size_t)I * O * 4 * (x2 ? 2 : 1);
+  if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  bool fuse_att = att && is_pow2(LPR) && LPR <= 64;
+  if (att && !fuse_att && (bias || act != HSCN_ACT_IDENTITY || x2)) return HSCN_E_UNSUPPORTED;
+  int64_t nb = (rows + RPB - 1) / RPB;
+  if (nb > 2048) nb = 2048;
+  if (VEC == 4) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_linear<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_linear<4><<<(unsigned)nb, LIN_THREADS, lds, st>>>(x, W, bias, x2, W2, fuse_att ? att : nullptr,
+                                                         fuse_att ? a_out : nullptr, y, rows, I, O, w_layout,
+                                                         act, LPR, RPB);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_linear<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_linear<1><<<(unsigned)nb, LIN_THREADS, lds, st>>>(x, W, bias, x2, W2, fuse_att ? att : nullptr,
+                                                         fuse_att ? a_out : nullptr, y, rows, I, O, w_layout,
+                                                         act, LPR, RPB);
+  }
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  if (att && !fuse_att) {
+    k_rowdot<<<hscn_blocks(rows, 256), 256, 0, st>>>(y, att, a_out, rows, O);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
+  return 0;
+}
+
+size_t hscn_linear_bwd_w_workspace_bytes(int64_t rows, int I, int O) {
+  return (size_t)chunks_for(rows) * (size_t)O * (I + 1) * 4;
+}
+
+int hscn_linear_bwd_w(const float* gy, const float* x, float* gW, float* gb, int64_t rows, int I, int O,
+                      int accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
+  // in_f == 0 with x == NULL: bias gradient only (column sums of gy)
+  if (rows < 0 || I < 0 || O < 1 || !workspace || (rows > 0 && (!gy || (I > 0 && !x)))) return HSCN_E_BADARG;
+  if (workspace_bytes < hscn_linear_bwd_w_workspace_bytes(rows, I, O)) return HSCN_E_WORKSPACE;
+  hipStream_t st = hscn_stream(stream_);
+  const int P = O * (I + 1);
+  const int G = chunks_for(rows);
+  const int64_t rpc = (rows + G - 1) / G;
+  size_t lds = (size_t)BW_T * (O + I + 1) * 4;
+  if (lds > 64 * 1024) return HSCN_E_UNSUPPORTED;
+  dim3 grid(G, (P + BW_PAIRS - 1) / BW_PAIRS);
+  k_linear_bwd_w_partial<<<grid, LIN_THREADS, lds, st>>>(gy, x, (float*)workspace, rows, I, O, rpc, P);
+  k_linear_bwd_w_reduce<<<hscn_blocks(P, 256), 256, 0, st>>>((const float*)workspace, gW, gb, G, I, O, P,
+                                                             accumulate);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_act_fwd(const float* x, float* y, int64_t count, int act, void* stream_) {
+  if (count < 0 || (count > 0 && (!x || !y))) return HSCN_E_BADARG;
+  if (count == 0) return 0;
+  unsigned nb = hscn_blocks(count, 256);
+  if (nb > 4096) nb = 4096;
+  k_act_fwd<<<nb, 256, 0, hscn_stream(stream_)>>>(x, y, count, act);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_act_bwd(const float* gy, const float* y, float* g, int64_t count, int act, void* stream_) {
+  if (count < 0 || (count > 0 && (!gy || !y || !g))) return HSCN_E_BADARG;
+  if (count == 0) return 0;
+  unsigned nb = hscn_blocks(count, 256);
+  if (nb > 4096) nb = 4096;
+  k_act_bwd<<<nb, 256, 0, hscn_stream(stream_)>>>(gy, y, g, count, act);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // extern "C"

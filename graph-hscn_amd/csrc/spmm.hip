@@ -1,0 +1,118 @@
+// CSR gather-reduce (SpMM) kernels: the GCNConv / GraphConv propagate step of the
+// hot path (reference model/hscn.py:32,40,88-93).
+//
+// HBM-bound: per row one rowptr pair, its column indices, one gathered feature
+// row per neighbour, one written row.  A row is owned by LPR = width/VEC
+// consecutive lanes (VEC=4: 16-byte loads/stores), so a wave covers 64/LPR rows
+// and every global access of a lane group is one contiguous row segment.  Rows
+// accumulate in CSR slot order with separately rounded multiply and add: the
+// order and rounding of the CPU reference's gather -> scale -> index_add_.
+#include "hscn_common.h"
+
+namespace {
+
+constexpr int SP_THREADS = 256;
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  using T = float4;
+  static __device__ __forceinline__ T load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ T axpy(float w, T x, T a) {
+    return make_float4(add_rn(a.x, mul_rn(w, x.x)), add_rn(a.y, mul_rn(w, x.y)),
+                       add_rn(a.z, mul_rn(w, x.z)), add_rn(a.w, mul_rn(w, x.w)));
+  }
+  static __device__ __forceinline__ T add(T a, T b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+  static __device__ __forceinline__ T act(T a, int k) {
+    return make_float4(apply_act(a.x, k), apply_act(a.y, k), apply_act(a.z, k), apply_act(a.w, k));
+  }
+};
+template <>
+struct Vec<1> {
+  using T = float;
+  static __device__ __forceinline__ T load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
+  static __device__ __forceinline__ T zero() { return 0.f; }
+  static __device__ __forceinline__ T axpy(float w, T x, T a) { return add_rn(a, mul_rn(w, x)); }
+  static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+  static __device__ __forceinline__ T act(T a, int k) { return apply_act(a, k); }
+};
+
+// MODE 0: w = dinv_c[col]*dinv_r[row] (GCN)   MODE 1: w = wts[eid ? eid[p] : p] or 1
+template <int VEC, int MODE>
+__global__ void __launch_bounds__(SP_THREADS)
+k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+       const float* __restrict__ dinv_r, const float* __restrict__ dinv_c, const float* __restrict__ wts,
+       const float* __restrict__ h, const float* __restrict__ bias, float* __restrict__ out,
+       int64_t num_rows, int width, int LPR, int RPB, int accumulate, int act) {
+  using V = Vec<VEC>;
+  const int rl = threadIdx.x / LPR;
+  const int f = (threadIdx.x - rl * LPR) * VEC;
+  if (rl >= RPB) return;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rl; r < num_rows; r += (int64_t)gridDim.x * RPB) {
+    const int s = rowptr[r], t = rowptr[r + 1];
+    typename V::T acc = V::zero();
+    float dr = 0.f;
+    if (MODE == 0) dr = dinv_r[r];
+    for (int p = s; p < t; ++p) {
+      const int j = col[p];
+      float w;
+      if (MODE == 0) w = mul_rn(dinv_c[j], dr);
+      else w = wts ? wts[eid ? eid[p] : p] : 1.0f;
+      acc = V::axpy(w, V::load(h + (size_t)j * width + f), acc);
+    }
+    if (bias) acc = V::add(acc, V::load(bias + f));
+    if (accumulate) acc = V::add(acc, V::load(out + (size_t)r * width + f));
+    V::store(out + (size_t)r * width + f, V::act(acc, act));
+  }
+}
+
+template <int MODE>
+int launch_spmm(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const float* dinv_r,
+                const float* dinv_c, const float* wts, const float* h, const float* bias, float* out,
+                int64_t num_rows, int width, int accumulate, int act, hipStream_t st) {
+  const int VEC = (width % 4 == 0) ? 4 : 1;
+  const int LPR = width / VEC;
+  if (LPR > SP_THREADS) return HSCN_E_UNSUPPORTED;
+  const int RPB = SP_THREADS / LPR;
+  int64_t nb = (num_rows + RPB - 1) / RPB;
+  if (nb > 8192) nb = 8192;
+  if (VEC == 4)
+    k_spmm<4, MODE><<<(unsigned)nb, SP_THREADS, 0, st>>>(rowptr, col, eid, dinv_r, dinv_c, wts, h, bias, out,
+                                                         num_rows, width, LPR, RPB, accumulate, act);
+  else
+    k_spmm<1, MODE><<<(unsigned)nb, SP_THREADS, 0, st>>>(rowptr, col, eid, dinv_r, dinv_c, wts, h, bias, out,
+                                                         num_rows, width, LPR, RPB, accumulate, act);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hscn_spmm_csr_gcn(const int32_t* rowptr, const int32_t* col, const float* dinv_r, const float* dinv_c,
+                      const float* h, const float* bias, float* out, int64_t num_rows, int width,
+                      int accumulate, int act, void* stream_) {
+  if (num_rows < 0 || width < 1) return HSCN_E_BADARG;
+  if (num_rows == 0) return 0;
+  if (!rowptr || !col || !dinv_r || !dinv_c || !h || !out) return HSCN_E_BADARG;
+  return launch_spmm<0>(rowptr, col, nullptr, dinv_r, dinv_c, nullptr, h, bias, out, num_rows, width,
+                        accumulate, act, hscn_stream(stream_));
+}
+
+int hscn_spmm_csr_weighted(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const float* w,
+                           const float* x, float* out, int64_t num_rows, int width, void* stream_) {
+  if (num_rows < 0 || width < 1) return HSCN_E_BADARG;
+  if (num_rows == 0) return 0;
+  if (!rowptr || !col || !x || !out) return HSCN_E_BADARG;
+  return launch_spmm<1>(rowptr, col, eid, nullptr, nullptr, w, x, nullptr, out, num_rows, width, 0,
+                        HSCN_ACT_IDENTITY, hscn_stream(stream_));
+}
+
+}  // extern "C"

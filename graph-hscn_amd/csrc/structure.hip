@@ -1,0 +1,328 @@
+// Graph structure kernels: stable COO(int64) -> CSR(int32), degree
+// normalisation, argmax assignment, dense adjacency.
+//
+// Integer/byte work, HBM- (at LRGB batch sizes: latency-) bound.  No float
+// atomics: the only atomics are int32 counters whose final values do not depend
+// on arrival order, and exact +1.0f adds in to_dense_adj.
+#include "hscn_common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 entries per block
+
+// ---- histogram: cnt[key+1] += 1 -------------------------------------------------
+__global__ void k_hist(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int64_t E,
+                       int64_t num_rows, int64_t num_cols, int32_t* __restrict__ cnt,
+                       int32_t* __restrict__ flag) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t k = key[e], o = other[e];
+  if (k < 0 || k >= num_rows || o < 0 || o >= num_cols) {
+    if (flag) atomicOr(flag, 1);
+    return;
+  }
+  atomicAdd(&cnt[k + 1], 1);
+}
+
+// ---- block-wise inclusive scan of cnt[0..n] (n+1 entries) in place ---------------
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total) {
+  // wave scan then cross-wave
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) lds[w] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+    int s = lds[i];
+    if (i < w) woff += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return woff + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partial(const int32_t* __restrict__ a, int64_t n,
+                                                               int32_t* __restrict__ blocksum) {
+  __shared__ int lds[SCAN_THREADS / 64];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    if (idx < n) s += a[idx];
+  }
+  int total;
+  block_exclusive_scan(s, lds, total);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_blocksums(int32_t* __restrict__ blocksum, int nblocks) {
+  __shared__ int lds[16];
+  int carry = 0;
+  for (int base = 0; base < nblocks; base += 1024) {
+    int idx = base + threadIdx.x;
+    int v = idx < nblocks ? blocksum[idx] : 0;
+    int total;
+    int ex = block_exclusive_scan(v, lds, total);
+    if (idx < nblocks) blocksum[idx] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(int32_t* __restrict__ a, int64_t n,
+                                                             const int32_t* __restrict__ blockoff) {
+  __shared__ int lds[SCAN_THREADS / 64];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    v[i] = idx < n ? a[idx] : 0;
+    s += v[i];
+  }
+  int total;
+  int ex = block_exclusive_scan(s, lds, total) + blockoff[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    ex += v[i];
+    if (idx < n) a[idx] = ex;  // inclusive
+  }
+}
+
+// Small-n path: a single block scans everything (one launch instead of three).
+__global__ void __launch_bounds__(1024) k_scan_single(int32_t* __restrict__ a, int64_t n) {
+  __shared__ int lds[16];
+  int carry = 0;
+  for (int64_t base = 0; base < n; base += 1024 * 4) {
+    int64_t i0 = base + (int64_t)threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = (i0 + i) < n ? a[i0 + i] : 0;
+      s += v[i];
+    }
+    int total;
+    int ex = block_exclusive_scan(s, lds, total) + carry;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ex += v[i];
+      if ((i0 + i) < n) a[i0 + i] = ex;
+    }
+    carry += total;
+  }
+}
+
+// ---- fill: unordered placement through an int cursor ----------------------------
+__global__ void k_fill(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int64_t E,
+                       int64_t num_rows, int64_t num_cols, const int32_t* __restrict__ rowptr,
+                       int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t k = key[e], o = other[e];
+  if (k < 0 || k >= num_rows || o < 0 || o >= num_cols) return;
+  int p = atomicAdd(&cursor[k], 1);
+  tmp[rowptr[k] + p] = (int32_t)e;
+}
+
+// ---- rank inside the row by edge id => stable, arrival-order independent ---------
+__global__ void k_rank(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int64_t E,
+                       int64_t num_rows, int64_t num_cols, const int32_t* __restrict__ rowptr,
+                       const int32_t* __restrict__ tmp, int32_t* __restrict__ col, int32_t* __restrict__ eid) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t k = key[e], o = other[e];
+  if (k < 0 || k >= num_rows || o < 0 || o >= num_cols) return;
+  int s = rowptr[k], t = rowptr[k + 1];
+  int rank = 0;
+  int me = (int)e;
+  for (int q = s; q < t; ++q) rank += (tmp[q] < me) ? 1 : 0;
+  col[s + rank] = (int32_t)o;
+  eid[s + rank] = me;
+}
+
+__global__ void k_inv_pos(const int32_t* __restrict__ eid, int64_t E, int32_t* __restrict__ inv) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < E) inv[eid[p]] = (int32_t)p;
+}
+__global__ void k_pos_t(const int32_t* __restrict__ eid_t, const int32_t* __restrict__ inv, int64_t E,
+                        int32_t* __restrict__ pos_t) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < E) pos_t[q] = inv[eid_t[q]];
+}
+
+__global__ void k_dinv(const int32_t* __restrict__ rowptr, int64_t n, float* __restrict__ dinv) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int d = rowptr[i + 1] - rowptr[i];
+  // torch: deg.pow(-0.5) == 1/sqrt(deg) (both correctly rounded); inf -> 0
+  dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
+}
+
+__global__ void k_wdeg_dinv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ eid,
+                            const float* __restrict__ w, int64_t n, float* __restrict__ dinv) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float deg = 0.f;
+  for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) deg = add_rn(deg, w ? w[eid[p]] : 1.0f);
+  float r = 1.0f / sqrtf(deg);
+  dinv[i] = isinf(r) ? 0.f : r;
+}
+
+__global__ void k_wnorm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                        const int32_t* __restrict__ eid, const float* __restrict__ w,
+                        const float* __restrict__ dinv, int64_t n, float* __restrict__ wn) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float di = dinv[i];
+  for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+    int e = eid[p];
+    float we = w ? w[e] : 1.0f;
+    wn[e] = mul_rn(mul_rn(dinv[col[p]], we), di);  // dis[row]*w*dis[col]
+  }
+}
+
+__global__ void k_argmax(const float* __restrict__ S, int64_t* __restrict__ ids, int64_t n, int K) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = S + i * K;
+  float best = r[0];
+  int bi = 0;
+  for (int k = 1; k < K; ++k) {
+    float v = r[k];
+    if (v > best) { best = v; bi = k; }
+  }
+  ids[i] = bi;
+}
+
+__global__ void k_dense_adj(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t E,
+                            int64_t n, float* __restrict__ adj) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t r = row[e], c = col[e];
+  if (r < 0 || r >= n || c < 0 || c >= n) return;
+  atomicAdd(&adj[r * n + c], 1.0f);  // exact: integer-valued, order independent
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int hscn_abi_version(void) { return HSCN_ABI_VERSION; }
+
+const char* hscn_strerror(int code) {
+  if (code == 0) return "ok";
+  if (code == HSCN_E_BADARG) return "hscn: bad argument";
+  if (code == HSCN_E_WORKSPACE) return "hscn: workspace too small";
+  if (code == HSCN_E_UNSUPPORTED) return "hscn: unsupported shape";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "hscn: unknown error";
+}
+
+size_t hscn_csr_workspace_bytes(int64_t E, int64_t num_rows) {
+  size_t cursor = align_up((size_t)(num_rows > 0 ? num_rows : 1) * 4, 256);
+  size_t tmp = align_up((size_t)(E > 0 ? E : 1) * 4, 256);
+  size_t nblk = (size_t)((num_rows + 1 + SCAN_TILE - 1) / SCAN_TILE);
+  size_t bs = align_up((nblk + 1) * 4, 256);
+  return cursor + tmp + bs;
+}
+
+int hscn_csr_build(const int64_t* key, const int64_t* other, int64_t E, int64_t num_rows, int64_t num_cols,
+                   int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* flag, void* workspace,
+                   size_t workspace_bytes, void* stream_) {
+  if (E < 0 || num_rows < 0 || !rowptr || (E > 0 && (!key || !other || !col || !eid)) || !workspace)
+    return HSCN_E_BADARG;
+  if (E > INT32_MAX || num_rows >= INT32_MAX || num_cols > INT32_MAX) return HSCN_E_UNSUPPORTED;
+  if (workspace_bytes < hscn_csr_workspace_bytes(E, num_rows)) return HSCN_E_WORKSPACE;
+  hipStream_t st = hscn_stream(stream_);
+  char* ws = (char*)workspace;
+  size_t cursor_b = align_up((size_t)(num_rows > 0 ? num_rows : 1) * 4, 256);
+  size_t tmp_b = align_up((size_t)(E > 0 ? E : 1) * 4, 256);
+  int32_t* cursor = (int32_t*)ws;
+  int32_t* tmp = (int32_t*)(ws + cursor_b);
+  int32_t* blocksum = (int32_t*)(ws + cursor_b + tmp_b);
+
+  hipError_t err = hipMemsetAsync(rowptr, 0, (size_t)(num_rows + 1) * 4, st);
+  if (err != hipSuccess) return (int)err;
+  err = hipMemsetAsync(cursor, 0, cursor_b, st);
+  if (err != hipSuccess) return (int)err;
+  if (E > 0) {
+    k_hist<<<hscn_blocks(E, 256), 256, 0, st>>>(key, other, E, num_rows, num_cols, rowptr, flag);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
+  int64_t n1 = num_rows + 1;
+  if (n1 <= 64 * 1024) {
+    k_scan_single<<<1, 1024, 0, st>>>(rowptr, n1);
+  } else {
+    int nblk = (int)((n1 + SCAN_TILE - 1) / SCAN_TILE);
+    k_scan_partial<<<nblk, SCAN_THREADS, 0, st>>>(rowptr, n1, blocksum);
+    k_scan_blocksums<<<1, 1024, 0, st>>>(blocksum, nblk);
+    k_scan_final<<<nblk, SCAN_THREADS, 0, st>>>(rowptr, n1, blocksum);
+  }
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  if (E > 0) {
+    k_fill<<<hscn_blocks(E, 256), 256, 0, st>>>(key, other, E, num_rows, num_cols, rowptr, cursor, tmp);
+    k_rank<<<hscn_blocks(E, 256), 256, 0, st>>>(key, other, E, num_rows, num_cols, rowptr, tmp, col, eid);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
+  return 0;
+}
+
+int hscn_csr_cross_positions(const int32_t* eid, const int32_t* eid_t, int64_t E, int32_t* inv, int32_t* pos_t,
+                             void* stream_) {
+  if (E < 0 || (E > 0 && (!eid || !eid_t || !inv || !pos_t))) return HSCN_E_BADARG;
+  if (E == 0) return 0;
+  hipStream_t st = hscn_stream(stream_);
+  k_inv_pos<<<hscn_blocks(E, 256), 256, 0, st>>>(eid, E, inv);
+  k_pos_t<<<hscn_blocks(E, 256), 256, 0, st>>>(eid_t, inv, E, pos_t);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_gcn_dinv(const int32_t* rowptr, int64_t n, float* dinv, void* stream_) {
+  if (n < 0 || (n > 0 && (!rowptr || !dinv))) return HSCN_E_BADARG;
+  if (n == 0) return 0;
+  k_dinv<<<hscn_blocks(n, 256), 256, 0, hscn_stream(stream_)>>>(rowptr, n, dinv);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_gcn_norm_weights(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const float* w,
+                          int64_t n, float* dinv, float* w_norm, void* stream_) {
+  if (n < 0 || (n > 0 && (!rowptr || !col || !eid || !dinv || !w_norm))) return HSCN_E_BADARG;
+  if (n == 0) return 0;
+  hipStream_t st = hscn_stream(stream_);
+  k_wdeg_dinv<<<hscn_blocks(n, 256), 256, 0, st>>>(rowptr, eid, w, n, dinv);
+  k_wnorm<<<hscn_blocks(n, 256), 256, 0, st>>>(rowptr, col, eid, w, dinv, n, w_norm);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_assign_argmax(const float* S, int64_t* ids, int64_t n, int K, void* stream_) {
+  if (n < 0 || K < 1 || (n > 0 && (!S || !ids))) return HSCN_E_BADARG;
+  if (n == 0) return 0;
+  k_argmax<<<hscn_blocks(n, 256), 256, 0, hscn_stream(stream_)>>>(S, ids, n, K);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t E, int64_t n, float* adj, void* stream_) {
+  if (E < 0 || n < 0 || (E > 0 && (!row || !col || !adj))) return HSCN_E_BADARG;
+  if (E == 0) return 0;
+  k_dense_adj<<<hscn_blocks(E, 256), 256, 0, hscn_stream(stream_)>>>(row, col, E, n, adj);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // extern "C"

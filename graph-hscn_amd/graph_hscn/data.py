@@ -1,0 +1,218 @@
+"""Minimal graph containers with the protocol the reference's loops touch.
+
+torch_geometric is not available on the target boxes, so the package owns the
+few container behaviours the hot path's callers use
+(/root/reference/graph_hscn/train/train.py:73-77, train_clustering.py:36-47,
+loader/hetero_data.py:62-87, loader/loader.py:48-60):
+
+  Data(x, edge_index, edge_weight, y, num_nodes), ``.to(device)``
+  HeteroData: ``h["local"].x``, ``h["local","to","local"].edge_index``,
+              ``.x_dict``, ``.edge_index_dict``
+  Batch / HeteroBatch ``.from_data_list`` with PyG collate semantics
+              (concat per type, offset edge indices, ``batch`` / ``ptr`` vectors)
+  DataLoader(dataset, batch_size, shuffle)
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import Tensor
+
+EdgeType = Tuple[str, str, str]
+
+
+class Store:
+    """Attribute bag for one node type or one edge type."""
+
+    def __init__(self, **kw):
+        self.__dict__["_d"] = {}
+        for k, v in kw.items():
+            self._d[k] = v
+
+    def __getattr__(self, k):
+        try:
+            return self.__dict__["_d"][k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __setattr__(self, k, v):
+        self._d[k] = v
+
+    def __contains__(self, k):
+        return k in self._d
+
+    def keys(self):
+        return self._d.keys()
+
+    def items(self):
+        return self._d.items()
+
+    def to(self, device, non_blocking: bool = False) -> "Store":
+        out = Store()
+        for k, v in self._d.items():
+            out._d[k] = v.to(device, non_blocking=non_blocking) if isinstance(v, Tensor) else v
+        return out
+
+    @property
+    def num_nodes(self) -> int:
+        if "num_nodes" in self._d:
+            return int(self._d["num_nodes"])
+        return int(self._d["x"].size(0))
+
+
+class Data(Store):
+    """Homogeneous graph.  ``edge_index`` is int64 ``[2, E]`` = [source; target]."""
+
+    def __init__(self, x: Optional[Tensor] = None, edge_index: Optional[Tensor] = None,
+                 y: Optional[Tensor] = None, edge_weight: Optional[Tensor] = None,
+                 num_nodes: Optional[int] = None, **kw):
+        super().__init__()
+        self._d.update(dict(x=x, edge_index=edge_index, y=y, edge_weight=edge_weight))
+        if num_nodes is not None:
+            self._d["num_nodes"] = int(num_nodes)
+        self._d.update(kw)
+
+    @property
+    def num_features(self) -> int:
+        return int(self.x.size(1))
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.edge_index.size(1))
+
+    def to(self, device, non_blocking: bool = False) -> "Data":
+        out = self.__class__.__new__(self.__class__)
+        out.__dict__["_d"] = {
+            k: (v.to(device, non_blocking=non_blocking) if isinstance(v, Tensor) else v)
+            for k, v in self._d.items()
+        }
+        return out
+
+
+class Batch(Data):
+    """Block-diagonal union of ``Data`` graphs (PyG ``Batch.from_data_list``)."""
+
+    @classmethod
+    def from_data_list(cls, graphs: Sequence[Data]) -> "Batch":
+        ns = [g.num_nodes for g in graphs]
+        ptr = torch.zeros(len(ns) + 1, dtype=torch.long)
+        ptr[1:] = torch.cumsum(torch.as_tensor(ns, dtype=torch.long), 0)
+        out = cls(
+            x=torch.cat([g.x for g in graphs], 0),
+            edge_index=torch.cat([g.edge_index + int(ptr[i]) for i, g in enumerate(graphs)], 1),
+            num_nodes=int(ptr[-1]),
+        )
+        if all(g.y is not None for g in graphs):
+            out.y = torch.cat([g.y if g.y.dim() >= 2 else g.y.view(1, -1) for g in graphs], 0)
+        if all(g.edge_weight is not None for g in graphs):
+            out.edge_weight = torch.cat([g.edge_weight for g in graphs], 0)
+        out.batch = torch.repeat_interleave(torch.arange(len(ns)), torch.as_tensor(ns))
+        out.ptr = ptr
+        out.num_graphs = len(graphs)
+        return out
+
+    @property
+    def batch_size(self) -> int:
+        return int(self.num_graphs)
+
+
+class HeteroData:
+    """Typed graph: node stores keyed by ``str``, edge stores by ``(src, rel, dst)``."""
+
+    def __init__(self):
+        self._nodes: Dict[str, Store] = {}
+        self._edges: Dict[EdgeType, Store] = {}
+
+    def __getitem__(self, key: Union[str, EdgeType]) -> Store:
+        if isinstance(key, tuple):
+            return self._edges.setdefault(tuple(key), Store())
+        return self._nodes.setdefault(key, Store())
+
+    @property
+    def node_types(self) -> List[str]:
+        return list(self._nodes)
+
+    @property
+    def edge_types(self) -> List[EdgeType]:
+        return list(self._edges)
+
+    @property
+    def x_dict(self) -> Dict[str, Tensor]:
+        return {k: s.x for k, s in self._nodes.items() if "x" in s}
+
+    @property
+    def edge_index_dict(self) -> Dict[EdgeType, Tensor]:
+        return {k: s.edge_index for k, s in self._edges.items() if "edge_index" in s}
+
+    def to(self, device, non_blocking: bool = False):
+        out = self.__class__()
+        out._nodes = {k: s.to(device, non_blocking) for k, s in self._nodes.items()}
+        out._edges = {k: s.to(device, non_blocking) for k, s in self._edges.items()}
+        for k, v in self.__dict__.items():
+            if k not in ("_nodes", "_edges"):
+                out.__dict__[k] = v
+        return out
+
+
+class HeteroBatch(HeteroData):
+    """PyG collate for ``HeteroData``: relation insertion order
+    of the first graph is kept (ll, vv, lv for loader/hetero_data.py:67,77,84)."""
+
+    num_graphs: int = 0
+
+    @classmethod
+    def from_data_list(cls, graphs: Sequence[HeteroData]) -> "HeteroBatch":
+        out = cls()
+        out.num_graphs = len(graphs)
+        ptrs: Dict[str, Tensor] = {}
+        for nt in graphs[0].node_types:
+            ns = [g[nt].num_nodes for g in graphs]
+            ptr = torch.zeros(len(ns) + 1, dtype=torch.long)
+            ptr[1:] = torch.cumsum(torch.as_tensor(ns, dtype=torch.long), 0)
+            ptrs[nt] = ptr
+            st = out[nt]
+            st.x = torch.cat([g[nt].x for g in graphs], 0)
+            st.batch = torch.repeat_interleave(torch.arange(len(ns)), torch.as_tensor(ns))
+            st.ptr = ptr
+            st.num_nodes = int(ptr[-1])
+            if all("y" in g[nt] and g[nt].y is not None for g in graphs):
+                st.y = torch.cat([g[nt].y if g[nt].y.dim() >= 2 else g[nt].y.view(1, -1) for g in graphs], 0)
+        for et in graphs[0].edge_types:
+            s, _, d = et
+            off = torch.stack([ptrs[s][:-1], ptrs[d][:-1]], 0)  # [2, B]
+            out[et].edge_index = torch.cat(
+                [g[et].edge_index + off[:, i : i + 1] for i, g in enumerate(graphs)], 1)
+        return out
+
+    @property
+    def batch_size(self) -> int:
+        return int(self.num_graphs)
+
+
+class DataLoader:
+    """List-backed mini-batch iterator (reference: loader/loader.py:48-60 wraps the
+    PyG DataLoader; workers default to 0, defaults.py:3)."""
+
+    def __init__(self, dataset: Sequence, batch_size: int = 1, shuffle: bool = False,
+                 num_workers: int = 0, persistent_workers: bool = False,
+                 generator: Optional[torch.Generator] = None, **_):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.generator = generator
+
+    def __len__(self) -> int:
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self) -> Iterator:
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        for i in range(0, n, self.batch_size):
+            yield collate([self.dataset[j] for j in order[i : i + self.batch_size]])
+
+
+def collate(graphs: Sequence):
+    if isinstance(graphs[0], HeteroData):
+        return HeteroBatch.from_data_list(graphs)
+    return Batch.from_data_list(graphs)

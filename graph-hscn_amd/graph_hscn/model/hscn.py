@@ -1,0 +1,149 @@
+"""SCN (MinCUT spectral clustering net) and HSCN (heterogeneous local/virtual
+message passing) with the reference's class names, constructor and ``forward``
+signatures (/root/reference/graph_hscn/model/hscn.py:19-140), computing on
+MI355X through the HIP C ABI (include/hscn.h).
+
+Differences a caller can observe, all documented in DESIGN.md:
+  * parameters are materialised eagerly (the reference's lazy ``-1`` dims
+    materialise after the optimizer was built, train/train.py:155-159);
+  * ``SCN.forward`` accepts an optional ``node_ptr`` to process a block-diagonal
+    batch of graphs in one call (losses = mean over graphs); without it the call
+    is the reference's single-graph step;
+  * the dense ``[1,n,n]`` adjacency the reference returns and both callers drop
+    (train/train_clustering.py:45,65) is built on the device only for
+    single-graph calls; batched calls return ``None`` in that slot.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ..config.config import ACT_DICT, CONV_DICT, HSCNConfig
+from ..nn import GATConv, GCNConv, GraphConv, HeteroConv, Linear
+from ..nn import functional as Fh
+from ..nn.pool import global_mean_pool, mincut_pool_sparse, to_dense_adj
+from ..structure import Relation, relation_of
+
+LL = ("local", "to", "local")
+VV = ("virtual", "to", "virtual")
+LV = ("local", "to", "virtual")
+
+
+def _act_name(act) -> Optional[str]:
+    if isinstance(act, str):
+        return act.lower()
+    return getattr(act, "hscn_name", None)
+
+
+class _MessagePassingStack(nn.Module):
+    """Stand-in for PyG ``Sequential('x, edge_index, edge_weight', [...])``
+    (hscn.py:28-45): GraphConv children are registered as ``module_{2i}`` so the
+    ``state_dict`` keys equal the reference's."""
+
+    def __init__(self, num_features: int, mp_units: list, act: str):
+        super().__init__()
+        self.act = act
+        self.num = len(mp_units)
+        dims = [num_features] + list(mp_units)
+        for i in range(self.num):
+            setattr(self, f"module_{2 * i}", GraphConv(dims[i], dims[i + 1]))
+
+    def forward(self, x: Tensor, rel: Relation, edge_weight: Optional[Tensor]) -> Tensor:
+        for i in range(self.num):
+            x = getattr(self, f"module_{2 * i}")(x, rel, edge_weight, act=self.act)
+        return x
+
+
+class SCN(nn.Module):
+    def __init__(self, mp_units: list, mp_act: str, num_features: int, num_clusters: int,
+                 mlp_units: list = [], mlp_act: str = "identity"):
+        super().__init__()
+        if _act_name(mp_act) not in ACT_DICT or _act_name(mlp_act) not in ACT_DICT:
+            raise KeyError(f"unknown activation {mp_act!r}/{mlp_act!r}")  # ACT_DICT[...] at hscn.py:34,53
+        self.mp = _MessagePassingStack(num_features, mp_units, _act_name(mp_act))
+        out_channels = mp_units[-1]
+        self.mlp_act = _act_name(mlp_act)
+        self.mlp = nn.Sequential()
+        # hscn.py:50-53 keeps `out_channels` as the input width of every layer (the
+        # notebook's `out_chan = units` got inverted); restated literally.
+        for units in mlp_units:
+            self.mlp.append(Linear(out_channels, units))
+            self.mlp.append(nn.Identity())
+        self.mlp.append(Linear(out_channels, num_clusters))
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
+                node_ptr: Optional[Tensor] = None):
+        n = x.size(0)
+        rel = relation_of(edge_index, n, n)
+        x = self.mp(x.float(), rel, edge_weight)
+        s = x
+        layers = list(self.mlp)
+        for i, m in enumerate(layers):
+            if isinstance(m, Linear):
+                last = i == len(layers) - 1
+                s = m(s, act="identity" if last else self.mlp_act)
+        S, _, _, mc_loss, o_loss = mincut_pool_sparse(x, rel, s, node_ptr)
+        adj = to_dense_adj(edge_index, n) if node_ptr is None else None
+        return S, mc_loss, o_loss, adj
+
+
+def build_conv_relation(conv_type: str, hidden_channels: int, in_channels=None) -> nn.Module:
+    """hscn.py:117-125.  ``in_channels`` (extension) materialises the lazy ``-1``."""
+    if conv_type == "GAT":
+        dim = (-1, -1) if in_channels is None else (in_channels, in_channels)
+    else:
+        dim = -1 if in_channels is None else in_channels
+    return CONV_DICT[conv_type.lower()](dim, hidden_channels, add_self_loops=False, cached=False)
+
+
+class HSCN(nn.Module):
+    def __init__(self, lv_conv: str, ll_conv: str, vv_conv: str, activation: Callable, num_features: int,
+                 hidden_channels: int, num_classes: int, num_layers: int) -> None:
+        super().__init__()
+        self.activation = activation
+        self.convs = nn.ModuleList()
+        for layer in range(num_layers):
+            fin = num_features if layer == 0 else hidden_channels
+            conv = HeteroConv(
+                {
+                    LV: build_conv_relation(lv_conv, hidden_channels, fin),
+                    LL: build_conv_relation(ll_conv, hidden_channels, fin),
+                    VV: build_conv_relation(vv_conv, hidden_channels, fin),
+                },
+                aggr="sum",
+            )
+            self.convs.append(conv)
+        self.lin_1 = Linear(hidden_channels, hidden_channels)
+        self.lin_2 = Linear(hidden_channels, num_classes)
+
+    def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[Tuple[str, str, str], Tensor],
+                batch) -> Tensor:
+        relu = ACT_DICT["relu"]
+        for conv in self.convs:
+            x_dict = conv(x_dict, edge_index_dict)
+            x_dict = {key: relu(x) for key, x in x_dict.items()}           # hscn.py:110 (hard-coded ReLU)
+        local = batch["local"]
+        size = getattr(batch, "num_graphs", None) or None
+        x = global_mean_pool(x_dict["local"], local.batch, size)           # hscn.py:111
+        name = _act_name(self.activation)
+        if name is not None:
+            x = self.lin_1(x, act=name)                                    # hscn.py:112 fused epilogue
+        else:
+            x = self.activation(self.lin_1(x))
+        return self.lin_2(x)                                               # hscn.py:113
+
+
+def build_hscn(model_cfg: HSCNConfig, num_features: int, num_classes: int) -> HSCN:
+    return HSCN(
+        model_cfg.lv_conv_type,
+        model_cfg.ll_conv_type,
+        model_cfg.vv_conv_type,
+        ACT_DICT[model_cfg.activation.lower()],
+        num_features,
+        model_cfg.hidden_channels,
+        num_classes,
+        model_cfg.num_layers,
+    )

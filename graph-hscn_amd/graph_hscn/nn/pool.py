@@ -1,0 +1,85 @@
+"""Pooling / coarsening functions with the torch_geometric signatures the
+reference imports (model/hscn.py:6-14; train/train_clustering.py:6)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from .. import _hip
+from .._hip import call, ptr, stream
+from ..structure import CSR, Relation, build_csr, relation_of, segments_from_batch
+from . import functional as Fh
+
+
+def global_mean_pool(x: Tensor, batch: Optional[Tensor], size: Optional[int] = None,
+                     ptr_: Optional[Tensor] = None) -> Tensor:
+    """PyG global_mean_pool (model/hscn.py:111).  ``size=None`` reads
+    ``batch.max()+1`` from the device (one sync), like the reference."""
+    if batch is None:
+        batch = torch.zeros(x.size(0), dtype=torch.int64, device=x.device)
+        size = 1
+    seg = segments_from_batch(batch, size)
+    return Fh.SegmentMeanFn.apply(x, seg, batch.contiguous(), False)
+
+
+def to_dense_adj(edge_index: Tensor, max_num_nodes: Optional[int] = None) -> Tensor:
+    """PyG to_dense_adj without batch / edge_attr (model/hscn.py:61):
+    ``adj[0, row, col] += 1`` -> ``[1, N, N]``.  ``N`` defaults to
+    ``edge_index.max()+1`` (one sync, as in PyG)."""
+    N = int(edge_index.max().item()) + 1 if max_num_nodes is None else int(max_num_nodes)
+    adj = torch.zeros(N, N, dtype=torch.float32, device=edge_index.device)
+    E = edge_index.size(1)
+    call("hscn_to_dense_adj", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()), E, N,
+         ptr(adj), stream())
+    return adj.view(1, N, N)
+
+
+def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor] = None, num_nodes: Optional[int] = None,
+             improved: bool = False, add_self_loops: bool = True,
+             dtype: torch.dtype = torch.float32) -> Tuple[Tensor, Tensor]:
+    """PyG gcn_norm (train/train_clustering.py:37-42).
+
+    The self-loop bookkeeping (existing loops move to the tail block keeping
+    their weight, missing ones are appended with weight 1) is index plumbing on
+    the device; degrees and the symmetric normalisation run in
+    ``hscn_gcn_norm_weights`` with the reference's summation order."""
+    if num_nodes is None:
+        num_nodes = int(edge_index.max().item()) + 1
+    N = int(num_nodes)
+    dev = edge_index.device
+    fill = 2.0 if improved else 1.0
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype, device=dev)
+    if add_self_loops:
+        mask = edge_index[0] != edge_index[1]
+        loop_attr = torch.full((N,), fill, dtype=edge_weight.dtype, device=dev)
+        inv = ~mask
+        loop_attr[edge_index[0][inv]] = edge_weight[inv]
+        loops = torch.arange(N, dtype=torch.int64, device=dev)
+        edge_index = torch.cat([edge_index[:, mask], loops.unsqueeze(0).repeat(2, 1)], 1).contiguous()
+        edge_weight = torch.cat([edge_weight[mask], loop_attr], 0).contiguous()
+    csr = build_csr(edge_index[1], edge_index[0], N, N)
+    dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+    w = torch.empty(max(edge_index.size(1), 1), dtype=torch.float32, device=dev)
+    call("hscn_gcn_norm_weights", ptr(csr.rowptr), ptr(csr.col), ptr(csr.eid), ptr(edge_weight.contiguous()),
+         N, ptr(dinv), ptr(w), stream())
+    return edge_index, w[: edge_index.size(1)]
+
+
+def mincut_pool_sparse(x: Optional[Tensor], edge_index: Union[Tensor, Relation], s: Tensor,
+                       node_ptr: Optional[Tensor] = None):
+    """dense_mincut_pool semantics evaluated on the edge list:
+    ``A = sum_e E[row_e, col_e]`` is never densified.  ``node_ptr`` (int32
+    ``[G+1]``) splits a block-diagonal batch into graphs; losses are the mean over
+    graphs, exactly dense_mincut_pool's mean over its batch dimension.
+
+    Returns ``(S, pooled_x [G,K,F], pooled_adj [G,K,K], mincut_loss, ortho_loss)``."""
+    n = s.size(0)
+    rel = edge_index if isinstance(edge_index, Relation) else relation_of(edge_index, n, n)
+    if node_ptr is None:
+        node_ptr = torch.tensor([0, n], dtype=torch.int32, device=s.device)
+    G = int(node_ptr.numel()) - 1
+    S, losses, px, padj = Fh.MinCutSparseFn.apply(s, x, rel, node_ptr.to(torch.int32).contiguous(), G)
+    return S, px, padj, losses[0], losses[1]

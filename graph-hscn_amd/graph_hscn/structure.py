@@ -1,0 +1,140 @@
+"""Device-side graph structure for the hot-path kernels.
+
+PyG's MessagePassing gathers by ``edge_index[0]`` and scatters by
+``edge_index[1]`` on every call (reference model/hscn.py:32,40,85-93).  The HIP
+kernels instead walk a CSR keyed by the target node, built once per
+``edge_index`` tensor on the device (stable: a row keeps its edges in edge
+order, the order torch's CPU ``index_add_`` sums in) and cached for the layers
+and steps that reuse the same tensor.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _hip
+
+
+@dataclass
+class CSR:
+    rowptr: Tensor   # int32 [num_rows+1]
+    col: Tensor      # int32 [max(E,1)]
+    eid: Tensor      # int32 [max(E,1)]  original edge number of each slot
+    num_rows: int
+    num_cols: int
+    num_edges: int
+    flag: Tensor     # int32 [1]; 1 if an edge was out of range and skipped
+
+    def check(self) -> None:
+        """Synchronising validity check (out-of-range indices)."""
+        if int(self.flag.item()) != 0:
+            raise IndexError("edge_index holds node ids outside [0, num_nodes)")
+
+
+def build_csr(key: Tensor, other: Tensor, num_rows: int, num_cols: int) -> CSR:
+    """COO(int64) -> CSR(int32) through hscn_csr_build."""
+    if key.dtype != torch.int64 or other.dtype != torch.int64:
+        raise TypeError("edge_index must be int64")
+    dev = key.device
+    E = int(key.numel())
+    key = key.contiguous()
+    other = other.contiguous()
+    rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = _hip.lib()
+    ws_bytes = int(L.hscn_csr_workspace_bytes(E, num_rows))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _hip.call("hscn_csr_build", _hip.ptr(key) if E else None, _hip.ptr(other) if E else None, E, num_rows,
+              num_cols, _hip.ptr(rowptr), _hip.ptr(col), _hip.ptr(eid), _hip.ptr(flag), _hip.ptr(ws),
+              ws_bytes, _hip.stream())
+    return CSR(rowptr, col, eid, num_rows, num_cols, E, flag)
+
+
+class Relation:
+    """One edge type ``src -> dst``: forward CSR (keyed by target), and lazily
+    the transposed CSR (keyed by source), cross positions and GCN degree norm."""
+
+    def __init__(self, edge_index: Tensor, num_src: int, num_dst: int):
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("edge_index must be [2, E]")
+        self.edge_index = edge_index
+        self.num_src = int(num_src)
+        self.num_dst = int(num_dst)
+        self.num_edges = int(edge_index.size(1))
+        self.csr = build_csr(edge_index[1], edge_index[0], self.num_dst, self.num_src)
+        self._csr_t: Optional[CSR] = None
+        self._pos_t: Optional[Tensor] = None
+        self._dinv: Optional[Tensor] = None
+
+    @property
+    def csr_t(self) -> CSR:
+        if self._csr_t is None:
+            self._csr_t = build_csr(self.edge_index[0], self.edge_index[1], self.num_src, self.num_dst)
+        return self._csr_t
+
+    @property
+    def pos_t(self) -> Tensor:
+        """CSR slot of the edge stored at each transposed-CSR slot."""
+        if self._pos_t is None:
+            E = self.num_edges
+            dev = self.edge_index.device
+            inv = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            pos = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            _hip.call("hscn_csr_cross_positions", _hip.ptr(self.csr.eid), _hip.ptr(self.csr_t.eid), E,
+                      _hip.ptr(inv), _hip.ptr(pos), _hip.stream())
+            self._pos_t = pos
+        return self._pos_t
+
+    @property
+    def dinv(self) -> Tensor:
+        """PyG gcn_norm degree term for unit weights, no self loops: in-degree^-1/2."""
+        if self._dinv is None:
+            d = torch.empty(max(self.num_dst, 1), dtype=torch.float32, device=self.edge_index.device)
+            _hip.call("hscn_gcn_dinv", _hip.ptr(self.csr.rowptr), self.num_dst, _hip.ptr(d), _hip.stream())
+            self._dinv = d
+        return self._dinv
+
+    def check(self) -> None:
+        self.csr.check()
+
+
+_CACHE: "OrderedDict[Tuple, Relation]" = OrderedDict()
+_CACHE_MAX = 64
+
+
+def relation_of(edge_index: Tensor, num_src: int, num_dst: int, cache: bool = True) -> Relation:
+    """Structure for ``edge_index``; cached per tensor (pointer, shape, version) so
+    the L layers of one forward and repeated epochs over the same batch build it once."""
+    if not cache:
+        return Relation(edge_index, num_src, num_dst)
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
+           int(num_src), int(num_dst))
+    rel = _CACHE.get(key)
+    if rel is not None and rel.edge_index is edge_index:
+        _CACHE.move_to_end(key)
+        return rel
+    rel = Relation(edge_index, num_src, num_dst)
+    _CACHE[key] = rel
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)
+    return rel
+
+
+def clear_cache() -> None:
+    _CACHE.clear()
+
+
+def segments_from_batch(batch: Tensor, num_segments: Optional[int] = None) -> CSR:
+    """CSR over graphs from a PyG ``batch`` vector (any order): row g lists the
+    nodes of graph g.  ``num_segments=None`` reads ``batch.max()+1`` (one sync),
+    as global_mean_pool does."""
+    if num_segments is None:
+        num_segments = int(batch.max().item()) + 1 if batch.numel() else 0
+    node = torch.arange(batch.numel(), dtype=torch.int64, device=batch.device)
+    return build_csr(batch, node, int(num_segments), int(batch.numel()))

@@ -1,0 +1,220 @@
+/*
+ * hscn.h -- C ABI of the MI355X (gfx950) hot path of Graph-HSCN.
+ *
+ * The reference (camille-004/Graph-HSCN) has no FFI layer: its hot path is
+ * Python that calls un-vendored torch_geometric / torch_scatter operators
+ * (reference graph_hscn/model/hscn.py:6-14).  This header is the boundary a
+ * replacement shared library must export; every entry point names the
+ * reference call site (file:line under /root/reference) whose arithmetic it
+ * replaces.  The Python mirror in graph-hscn_amd/graph_hscn binds it with
+ * ctypes.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the parameter name ends in _host;
+ *   - the caller allocates every output and workspace; nothing is allocated,
+ *     freed or synchronised inside (safe under hipGraph stream capture);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, a positive hipError_t from the launch, or a
+ *     negative HSCN_E_* for bad arguments; never throws;
+ *   - node features are row-major fp32 [rows, width]; CSR indices are int32,
+ *     COO inputs are int64 [2,E] as torch_geometric stores them;
+ *   - stateless and re-entrant; no global handles;
+ *   - all reductions are ordered: results are bitwise reproducible run to run
+ *     (no floating-point atomics anywhere).
+ */
+#ifndef HSCN_H
+#define HSCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSCN_ABI_VERSION 1
+
+#define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
+#define HSCN_E_WORKSPACE (-2) /* workspace too small */
+#define HSCN_E_UNSUPPORTED (-3)
+
+/* activation codes (reference graph_hscn/config/config.py:13-18 ACT_DICT) */
+#define HSCN_ACT_IDENTITY 0
+#define HSCN_ACT_RELU 1
+#define HSCN_ACT_ELU 2
+#define HSCN_ACT_TANH 3
+
+int hscn_abi_version(void);
+const char* hscn_strerror(int code);
+
+/* ------------------------------------------------------------------------- *
+ * Graph structure: COO(int64) -> CSR(int32), stable.
+ * Replaces the per-call index bookkeeping inside PyG MessagePassing.propagate
+ * (gather by edge_index[0], scatter by edge_index[1]) for every conv at
+ * reference model/hscn.py:32,40,85-93.
+ *   key[e]   : row of edge e in the CSR being built (target for a forward
+ *              CSR, source for the transposed one)
+ *   other[e] : column stored for edge e
+ * Rows keep their edges in ascending e (the order torch's CPU index_add_
+ * accumulates in).  eid[p] is the original edge number of CSR slot p.
+ * Edges whose key/other fall outside [0,num_rows)/[0,num_cols) are skipped and
+ * flag[0] is set to 1 (flag may be NULL).
+ * ------------------------------------------------------------------------- */
+size_t hscn_csr_workspace_bytes(int64_t num_edges, int64_t num_rows);
+int hscn_csr_build(const int64_t* key, const int64_t* other, int64_t num_edges,
+                   int64_t num_rows, int64_t num_cols,
+                   int32_t* rowptr /*[num_rows+1]*/, int32_t* col /*[E]*/, int32_t* eid /*[E]*/,
+                   int32_t* flag /*[1] or NULL*/, void* workspace, size_t workspace_bytes, void* stream);
+
+/* inv_pos[eid[p]] = p  and  pos_t[q] = inv_pos[eid_t[q]]: CSR slot of the edge
+ * at slot q of the transposed CSR (used by backward passes that stored
+ * per-edge values in forward-CSR order). */
+int hscn_csr_cross_positions(const int32_t* eid, const int32_t* eid_t, int64_t num_edges,
+                             int32_t* inv_pos_scratch /*[E]*/, int32_t* pos_t /*[E]*/, void* stream);
+
+/* PyG gcn_norm(add_self_loops=False) degree part, unit edge weights
+ * (reference model/hscn.py:88-93 via GCNConv): dinv[i] = indeg(i)^-1/2, 0 if
+ * indeg(i)==0, with indeg read off rowptr. */
+int hscn_gcn_dinv(const int32_t* rowptr, int64_t num_rows, float* dinv, void* stream);
+
+/* PyG gcn_norm with explicit edge weights (reference
+ * train/train_clustering.py:37-42): deg[i] = sum of w over CSR row i in edge
+ * order; dinv = deg^-1/2 (inf -> 0); w_norm[e] = dinv[src]*w[e]*dinv[dst].
+ * rowptr/col/eid: CSR keyed by target. */
+int hscn_gcn_norm_weights(const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                          const float* w /*[E] by edge id, or NULL = ones*/, int64_t num_rows,
+                          float* dinv_scratch /*[num_rows]*/, float* w_norm /*[E] by edge id*/, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dense feature transform  y = act( x W^T + b  [+ x2 W2^T] ), optional row
+ * dot a[r] = sum_o (x W^T)[r,o] * att[o]  (pre-bias, pre-activation).
+ * Replaces torch_geometric.nn.Linear inside GraphConv/GCNConv/GATConv and the
+ * head (reference model/hscn.py:51,54,99,100,112-113) and GATConv's
+ * (x*att).sum(-1).
+ *   w_layout 0: W is [out,in] (nn.Linear layout);  1: W is [in,out].
+ * ------------------------------------------------------------------------- */
+int hscn_linear_fwd(const float* x, const float* W, const float* bias /*or NULL*/,
+                    const float* x2 /*or NULL*/, const float* W2 /*or NULL*/,
+                    const float* att /*[out] or NULL*/, float* a_out /*[rows] or NULL*/,
+                    float* y, int64_t rows, int in_f, int out_f, int w_layout, int act, void* stream);
+
+/* gy <- gy * act'(y) in place is NOT done here; see hscn_act_bwd.
+ * gW[out,in] = sum_r gy[r,:]^T x[r,:],  gb[out] = sum_r gy[r,:]  (either may be
+ * NULL).  Two ordered stages through `partials`
+ * (hscn_linear_bwd_w_workspace_bytes). */
+size_t hscn_linear_bwd_w_workspace_bytes(int64_t rows, int in_f, int out_f);
+int hscn_linear_bwd_w(const float* gy, const float* x, float* gW, float* gb,
+                      int64_t rows, int in_f, int out_f, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = act(x) elementwise (reference config/config.py:13-18 ACT_DICT; the
+ * inter-layer ReLU at model/hscn.py:110 when it is not fused into a conv). */
+int hscn_act_fwd(const float* x, float* y, int64_t count, int act, void* stream);
+
+/* g[r,:] = gy[r,:] * act'(y[r,:]) using the forward OUTPUT y (relu: y>0;
+ * elu: y>0 ? 1 : y+1; tanh: 1-y^2).  g may alias gy. */
+int hscn_act_bwd(const float* gy, const float* y, float* g, int64_t count, int act, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a12  GCNConv propagate, unit weights, no self loops
+ * (reference model/hscn.py:88-93):
+ *   out[i,:] = act( sum_{p in row i} (dinv_c[col[p]] * dinv_r[i]) * h[col[p],:]  + bias
+ *                   [+ out_prev[i,:] if accumulate] )
+ * summed in slot order with separately rounded multiply and add (the CPU
+ * reference's index_add_ order).  The backward w.r.t. h is the same entry
+ * point on the transposed CSR with bias=NULL, act=identity.
+ * ------------------------------------------------------------------------- */
+int hscn_spmm_csr_gcn(const int32_t* rowptr, const int32_t* col,
+                      const float* dinv_r /*[num_rows]*/, const float* dinv_c /*[num_cols]*/,
+                      const float* h, const float* bias /*or NULL*/, float* out,
+                      int64_t num_rows, int width, int accumulate, int act, void* stream);
+
+/* a3  GraphConv propagate with per-edge weights (reference model/hscn.py:32,40;
+ * SURVEY.md A.2): out[i,:] = sum_{p in row i} w[eid[p]] * x[col[p],:]
+ * (w NULL = unit weights; eid NULL = weights already in slot order). */
+int hscn_spmm_csr_weighted(const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                           const float* w, const float* x, float* out,
+                           int64_t num_rows, int width, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a13  GATConv (heads=1, bipartite, add_self_loops=False) attention part
+ * (reference model/hscn.py:85-87).  CSR keyed by target v:
+ *   e_p    = leaky_relu(a_src[col[p]] + a_dst[v], slope)
+ *   alpha_p= exp(e_p - max_row) / (sum_row exp(e_p - max_row) + 1e-16)
+ *   out[v,:] = act( sum_p alpha_p * h_src[col[p],:] + bias [+ out_prev[v,:]] )
+ * alpha (slot order) is kept for the backward.
+ * ------------------------------------------------------------------------- */
+int hscn_gat_segment_fwd(const int32_t* rowptr, const int32_t* col,
+                         const float* a_src, const float* a_dst, const float* h_src,
+                         const float* bias /*or NULL*/, float* alpha /*[E]*/, float* out,
+                         int64_t num_dst, int width, float slope, int accumulate, int act, void* stream);
+
+/* Backward, target side: given g = dL/d(pre-activation out) [num_dst,width]
+ *   g_pre[p]  = dL/d(a_src[col[p]] + a_dst[v])   (slot order)
+ *   g_a_dst[v]= sum_p g_pre[p] */
+int hscn_gat_segment_bwd_dst(const int32_t* rowptr, const int32_t* col,
+                             const float* a_src, const float* a_dst, const float* h_src,
+                             const float* alpha, const float* g,
+                             float* g_pre /*[E]*/, float* g_a_dst /*[num_dst]*/,
+                             int64_t num_dst, int width, float slope, void* stream);
+
+/* Backward, source side over the transposed CSR (keyed by source j):
+ *   g_a_src[j]   = sum_q g_pre[pos_t[q]]
+ *   g_h_src[j,:] = sum_q alpha[pos_t[q]] * g[col_t[q],:]  +  g_a_src[j] * att_src[:] */
+int hscn_gat_segment_bwd_src(const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                             const float* alpha, const float* g_pre, const float* g,
+                             const float* att_src /*[width]*/,
+                             float* g_a_src /*[num_src]*/, float* g_h_src /*[num_src,width]*/,
+                             int64_t num_src, int width, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a14  global_mean_pool (reference model/hscn.py:111).
+ * Segments given as CSR over graphs: out[g,:] = mean_{p in seg g} x[node[p],:]
+ * (node NULL = identity, i.e. sorted batch vector with ptr = rowptr);
+ * empty segments give 0.  Backward: g_x[i,:] = g_out[batch[i],:] / count. */
+int hscn_segment_mean_fwd(const int32_t* rowptr, const int32_t* node, const float* x, float* out,
+                          int64_t num_segments, int width, void* stream);
+int hscn_segment_mean_bwd(const int32_t* rowptr, const int64_t* batch /*[num_nodes]*/, const float* g_out,
+                          float* g_x, int64_t num_nodes, int width, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a6  dense_mincut_pool on the sparse (edge list) route
+ * (reference model/hscn.py:61-63).  A = sum_e E[row_e, col_e]
+ * is never densified: tr(S^T A S) = sum_e s_row . s_col,
+ * tr(S^T D S) = sum_i d_i |s_i|^2, d_i = out-degree of i in the edge list.
+ * Graph g owns nodes [node_ptr[g], node_ptr[g+1]).  CSR keyed by edge ROW.
+ * Per graph outputs (any of pooled_x / pooled_adj may be NULL):
+ *   S        [N,K]   softmax(logits)                 (hscn.py:64 first return)
+ *   stats    [G,4]   {num, den, |S^T S|_F, ortho_g}
+ *   ss       [G,K,K] S^T S
+ *   pooled_x [G,K,Fx] S^T X                          (A.4 `out`)
+ *   pooled_adj[G,K,K] normalised S^T A S (zero diagonal, d^-1/2 scaling)
+ *   losses   [2]     {mean_g(-num/den), mean_g(ortho_g)}
+ * ------------------------------------------------------------------------- */
+int hscn_mincut_sparse_fwd(const float* logits, const float* x /*or NULL*/,
+                           const int32_t* rowptr, const int32_t* col, const int32_t* node_ptr,
+                           float* S, float* stats, float* ss, float* pooled_x, float* pooled_adj,
+                           float* losses, int64_t num_nodes, int64_t num_graphs, int K, int Fx, void* stream);
+
+/* dL/dlogits [N,K] given upstream scalars g_losses_host = {dL/dmincut, dL/dortho}
+ * passed BY VALUE (host floats).  rowptr/col keyed by ROW, rowptr_t/col_t keyed by COL. */
+int hscn_mincut_sparse_bwd(const float* S, const float* stats, const float* ss,
+                           const int32_t* rowptr, const int32_t* col,
+                           const int32_t* rowptr_t, const int32_t* col_t, const int32_t* node_ptr,
+                           const float* g_losses /*[2] device*/, float* g_logits,
+                           int64_t num_nodes, int64_t num_graphs, int K, void* stream);
+
+/* a7  cluster assignment (reference train/train_clustering.py:68):
+ * ids[i] = first index of the row maximum of S[i,:]. */
+int hscn_assign_argmax(const float* S, int64_t* ids, int64_t num_nodes, int K, void* stream);
+
+/* a5  to_dense_adj (reference model/hscn.py:61): adj must be
+ * zero-filled by the caller's stream order; adj[row_e*n + col_e] += 1. */
+int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t num_edges, int64_t n,
+                      float* adj /*[n,n]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSCN_H */
