@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Graph-HSCN hot-path benchmark on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = HSCN forward + criterion + backward over one Peptides-func-shaped
+batch of 128 heterogeneous graphs per GPU (BASELINE.json configs[1]: K=16
+clusters, hidden 16, 3 layers, 10 classes), inputs resident in HBM, including
+the per-batch COO->CSR structure build.  Weak scaling: every rank owns its own
+128-graph shard; gradients are all-reduced (RCCL) as one flat buffer per step.
+Prints ONE JSON line on rank 0 (contract in the task statement) with the
+`roofline` of the local->local SpMM kernel and a `cpu_baseline` (the CPU oracle
+= restatement of the reference's PyG path, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "graph-hscn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+WORKLOADS = {
+    # name: (shape, B per GPU, K clusters, classes, loss)
+    "peptides_func": ("peptides_func", 128, 16, 10, "cross_entropy"),
+    "peptides_struct": ("peptides_struct", 32, 32, 11, "l1"),
+    "pascalvoc_sp": ("pascalvoc_sp", 128, 64, 21, "cross_entropy"),
+    "pcqm_contact": ("pcqm_contact", 256, 16, 1, "l1"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="peptides_func", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default: the workload's)")
+    ap.add_argument("--hidden", type=int, default=16)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+                    help="graph: the step (structure build + fwd + loss + bwd) is replayed as one hipGraph")
+    ap.add_argument("--structure", default="per-step", choices=["per-step", "cached"],
+                    help="per-step: COO->CSR build is inside every timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_hetero_batch(workload, B, K, seed, dev):
+    """Synthetic graphs -> cluster ids from a seeded random-weight SCN on the HIP
+    path -> generate_hetero_data transform -> one collated batch on the device."""
+    from graph_hscn.data import Batch, HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import SCN
+    from graph_hscn.nn.pool import gcn_norm
+    from graph_hscn import _hip
+
+    graphs = make_dataset(workload, B, seed=seed)
+    big = Batch.from_data_list(graphs)
+    torch.manual_seed(1234 + seed)
+    scn = SCN([16], "elu", graphs[0].num_features, K).to(dev)
+    with torch.no_grad():
+        ei, ew = gcn_norm(big.edge_index.to(dev), None, big.num_nodes, add_self_loops=True)
+        S, _, _, _ = scn(big.x.to(dev).float(), ei, ew, node_ptr=big.ptr.to(dev).to(torch.int32))
+        ids = torch.empty(big.num_nodes, dtype=torch.int64, device=dev)
+        _hip.call("hscn_assign_argmax", _hip.ptr(S), _hip.ptr(ids), big.num_nodes, K, _hip.stream())
+    ids = ids.cpu().numpy()
+    ptr = big.ptr.numpy()
+    hs = [hetero_from_clusters(g, ids[ptr[i]:ptr[i + 1]], K) for i, g in enumerate(graphs)]
+    hb = HeteroBatch.from_data_list(hs)
+    return hb, graphs, ids
+
+
+class KernelTimer:
+    """HIP-event timing of selected C-ABI launches on the stream they run on."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = []
+
+    def wrap(self, name, fn, *args):
+        if name not in self.names:
+            return fn(*args)
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        self.events.append((name, args, s, e))
+        return rc
+
+
+def cpu_baseline(hb, args, C, loss_fn, seconds):
+    """CPU oracle (PyG-order restatement of the reference path), fwd + loss + bwd
+    on the same batch, all host cores."""
+    from oracle import models as OM
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    F = hb["local"].x.size(1)
+    m = OM.HSCN("GAT", "GCN", "GCN", OM.ACT["relu"], F, args.hidden, C, args.layers)
+    xd = {k: v.clone() for k, v in hb.x_dict.items()}
+    ed = {k: v.clone() for k, v in hb.edge_index_dict.items()}
+    bl = hb["local"].batch.clone()
+    y = hb["local"].y.clone()
+    B = hb.num_graphs
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        out = m(xd, ed, bl, B)
+        loss, _ = OM.criterion(loss_fn, out, y)
+        loss.backward()
+
+    for _ in range(3):
+        step()
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    n = int(max(5, min(2000, seconds / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same {B}-graph batch (fwd+loss+bwd), torch {torch.__version__} "
+                      f"set_num_threads({cores}), CPU oracle = PyG-order restatement of the reference path",
+            "ms_per_step": 1e3 * dt / n}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from graph_hscn import _hip, structure
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.distributed import FlatGradReducer
+    from graph_hscn.loss import criterion
+    from graph_hscn.model.hscn import HSCN
+
+    _hip.lib()
+    shape, B0, K, C, loss_fn = WORKLOADS[args.workload]
+    B = args.batch or B0
+    hb_host, graphs, _ = build_hetero_batch(shape, B, K, args.seed * 1000 + rank, dev)
+    hb = hb_host.to(dev)
+    y = hb["local"].y
+    F = hb["local"].x.size(1)
+    torch.manual_seed(0)  # identical replicas
+    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], F, args.hidden, C, args.layers).to(dev)
+    reducer = FlatGradReducer(model) if world > 1 else None
+    x_dict, ei_dict = hb.x_dict, hb.edge_index_dict
+
+    def fwd_bwd():
+        if args.structure == "per-step":
+            structure.clear_cache()
+        for p in model.parameters():
+            p.grad = None
+        pred = model(x_dict, ei_dict, hb)
+        loss, _ = criterion(loss_fn, pred, y)
+        loss.backward()
+        return loss
+
+    def step_eager():
+        loss = fwd_bwd()
+        if reducer is not None:
+            reducer.reduce(B, B * world)
+        return loss
+
+    graph = None
+    if args.mode == "graph":
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = fwd_bwd()
+
+        def step():
+            graph.replay()
+            if reducer is not None:
+                reducer.reduce(B, B * world)
+            return static_loss
+    else:
+        step = step_eager
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = 1e3 * dt / args.steps
+    value = B * world * args.steps / dt
+
+    # ---- roofline of the dominant HBM kernel (local->local SpMM), eager + HIP events ----
+    roofline = None
+    if rank == 0:
+        N = hb["local"].num_nodes
+        E = hb[("local", "to", "local")].edge_index.size(1)
+        H = args.hidden
+        timer = KernelTimer(["hscn_spmm_csr_gcn"])
+        orig_call = _hip.call
+
+        def timed_call(name, *a):
+            return timer.wrap(name, lambda *b: orig_call(name, *b), *a)
+
+        import graph_hscn.nn.functional as Fh
+        Fh.call = timed_call
+        nprof = max(5, min(50, args.steps))
+        for _ in range(nprof):
+            step_eager()
+        torch.cuda.synchronize()
+        Fh.call = orig_call
+        # args[7] = num_rows, args[8] = width of hscn_spmm_csr_gcn
+        ll = [s.elapsed_time(e) * 1e-3 for (_, a, s, e) in timer.events if a[7] == N and a[8] == H]
+        avg = float(np.mean(ll)) if ll else float("nan")
+        alg_bytes = 4 * (N + 1) + 4 * E + 4 * N + 8 * N * H   # rowptr + col + dinv + read h + write out
+        achieved = alg_bytes / avg / 1e9 if ll else None
+        roofline = {"bound": "hbm", "kernel": "k_spmm<4,0> (hscn_spmm_csr_gcn, local->local fwd+bwd)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                    "avg_launch_us": avg * 1e6, "launches_timed": len(ll)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(hb_host, args, C, loss_fn, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "graphs/sec (fwd+bwd) on Peptides-func batch=128" if args.workload == "peptides_func"
+            else f"graphs/sec (fwd+bwd) on {args.workload}",
+            "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Graph-HSCN stage C (HSCN fwd+loss+bwd) on {args.workload}-shaped graphs",
+                       "graphs_per_gpu": B, "global_batch": B * world, "num_clusters": K, "hidden": args.hidden,
+                       "layers": args.layers, "classes": C, "nodes_per_gpu": int(hb["local"].num_nodes),
+                       "ll_edges_per_gpu": int(hb[("local", "to", "local")].edge_index.size(1)),
+                       "virtual_nodes_per_gpu": int(hb["virtual"].num_nodes),
+                       "mode": args.mode, "structure_build": args.structure,
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

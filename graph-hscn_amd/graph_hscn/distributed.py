@@ -1,0 +1,113 @@
+"""Data-parallel execution of the hot path: one process per GPU, graphs sharded
+across ranks, one flat-buffer gradient all-reduce per optimizer step.
+
+The reference is single process (no torch.distributed anywhere),
+so this is new functionality, not a replacement.  Graphs of a batch are
+independent units (block-diagonal adjacency, per-graph virtual nodes and
+pooling), so the only exchange step is the gradient reduction: 3 306 - 159 381
+fp32 values (13 - 640 KB), a latency-bound message -- a single RCCL all-reduce
+of ONE contiguous buffer instead of one collective per parameter.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(sizes: Sequence[int], world_size: int) -> List[int]:
+    """Split graphs (given their node counts) into ``world_size`` contiguous
+    shards balanced by total nodes, not by graph count (Peptides n in [8, 444]).
+    Returns ``world_size + 1`` boundaries; every shard is non-empty when
+    ``len(sizes) >= world_size``."""
+    n = len(sizes)
+    if world_size <= 1:
+        return [0, n]
+    cs = [0]
+    for v in sizes:
+        cs.append(cs[-1] + int(v))
+    total = cs[-1]
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        g = bounds[-1]
+        # first boundary whose prefix sum is closest to the target
+        while g < n and abs(cs[g + 1] - target) <= abs(cs[g] - target):
+            g += 1
+        lo = bounds[-1] + 1 if n >= world_size else bounds[-1]
+        hi = n - (world_size - r) if n >= world_size else n
+        bounds.append(max(lo, min(g, hi)))
+    bounds.append(n)
+    return bounds
+
+
+def shard_list(items: Sequence, sizes: Sequence[int], rank: int, world_size: int) -> list:
+    b = shard_bounds(sizes, world_size)
+    return list(items[b[rank]: b[rank + 1]])
+
+
+class FlatGradReducer:
+    """All-reduce every gradient of ``module`` as one flat fp32 buffer.
+
+    ``reduce(local_weight)``: scales this rank's gradients by
+    ``local_weight / sum_r local_weight_r`` and sums across ranks, so that with
+    ``local_weight`` = number of graphs in the rank's shard the result equals the
+    gradient of the mean loss over the whole (unsharded) batch -- the reference's
+    ``criterion`` is a mean over B x C elements (loss.py:9,16)."""
+
+    def __init__(self, module: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.group = process_group
+        self._flat: Optional[torch.Tensor] = None
+        self._mask: Optional[List[bool]] = None
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _layout(self) -> List[bool]:
+        mask = [p.grad is not None for p in self.params]
+        if self._mask is None:
+            if dist.is_initialized() and self.world_size > 1:
+                dev = next((p.grad.device for p in self.params if p.grad is not None), torch.device("cpu"))
+                t = torch.tensor([1 if m else 0 for m in mask], dtype=torch.int32, device=dev)
+                lo, hi = t.clone(), t.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+                if not torch.equal(lo, hi):
+                    raise RuntimeError("ranks disagree on which parameters received gradients")
+            self._mask = mask
+        elif mask != self._mask:
+            raise RuntimeError("set of parameters with gradients changed between steps")
+        return mask
+
+    def reduce(self, local_weight: float = 1.0, total_weight: Optional[float] = None) -> None:
+        mask = self._layout()
+        grads = [p.grad for p, m in zip(self.params, mask) if m]
+        if not grads:
+            return
+        n = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
+            self._flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+        flat = self._flat
+        ws = self.world_size
+        if ws > 1 and total_weight is not None:
+            scale = float(local_weight) / float(total_weight)      # known up front: no host sync
+        elif ws > 1:
+            w = torch.tensor([float(local_weight)], dtype=torch.float64, device=flat.device)
+            dist.all_reduce(w, group=self.group)
+            scale = float(local_weight) / float(w.item())
+        else:
+            scale = 1.0
+        off = 0
+        for g in grads:
+            flat[off: off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
+        if ws > 1:
+            flat.mul_(scale)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off: off + g.numel()].view_as(g))
+            off += g.numel()
