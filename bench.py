@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: the step (structure build + fwd + loss + bwd) is replayed as one hipGraph")
+    ap.add_argument("--engine", default="auto", choices=["auto", "resident", "layered"],
+                    help="resident: one workgroup per graph, all layers in LDS; layered: one kernel per operator")
     ap.add_argument("--structure", default="per-step", choices=["per-step", "cached"],
                     help="per-step: COO->CSR build is inside every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -198,6 +200,7 @@ def main():
     F = hb["local"].x.size(1)
     torch.manual_seed(0)  # identical replicas
     model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], F, args.hidden, C, args.layers).to(dev)
+    model.engine = args.engine
     reducer = FlatGradReducer(model) if world > 1 else None
     x_dict, ei_dict = hb.x_dict, hb.edge_index_dict
 
@@ -258,35 +261,66 @@ def main():
     ms = 1e3 * dt / args.steps
     value = B * world * args.steps / dt
 
-    # ---- roofline of the dominant HBM kernel (local->local SpMM), eager + HIP events ----
+    # ---- roofline of the dominant kernel: eager steps, HIP events around its C-ABI launch ----
     roofline = None
     if rank == 0:
-        N = hb["local"].num_nodes
-        E = hb[("local", "to", "local")].edge_index.size(1)
-        H = args.hidden
-        timer = KernelTimer(["hscn_spmm_csr_gcn"])
+        import graph_hscn.engine as eng
+        import graph_hscn.nn.functional as Fh
+        N = int(hb["local"].num_nodes)
+        V = int(hb["virtual"].num_nodes)
+        E = int(hb[("local", "to", "local")].edge_index.size(1))
+        Evv = int(hb[("virtual", "to", "virtual")].edge_index.size(1))
+        H, L = args.hidden, args.layers
+        # SURVEY.md 8(d) algorithmic bytes, summed over the batch (fp32 values, int32 CSR indices):
+        ll_b = 4 * (N + B) + 4 * E + 4 * N + 8 * N * H          # rowptr + col + dinv + read h + write out
+        lv_b = 4 * N * H + 8 * N + 4 * V + 4 * V * H
+        vv_b = 8 * V * H + 4 * Evv
+        lin_b = 12 * N * H + 12 * V * H
+        used_resident = model.last_engine == "resident"
+        names = ["hscn_resident_fwd", "hscn_resident_bwd"] if used_resident else ["hscn_spmm_csr_gcn"]
+        timer = KernelTimer(names)
         orig_call = _hip.call
 
         def timed_call(name, *a):
             return timer.wrap(name, lambda *b: orig_call(name, *b), *a)
 
-        import graph_hscn.nn.functional as Fh
         Fh.call = timed_call
+        eng.call = timed_call
         nprof = max(5, min(50, args.steps))
         for _ in range(nprof):
             step_eager()
         torch.cuda.synchronize()
         Fh.call = orig_call
-        # args[7] = num_rows, args[8] = width of hscn_spmm_csr_gcn
-        ll = [s.elapsed_time(e) * 1e-3 for (_, a, s, e) in timer.events if a[7] == N and a[8] == H]
-        avg = float(np.mean(ll)) if ll else float("nan")
-        alg_bytes = 4 * (N + 1) + 4 * E + 4 * N + 8 * N * H   # rowptr + col + dinv + read h + write out
-        achieved = alg_bytes / avg / 1e9 if ll else None
-        roofline = {"bound": "hbm", "kernel": "k_spmm<4,0> (hscn_spmm_csr_gcn, local->local fwd+bwd)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                    "avg_launch_us": avg * 1e6, "launches_timed": len(ll)}
+        eng.call = orig_call
+
+        def avg_s(pred):
+            v = [s_.elapsed_time(e_) * 1e-3 for (nm, a, s_, e_) in timer.events if pred(nm, a)]
+            return (float(np.mean(v)), len(v)) if v else (float("nan"), 0)
+
+        if used_resident:
+            t_f, n_f = avg_s(lambda nm, a: nm == "hscn_resident_fwd")
+            t_b, n_b = avg_s(lambda nm, a: nm == "hscn_resident_bwd")
+            alg_f = L * (ll_b + lv_b + vv_b + lin_b)
+            alg_b = L * (ll_b + lin_b)     # the backward only walks the local->local relation (+ its transforms)
+            dom_fwd = t_f >= t_b
+            t, alg = (t_f, alg_f) if dom_fwd else (t_b, alg_b)
+            roofline = {"bound": "hbm",
+                        "kernel": "k_hscn_fwd (hscn_resident_fwd: all layers, 1 workgroup/graph)" if dom_fwd
+                        else "k_hscn_bwd + k_param_reduce (hscn_resident_bwd)",
+                        "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": alg, "avg_launch_us": t * 1e6,
+                        "launches_timed": n_f if dom_fwd else n_b,
+                        "fwd_us": t_f * 1e6, "bwd_us": t_b * 1e6,
+                        "fwd_algorithmic_bytes": alg_f, "bwd_algorithmic_bytes": alg_b,
+                        "note": "latency-bound at this batch: the whole working set is a few MB (SURVEY.md 8d)"}
+        else:
+            # args[7] = num_rows, args[8] = width of hscn_spmm_csr_gcn
+            t, n_l = avg_s(lambda nm, a: a[7] == N and a[8] == H)
+            roofline = {"bound": "hbm", "kernel": "k_spmm<4,0> (hscn_spmm_csr_gcn, local->local fwd+bwd)",
+                        "achieved": ll_b / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ll_b / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": ll_b, "avg_launch_us": t * 1e6, "launches_timed": n_l}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -304,7 +338,7 @@ def main():
                        "layers": args.layers, "classes": C, "nodes_per_gpu": int(hb["local"].num_nodes),
                        "ll_edges_per_gpu": int(hb[("local", "to", "local")].edge_index.size(1)),
                        "virtual_nodes_per_gpu": int(hb["virtual"].num_nodes),
-                       "mode": args.mode, "structure_build": args.structure,
+                       "mode": args.mode, "engine": model.last_engine, "structure_build": args.structure,
                        "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1,0 +1,674 @@
+// Graph-resident HSCN engine: one workgroup per graph, every layer in LDS.
+//
+// A batch of LRGB graphs is block-diagonal: graph g owns local nodes
+// [lptr[g], lptr[g+1]), virtual nodes [vptr[g], vptr[g+1]) and a contiguous slice
+// of each relation's edge list.  A Peptides graph (n <= 444, e <= ~1000, H = 16)
+// fits in a fraction of one CU's 160 KB LDS, so the whole HSCN forward
+// (reference model/hscn.py:102-114: L x HeteroConv{ll GCN, vv GCN, lv GAT} + ReLU,
+// mean pool, 2-layer head) runs in ONE launch with workgroup barriers only:
+//   COO slice -> stable CSR in LDS (LDS int atomics + rank by edge id)
+//   per layer: feature transform (W row in registers, X rows broadcast from LDS),
+//              ll gather-reduce, vv gather-reduce + lv segment softmax (wave per
+//              cluster, __shfl reductions), ReLU
+//   mean pool + head by wave 0.
+// HBM traffic is the algorithmic minimum: inputs once, per-layer local
+// activations once (kept for the backward), predictions.  The backward is the
+// mirror image (transposed CSR in LDS, per-graph parameter-gradient partials,
+// then one ordered reduction over graphs -- no float atomics).
+//
+// Numerics: same operation order as the layered kernels (spmm.hip / linear.hip):
+// k-ascending fmaf chains in the transforms, edge-order separately rounded
+// multiply/add in the gather-reduce.
+#include "hscn_common.h"
+
+namespace {
+
+constexpr int RT = 256;  // threads per workgroup
+constexpr int MAXL = 8;
+
+struct LayerP {
+  const float *W_ll, *b_ll, *W_vv, *b_vv, *W_src, *W_dst, *att_src, *att_dst, *b_gat;
+};
+
+struct FwdArgs {
+  const float* x_local;
+  const float* x_virtual;
+  const int64_t *ll_src, *ll_dst, *vv_src, *vv_dst, *lv_src, *lv_dst;
+  const int32_t *lptr, *vptr, *eptr_ll, *eptr_vv, *eptr_lv;
+  LayerP layer[MAXL];
+  const float *W1, *b1, *W2, *b2;
+  float *acts, *pooled, *z, *pred, *xv_out;
+  int32_t* flag;
+  int64_t N, V;
+  int F, L, C, head_act, max_n, max_v, max_ell, max_evv, compute_virtual;
+  float slope;
+};
+
+struct BwdArgs {
+  const float* x_local;
+  const int64_t *ll_src, *ll_dst;
+  const int32_t *lptr, *eptr_ll;
+  const float* W_ll[MAXL];
+  const float *W1, *W2;
+  const float *acts, *pooled, *z, *g_pred;
+  float* partials;  // [B][P]
+  int32_t* flag;
+  int64_t N;
+  int F, L, C, head_act, max_n, max_ell, P;
+};
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ---- workgroup inclusive scan of a[0..n) in LDS, in place -----------------------------
+__device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[RT/64+1]*/) {
+  const int per = (n + RT - 1) / RT;
+  const int b = threadIdx.x * per;
+  int s = 0;
+  for (int i = 0; i < per; ++i)
+    if (b + i < n) s += a[b + i];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int i = 0; i < w; ++i) off += wsum[i];
+  int run = off + incl - s;
+  __syncthreads();
+  for (int i = 0; i < per; ++i)
+    if (b + i < n) {
+      run += a[b + i];
+      a[b + i] = run;
+    }
+  __syncthreads();
+}
+
+// ---- stable CSR of one graph's edge slice, in LDS ------------------------------------------
+// rowptr[0..nrows], col[ne] = other - other_off, rows keep ascending edge order.
+// cursor: [nrows+1] ints, tmp: [ne] ints.  Edges leaving the graph's node ranges
+// are dropped and *flag is raised (the batch is then not block-diagonal).
+__device__ void build_csr_lds(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int e0, int ne,
+                              int key_off, int nrows, int other_off, int ncols, int* rowptr, int* col,
+                              int* cursor, int* tmp, int* wsum, int32_t* flag) {
+  for (int i = threadIdx.x; i <= nrows; i += RT) {
+    rowptr[i] = 0;
+    cursor[i] = 0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ne; e += RT) {
+    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
+    if (k < 0 || k >= nrows || o < 0 || o >= ncols) {
+      if (flag) atomicOr(flag, 2);
+    } else {
+      atomicAdd(&rowptr[k + 1], 1);
+    }
+  }
+  __syncthreads();
+  scan_inclusive_lds(rowptr, nrows + 1, wsum);
+  for (int e = threadIdx.x; e < ne; e += RT) {
+    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
+    if (k < 0 || k >= nrows || o < 0 || o >= ncols) continue;
+    const int p = atomicAdd(&cursor[k], 1);
+    tmp[rowptr[k] + p] = e;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ne; e += RT) {
+    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
+    if (k < 0 || k >= nrows || o < 0 || o >= ncols) continue;
+    const int s = rowptr[k], t = rowptr[k + 1];
+    int rank = 0;
+    for (int q = s; q < t; ++q) rank += (tmp[q] < e) ? 1 : 0;
+    col[s + rank] = o;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float* dinv) {
+  for (int i = threadIdx.x; i < n; i += RT) {
+    const int d = rowptr[i + 1] - rowptr[i];
+    dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
+  }
+}
+
+// ---- Y[n][H] = X[n][H(zero padded)] * W[H][fin]^T ; optional row dot with att ---------------
+template <int H>
+__device__ void lin_lds(const float* X, const float* __restrict__ Wg, int fin, float* Y, int n,
+                        const float* __restrict__ att, float* a_out) {
+  const int o = threadIdx.x % H, r0 = threadIdx.x / H;
+  constexpr int RS = RT / H;
+  float w[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) w[k] = k < fin ? Wg[o * fin + k] : 0.f;
+  const float at = att ? att[o] : 0.f;
+  for (int i = r0; i < n; i += RS) {
+    const float4* xr = reinterpret_cast<const float4*>(X + i * H);
+    float acc = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < H / 4; ++k4) {
+      const float4 x = xr[k4];
+      acc = fmaf(x.x, w[4 * k4 + 0], acc);
+      acc = fmaf(x.y, w[4 * k4 + 1], acc);
+      acc = fmaf(x.z, w[4 * k4 + 2], acc);
+      acc = fmaf(x.w, w[4 * k4 + 3], acc);
+    }
+    if (Y) Y[i * H + o] = acc;
+    if (att) {
+      float d = acc * at;
+#pragma unroll
+      for (int off = H >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      if (o == 0) a_out[i] = d;
+    }
+  }
+}
+
+// ---- Out[i] = act(sum_p (dc[col[p]]*dr[i]) * Hin[col[p]] + bias) ---------------------------------
+template <int H>
+__device__ void agg_gcn_lds(const int* rowptr, const int* col, const float* dr, const float* dc,
+                            const float* Hin, const float* __restrict__ bias, float* Out, int n, int relu,
+                            float* __restrict__ gout /* global rows or null */) {
+  constexpr int LPR = H / 4;
+  constexpr int RPB = RT / LPR;
+  const int rl = threadIdx.x / LPR, f = (threadIdx.x % LPR) * 4;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) b = *reinterpret_cast<const float4*>(bias + f);
+  for (int i = rl; i < n; i += RPB) {
+    const int s = rowptr[i], t = rowptr[i + 1];
+    const float di = dr[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = s; p < t; ++p) {
+      const int j = col[p];
+      const float w = mul_rn(dc[j], di);
+      const float4 v = *reinterpret_cast<const float4*>(Hin + j * H + f);
+      a.x = add_rn(a.x, mul_rn(w, v.x));
+      a.y = add_rn(a.y, mul_rn(w, v.y));
+      a.z = add_rn(a.z, mul_rn(w, v.z));
+      a.w = add_rn(a.w, mul_rn(w, v.w));
+    }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    if (relu) {
+      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(Out + i * H + f) = a;
+    if (gout) *reinterpret_cast<float4*>(gout + (size_t)i * H + f) = a;
+  }
+}
+
+// relu fmaxf(x,0) maps -0 -> +0 and NaN -> 0; apply_act(RELU) is v>0?v:0 (NaN -> 0): same results.
+
+template <int H>
+__global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int g = blockIdx.x;
+  const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
+  const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
+  const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
+  const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
+  const int el0 = A.eptr_lv[g], nel = A.eptr_lv[g + 1] - el0;
+  if (n > A.max_n || nv > A.max_v || ne > A.max_ell || nev > A.max_evv || nel > A.max_n || n < 0 || nv < 0) {
+    if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    return;
+  }
+  // ---- LDS carve --------------------------------------------------------------------
+  float* xa = reinterpret_cast<float*>(smem);              // [max_n][H] current local features
+  float* bh = xa + (size_t)A.max_n * H;                    // [max_n][H] transform output
+  float* xva = bh + (size_t)A.max_n * H;                   // [max_v][H]
+  float* xvb = xva + (size_t)A.max_v * H;                  // [max_v][H]
+  float* hv = xvb + (size_t)A.max_v * H;                   // [max_v][H]
+  float* a_s = hv + (size_t)A.max_v * H;                   // [max_n]
+  float* a_d = a_s + A.max_n;                              // [max_v]
+  float* dinv = a_d + A.max_v;                             // [max_n]
+  float* dinv_v = dinv + A.max_n;                          // [max_v]
+  float* vec = dinv_v + A.max_v;                           // [2*64] pooled / z
+  int* rowptr = reinterpret_cast<int*>(vec + 128);         // [max_n+1]
+  int* col = rowptr + A.max_n + 1;                         // [max_ell]
+  int* rowptr_lv = col + A.max_ell;                        // [max_v+1]
+  int* col_lv = rowptr_lv + A.max_v + 1;                   // [max_n]
+  int* rowptr_vv = col_lv + A.max_n;                       // [max_v+1]
+  int* col_vv = rowptr_vv + A.max_v + 1;                   // [max_evv]
+  int* cursor = col_vv + A.max_evv;                        // [max(max_n,max_v)+1]
+  const int maxrows = A.max_n > A.max_v ? A.max_n : A.max_v;
+  int* tmp = cursor + maxrows + 1;                         // [max(max_ell,max_n,max_evv)]
+  int maxe = A.max_ell > A.max_n ? A.max_ell : A.max_n;
+  maxe = maxe > A.max_evv ? maxe : A.max_evv;
+  int* wsum = tmp + maxe;                                  // [8]
+
+  // ---- structure ----------------------------------------------------------------------
+  build_csr_lds(A.ll_dst, A.ll_src, e0, ne, n0, n, n0, n, rowptr, col, cursor, tmp, wsum, A.flag);
+  dinv_from_rowptr(rowptr, n, dinv);
+  if (A.compute_virtual) {
+    build_csr_lds(A.lv_dst, A.lv_src, el0, nel, v0, nv, n0, n, rowptr_lv, col_lv, cursor, tmp, wsum, A.flag);
+    build_csr_lds(A.vv_dst, A.vv_src, ev0, nev, v0, nv, v0, nv, rowptr_vv, col_vv, cursor, tmp, wsum, A.flag);
+    dinv_from_rowptr(rowptr_vv, nv, dinv_v);
+  }
+  // ---- layer-0 inputs, zero padded to H ------------------------------------------------
+  const int F = A.F;
+  for (int idx = threadIdx.x; idx < n * H; idx += RT) {
+    const int i = idx / H, k = idx - i * H;
+    xa[idx] = k < F ? A.x_local[(size_t)(n0 + i) * F + k] : 0.f;
+  }
+  if (A.compute_virtual)
+    for (int idx = threadIdx.x; idx < nv * H; idx += RT) {
+      const int i = idx / H, k = idx - i * H;
+      xva[idx] = k < F ? A.x_virtual[(size_t)(v0 + i) * F + k] : 0.f;
+    }
+  __syncthreads();
+
+  for (int l = 0; l < A.L; ++l) {
+    const LayerP& P = A.layer[l];
+    const int fin = l == 0 ? F : H;
+    if (A.compute_virtual) {
+      // local -> virtual GAT: hs = lin_src(x_local), a_s; hd = lin_dst(x_virtual) only through a_d
+      lin_lds<H>(xa, P.W_src, fin, bh, n, P.att_src, a_s);
+      lin_lds<H>(xva, P.W_dst, fin, nullptr, nv, P.att_dst, a_d);
+      // virtual -> virtual GCN transform
+      lin_lds<H>(xva, P.W_vv, fin, hv, nv, nullptr, nullptr);
+      __syncthreads();
+      agg_gcn_lds<H>(rowptr_vv, col_vv, dinv_v, dinv_v, hv, P.b_vv, xvb, nv, 0, nullptr);
+      __syncthreads();
+      // segment softmax + weighted sum, one wave per cluster; added onto the vv output, then ReLU
+      {
+        constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
+        constexpr int S = 64 / LPR;
+        const int lane = threadIdx.x & 63, slot = lane / LPR, f = (lane % LPR) * 4;
+        for (int v = threadIdx.x >> 6; v < nv; v += RT / 64) {
+          const int s = rowptr_lv[v], t = rowptr_lv[v + 1];
+          const float ad = a_d[v];
+          float m = -INFINITY;
+          for (int p = s + lane; p < t; p += 64) m = fmaxf(m, leaky(a_s[col_lv[p]] + ad, A.slope));
+          m = wave_max(m);
+          float sum = 0.f;
+          for (int p = s + lane; p < t; p += 64) sum += expf(leaky(a_s[col_lv[p]] + ad, A.slope) - m);
+          sum = wave_sum(sum);
+          const float denom = sum + 1e-16f;
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int p = s + slot; p < t; p += S) {
+            const int j = col_lv[p];
+            const float al = expf(leaky(a_s[j] + ad, A.slope) - m) / denom;
+            const float4 hvv = *reinterpret_cast<const float4*>(bh + j * H + f);
+            acc.x = fmaf(al, hvv.x, acc.x);
+            acc.y = fmaf(al, hvv.y, acc.y);
+            acc.z = fmaf(al, hvv.z, acc.z);
+            acc.w = fmaf(al, hvv.w, acc.w);
+          }
+#pragma unroll
+          for (int off = 32; off >= LPR; off >>= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+            acc.w += __shfl_xor(acc.w, off, 64);
+          }
+          if (slot == 0) {
+            const float4 bg = *reinterpret_cast<const float4*>(P.b_gat + f);
+            float4 prev = *reinterpret_cast<const float4*>(xvb + v * H + f);
+            prev.x = fmaxf(prev.x + (acc.x + bg.x), 0.f);
+            prev.y = fmaxf(prev.y + (acc.y + bg.y), 0.f);
+            prev.z = fmaxf(prev.z + (acc.z + bg.z), 0.f);
+            prev.w = fmaxf(prev.w + (acc.w + bg.w), 0.f);
+            *reinterpret_cast<float4*>(xvb + v * H + f) = prev;
+          }
+        }
+      }
+      __syncthreads();
+      {  // swap virtual buffers
+        float* t_ = xva; xva = xvb; xvb = t_;
+      }
+    }
+    // local -> local GCN: transform into bh, gather-reduce back into xa (xa is dead after the transform)
+    lin_lds<H>(xa, P.W_ll, fin, bh, n, nullptr, nullptr);
+    __syncthreads();
+    agg_gcn_lds<H>(rowptr, col, dinv, dinv, bh, P.b_ll, xa, n, 1,
+                   A.acts + ((size_t)l * A.N + n0) * H);
+    __syncthreads();
+  }
+
+  if (A.compute_virtual && A.xv_out)
+    for (int idx = threadIdx.x; idx < nv * H; idx += RT) A.xv_out[(size_t)v0 * H + idx] = xva[idx];
+
+  // ---- global_mean_pool + head, wave 0 ---------------------------------------------------
+  if (threadIdx.x < 64) {
+    constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
+    constexpr int S = 64 / LPR;
+    const int lane = threadIdx.x, slot = lane / LPR, f = (lane % LPR) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = slot; i < n; i += S) {
+      const float4 v = *reinterpret_cast<const float4*>(xa + i * H + f);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= LPR; off >>= 1) {
+      acc.x += __shfl_xor(acc.x, off, 64);
+      acc.y += __shfl_xor(acc.y, off, 64);
+      acc.z += __shfl_xor(acc.z, off, 64);
+      acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    const float cnt = (float)(n > 0 ? n : 1);
+    if (slot == 0) {
+      vec[f + 0] = acc.x / cnt; vec[f + 1] = acc.y / cnt; vec[f + 2] = acc.z / cnt; vec[f + 3] = acc.w / cnt;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float* pooled = vec;
+    float* zz = vec + 64;
+    if (lane < H) {
+      A.pooled[(size_t)g * H + lane] = pooled[lane];
+      float acc = 0.f;
+      for (int k = 0; k < H; ++k) acc = fmaf(pooled[k], A.W1[lane * H + k], acc);
+      acc += A.b1[lane];
+      acc = apply_act(acc, A.head_act);
+      zz[lane] = acc;
+      A.z[(size_t)g * H + lane] = acc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float* zz = vec + 64;
+    for (int c = threadIdx.x; c < A.C; c += 64) {
+      float acc = 0.f;
+      for (int k = 0; k < H; ++k) acc = fmaf(zz[k], A.W2[c * H + k], acc);
+      A.pred[(size_t)g * A.C + c] = acc + A.b2[c];
+    }
+  }
+}
+
+// =============================== backward =====================================================
+template <int H>
+__global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int g = blockIdx.x;
+  const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
+  const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
+  float* part = A.partials + (size_t)g * A.P;
+  if (n > A.max_n || ne > A.max_ell || n < 0) {
+    if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    for (int i = threadIdx.x; i < A.P; i += RT) part[i] = 0.f;
+    return;
+  }
+  float* G = reinterpret_cast<float*>(smem);            // [max_n][H]  dL/d(layer output), then pre-activation grad
+  float* GH = G + (size_t)A.max_n * H;                  // [max_n][H]  dL/d(transform output)
+  float* X = GH + (size_t)A.max_n * H;                  // [max_n][H]  layer input
+  float* dinv = X + (size_t)A.max_n * H;                // [max_n]
+  float* vec = dinv + A.max_n;                          // [4*64]: g_pred | z | g_zpre | g_pool
+  float* red = vec + 256;                               // [RT] bias-gradient partials
+  int* rowptr_t = reinterpret_cast<int*>(red + RT);     // [max_n+1]  CSR keyed by SOURCE
+  int* col_t = rowptr_t + A.max_n + 1;                  // [max_ell]
+  int* cursor = col_t + A.max_ell;                      // [max_n+1]
+  int* tmp = cursor + A.max_n + 1;                      // [max_ell]
+  int* wsum = tmp + A.max_ell;                          // [8]
+
+  // in-degree (by target) -> dinv, through the cursor array
+  for (int i = threadIdx.x; i <= n; i += RT) cursor[i] = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < ne; e += RT) {
+    const int d = (int)(A.ll_dst[e0 + e] - n0), s = (int)(A.ll_src[e0 + e] - n0);
+    if (d >= 0 && d < n && s >= 0 && s < n) atomicAdd(&cursor[d], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += RT) {
+    const int d = cursor[i];
+    dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
+  }
+  __syncthreads();
+  build_csr_lds(A.ll_src, A.ll_dst, e0, ne, n0, n, n0, n, rowptr_t, col_t, cursor, tmp, wsum, A.flag);
+
+  // ---- head backward (wave 0) ---------------------------------------------------------------
+  float* gp = vec;         // g_pred [C<=64.. loop]
+  float* zz = vec + 64;    // z
+  float* gz = vec + 128;   // dL/d(lin_1 output, pre-activation)
+  float* gpool = vec + 192;
+  // partial layout: per layer {W_ll [H*fin], b_ll [H]}, then W1 [H*H], b1 [H], W2 [C*H], b2 [C]
+  int off_head = 0;
+  for (int l = 0; l < A.L; ++l) off_head += H * (l == 0 ? A.F : H) + H;
+  const int oW1 = off_head, ob1 = oW1 + H * H, oW2 = ob1 + H, ob2 = oW2 + A.C * H;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    if (lane < H) zz[lane] = A.z[(size_t)g * H + lane];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    // g_zpre[k] = (sum_c g_pred[c] W2[c][k]) * act'(z[k])
+    if (lane < H) {
+      float acc = 0.f;
+      for (int c = 0; c < A.C; ++c) acc = fmaf(A.g_pred[(size_t)g * A.C + c], A.W2[c * H + lane], acc);
+      gz[lane] = acc * act_grad_from_output(zz[lane], A.head_act);
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < A.C * H; idx += RT) {
+    const int c = idx / H, k = idx - c * H;
+    part[oW2 + idx] = A.g_pred[(size_t)g * A.C + c] * zz[k];
+  }
+  for (int c = threadIdx.x; c < A.C; c += RT) part[ob2 + c] = A.g_pred[(size_t)g * A.C + c];
+  for (int idx = threadIdx.x; idx < H * H; idx += RT) {
+    const int o = idx / H, k = idx - o * H;
+    part[oW1 + idx] = gz[o] * A.pooled[(size_t)g * H + k];
+  }
+  if (threadIdx.x < H) {
+    part[ob1 + threadIdx.x] = gz[threadIdx.x];
+    float acc = 0.f;
+    for (int o = 0; o < H; ++o) acc = fmaf(gz[o], A.W1[o * H + threadIdx.x], acc);
+    gpool[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  // dL/d x_L[i][f] = g_pool[f] / n
+  {
+    const float cnt = (float)(n > 0 ? n : 1);
+    for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = gpool[idx % H] / cnt;
+  }
+  __syncthreads();
+
+  int off = off_head;
+  for (int l = A.L - 1; l >= 0; --l) {
+    const int fin = l == 0 ? A.F : H;
+    off -= H * fin + H;
+    const int oW = off, ob = off + H * fin;
+    // ReLU mask from the saved layer output; layer input -> X (zero padded)
+    const float* y = A.acts + ((size_t)l * A.N + n0) * H;
+    for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = y[idx] > 0.f ? G[idx] : 0.f;
+    if (l == 0) {
+      for (int idx = threadIdx.x; idx < n * H; idx += RT) {
+        const int i = idx / H, k = idx - i * H;
+        X[idx] = k < fin ? A.x_local[(size_t)(n0 + i) * fin + k] : 0.f;
+      }
+    } else {
+      const float* xin = A.acts + ((size_t)(l - 1) * A.N + n0) * H;
+      for (int idx = threadIdx.x; idx < n * H; idx += RT) X[idx] = xin[idx];
+    }
+    __syncthreads();
+    // bias gradient: column sums of G, RT/H row chunks then ordered fold
+    {
+      const int f = threadIdx.x % H, c = threadIdx.x / H;
+      constexpr int CH = RT / H;
+      float s = 0.f;
+      for (int i = c; i < n; i += CH) s += G[i * H + f];
+      red[threadIdx.x] = s;
+    }
+    // dL/d(transform output) = A_hat^T G  (transposed CSR, edge order)
+    agg_gcn_lds<H>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, nullptr);
+    __syncthreads();
+    if (threadIdx.x < H) {
+      constexpr int CH = RT / H;
+      float s = 0.f;
+      for (int c = 0; c < CH; ++c) s += red[c * H + threadIdx.x];
+      part[ob + threadIdx.x] = s;
+    }
+    // weight gradient: gW[o][k] = sum_j GH[j][o] * X[j][k]
+    for (int idx = threadIdx.x; idx < H * fin; idx += RT) {
+      const int o = idx / fin, k = idx - o * fin;
+      float acc = 0.f;
+      for (int j = 0; j < n; ++j) acc = fmaf(GH[j * H + o], X[j * H + k], acc);
+      part[oW + idx] = acc;
+    }
+    // input gradient: G[j][k] = sum_o GH[j][o] * W[o][k]   (W is [H][fin], fin == H here)
+    if (l > 0) {
+      __syncthreads();  // everyone done reading G (bias sums) -- GH/X reads above do not touch G
+      const int k = threadIdx.x % H, r0 = threadIdx.x / H;
+      constexpr int RS = RT / H;
+      float w[H];
+#pragma unroll
+      for (int o = 0; o < H; ++o) w[o] = A.W_ll[l][o * H + k];
+      for (int j = r0; j < n; j += RS) {
+        const float4* gr = reinterpret_cast<const float4*>(GH + j * H);
+        float acc = 0.f;
+#pragma unroll
+        for (int o4 = 0; o4 < H / 4; ++o4) {
+          const float4 v = gr[o4];
+          acc = fmaf(v.x, w[4 * o4 + 0], acc);
+          acc = fmaf(v.y, w[4 * o4 + 1], acc);
+          acc = fmaf(v.z, w[4 * o4 + 2], acc);
+          acc = fmaf(v.w, w[4 * o4 + 3], acc);
+        }
+        G[j * H + k] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[p] = sum_g partials[g][p], g ascending
+__global__ void k_param_reduce(const float* __restrict__ partials, float* __restrict__ out, int B, int P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float s = 0.f;
+  for (int g = 0; g < B; ++g) s += partials[(size_t)g * P + p];
+  out[p] = s;
+}
+
+inline size_t fwd_lds_bytes(int H, int max_n, int max_v, int max_ell, int max_evv) {
+  const int maxrows = max_n > max_v ? max_n : max_v;
+  int maxe = max_ell > max_n ? max_ell : max_n;
+  maxe = maxe > max_evv ? maxe : max_evv;
+  size_t fl = (size_t)2 * max_n * H + (size_t)3 * max_v * H + max_n + max_v + max_n + max_v + 128;
+  size_t in = (size_t)(max_n + 1) + max_ell + (max_v + 1) + max_n + (max_v + 1) + max_evv + (maxrows + 1) + maxe + 8;
+  return (fl + in) * 4;
+}
+inline size_t bwd_lds_bytes(int H, int max_n, int max_ell) {
+  size_t fl = (size_t)3 * max_n * H + max_n + 256 + RT;
+  size_t in = (size_t)(max_n + 1) + max_ell + (max_n + 1) + max_ell + 8;
+  return (fl + in) * 4;
+}
+
+template <int H>
+int launch_fwd(const FwdArgs& A, int64_t B, hipStream_t st) {
+  const size_t lds = fwd_lds_bytes(H, A.max_n, A.max_v, A.max_ell, A.max_evv);
+  if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_hscn_fwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k_hscn_fwd<H><<<(unsigned)B, RT, lds, st>>>(A);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+template <int H>
+int launch_bwd(const BwdArgs& A, int64_t B, hipStream_t st) {
+  const size_t lds = bwd_lds_bytes(H, A.max_n, A.max_ell);
+  if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_hscn_bwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k_hscn_bwd<H><<<(unsigned)B, RT, lds, st>>>(A);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hscn_resident_supported(int F, int H, int L, int C, int max_n, int max_v, int max_ell, int max_evv) {
+  if (!(H == 16 || H == 32 || H == 64) || F < 1 || F > H || L < 1 || L > MAXL || C < 1) return 0;
+  if (max_n < 0 || max_v < 0 || max_ell < 0 || max_evv < 0) return 0;
+  if (fwd_lds_bytes(H, max_n, max_v, max_ell, max_evv) > 160 * 1024) return 0;
+  if (bwd_lds_bytes(H, max_n, max_ell) > 160 * 1024) return 0;
+  return 1;
+}
+
+int64_t hscn_resident_param_count(int F, int H, int L, int C) {
+  int64_t P = 0;
+  for (int l = 0; l < L; ++l) P += (int64_t)H * (l == 0 ? F : H) + H;
+  return P + (int64_t)H * H + H + (int64_t)C * H + C;
+}
+
+int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_t* ei_ll, int64_t E_ll,
+                      const int64_t* ei_vv, int64_t E_vv, const int64_t* ei_lv, int64_t E_lv,
+                      const int32_t* lptr, const int32_t* vptr, const int32_t* eptr_ll, const int32_t* eptr_vv,
+                      const int32_t* eptr_lv, int64_t N, int64_t V, int64_t B, int F, int H, int L, int C,
+                      int head_act, float slope, const void* const* layer_params_host /* L x 9 */,
+                      const float* W1, const float* b1, const float* W2, const float* b2, int max_n, int max_v,
+                      int max_ell, int max_evv, int compute_virtual, float* acts, float* pooled, float* z,
+                      float* pred, float* xv_out, int32_t* flag, void* stream_) {
+  if (B < 0 || N < 0 || V < 0) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (!hscn_resident_supported(F, H, L, C, max_n, max_v, max_ell, max_evv)) return HSCN_E_UNSUPPORTED;
+  if (!x_local || !lptr || !vptr || !eptr_ll || !eptr_vv || !eptr_lv || !layer_params_host || !W1 || !b1 ||
+      !W2 || !b2 || !acts || !pooled || !z || !pred)
+    return HSCN_E_BADARG;
+  if ((E_ll > 0 && !ei_ll) || (compute_virtual && ((E_vv > 0 && !ei_vv) || (E_lv > 0 && !ei_lv) || !x_virtual)))
+    return HSCN_E_BADARG;
+  FwdArgs A;
+  A.x_local = x_local; A.x_virtual = x_virtual;
+  A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
+  A.vv_src = ei_vv; A.vv_dst = ei_vv ? ei_vv + E_vv : nullptr;
+  A.lv_src = ei_lv; A.lv_dst = ei_lv ? ei_lv + E_lv : nullptr;
+  A.lptr = lptr; A.vptr = vptr; A.eptr_ll = eptr_ll; A.eptr_vv = eptr_vv; A.eptr_lv = eptr_lv;
+  for (int l = 0; l < L; ++l) {
+    const void* const* q = layer_params_host + (size_t)l * 9;
+    for (int k = 0; k < 9; ++k)
+      if (!q[k] && (compute_virtual || k < 2)) return HSCN_E_BADARG;
+    A.layer[l] = LayerP{(const float*)q[0], (const float*)q[1], (const float*)q[2], (const float*)q[3],
+                        (const float*)q[4], (const float*)q[5], (const float*)q[6], (const float*)q[7],
+                        (const float*)q[8]};
+  }
+  A.W1 = W1; A.b1 = b1; A.W2 = W2; A.b2 = b2;
+  A.acts = acts; A.pooled = pooled; A.z = z; A.pred = pred; A.xv_out = xv_out; A.flag = flag;
+  A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
+  A.max_n = max_n; A.max_v = max_v; A.max_ell = max_ell; A.max_evv = max_evv;
+  A.compute_virtual = compute_virtual; A.slope = slope;
+  hipStream_t st = hscn_stream(stream_);
+  switch (H) {
+    case 16: return launch_fwd<16>(A, B, st);
+    case 32: return launch_fwd<32>(A, B, st);
+    case 64: return launch_fwd<64>(A, B, st);
+  }
+  return HSCN_E_UNSUPPORTED;
+}
+
+int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                      const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
+                      const void* const* W_ll_host /* L */, const float* W1, const float* W2, const float* acts,
+                      const float* pooled, const float* z, const float* g_pred, int max_n, int max_ell,
+                      float* partials /*[B][P]*/, float* grads /*[P]*/, int32_t* flag, void* stream_) {
+  if (B < 0 || N < 0) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (!hscn_resident_supported(F, H, L, C, max_n, 0, max_ell, 0)) return HSCN_E_UNSUPPORTED;
+  if (!x_local || !lptr || !eptr_ll || !W_ll_host || !W1 || !W2 || !acts || !pooled || !z || !g_pred ||
+      !partials || !grads || (E_ll > 0 && !ei_ll))
+    return HSCN_E_BADARG;
+  BwdArgs A;
+  A.x_local = x_local; A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
+  A.lptr = lptr; A.eptr_ll = eptr_ll;
+  for (int l = 0; l < L; ++l) {
+    if (!W_ll_host[l]) return HSCN_E_BADARG;
+    A.W_ll[l] = (const float*)W_ll_host[l];
+  }
+  A.W1 = W1; A.W2 = W2; A.acts = acts; A.pooled = pooled; A.z = z; A.g_pred = g_pred;
+  A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
+  A.max_n = max_n; A.max_ell = max_ell; A.P = (int)hscn_resident_param_count(F, H, L, C);
+  hipStream_t st = hscn_stream(stream_);
+  int rc = HSCN_E_UNSUPPORTED;
+  switch (H) {
+    case 16: rc = launch_bwd<16>(A, B, st); break;
+    case 32: rc = launch_bwd<32>(A, B, st); break;
+    case 64: rc = launch_bwd<64>(A, B, st); break;
+  }
+  if (rc) return rc;
+  k_param_reduce<<<hscn_blocks(A.P, 256), 256, 0, st>>>(partials, grads, (int)B, A.P);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // extern "C"

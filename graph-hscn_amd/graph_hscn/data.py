@@ -175,6 +175,8 @@ class HeteroBatch(HeteroData):
             st.x = torch.cat([g[nt].x for g in graphs], 0)
             st.batch = torch.repeat_interleave(torch.arange(len(ns)), torch.as_tensor(ns))
             st.ptr = ptr
+            st.ptr32 = ptr.to(torch.int32)          # per-graph node ranges for the graph-resident kernels
+            st.max_nodes = int(max(ns)) if ns else 0
             st.num_nodes = int(ptr[-1])
             if all("y" in g[nt] and g[nt].y is not None for g in graphs):
                 st.y = torch.cat([g[nt].y if g[nt].y.dim() >= 2 else g[nt].y.view(1, -1) for g in graphs], 0)
@@ -183,6 +185,11 @@ class HeteroBatch(HeteroData):
             off = torch.stack([ptrs[s][:-1], ptrs[d][:-1]], 0)  # [2, B]
             out[et].edge_index = torch.cat(
                 [g[et].edge_index + off[:, i : i + 1] for i, g in enumerate(graphs)], 1)
+            es = [int(g[et].edge_index.size(1)) for g in graphs]
+            eptr = torch.zeros(len(es) + 1, dtype=torch.int32)
+            eptr[1:] = torch.cumsum(torch.as_tensor(es, dtype=torch.int64), 0).to(torch.int32)
+            out[et].ptr32 = eptr                    # edges of graph g are the slice [ptr32[g], ptr32[g+1])
+            out[et].max_edges = int(max(es)) if es else 0
         return out
 
     @property

@@ -1,0 +1,150 @@
+"""Graph-resident execution of HSCN.forward / backward (csrc/resident.hip).
+
+``HSCN.forward`` (reference model/hscn.py:102-114) normally runs L x 3 relation
+convs, ReLUs, a pool and two linears as separate operators.  For block-diagonal
+batches whose graphs fit one CU's LDS (every LRGB molecule / superpixel graph at
+the reference's widths) the whole forward is ONE launch with a workgroup per
+graph, and the backward is one launch plus an ordered per-parameter reduction
+over graphs.  This module decides whether a call qualifies and wraps the two C
+entry points in a single autograd Function.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _hip
+from ._hip import ACT, call, ptr, stream
+
+LL = ("local", "to", "local")
+VV = ("virtual", "to", "virtual")
+LV = ("local", "to", "virtual")
+
+
+@dataclass
+class ResidentMeta:
+    """Per-batch segmentation the kernels need (device int32 ptrs + host maxima)."""
+    lptr: Tensor
+    vptr: Tensor
+    eptr_ll: Tensor
+    eptr_vv: Tensor
+    eptr_lv: Tensor
+    num_graphs: int
+    max_n: int
+    max_v: int
+    max_ell: int
+    max_evv: int
+    flag: Tensor
+
+    def check(self) -> None:
+        """Synchronising validity check of the last launches that used this meta."""
+        f = int(self.flag.item())
+        if f & 2:
+            raise IndexError("an edge connects nodes of different graphs: the batch is not block-diagonal")
+        if f & 4:
+            raise ValueError("a graph exceeds the sizes the resident launch was configured for")
+
+
+def meta_from_batch(batch, device) -> Optional[ResidentMeta]:
+    """Read the segmentation a ``graph_hscn.data.HeteroBatch`` carries; ``None`` if the
+    object does not provide it (foreign containers use the layered operators)."""
+    try:
+        loc, vir = batch["local"], batch["virtual"]
+        ell, evv, elv = batch[LL], batch[VV], batch[LV]
+        tensors = [loc.ptr32, vir.ptr32, ell.ptr32, evv.ptr32, elv.ptr32]
+        maxima = (int(loc.max_nodes), int(vir.max_nodes), int(ell.max_edges), int(evv.max_edges))
+    except (AttributeError, KeyError, TypeError):
+        return None
+    if any((not isinstance(t, Tensor)) or t.device != device or t.dtype != torch.int32 for t in tensors):
+        return None
+    cached = getattr(batch, "_resident_meta", None)
+    if cached is not None and cached.lptr is tensors[0]:
+        return cached
+    meta = ResidentMeta(*[t.contiguous() for t in tensors], int(tensors[0].numel()) - 1, *maxima,
+                        torch.zeros(1, dtype=torch.int32, device=device))
+    try:
+        batch._resident_meta = meta
+    except AttributeError:
+        pass
+    return meta
+
+
+def supported(F: int, H: int, L: int, C: int, meta: ResidentMeta) -> bool:
+    return bool(_hip.lib().hscn_resident_supported(F, H, L, C, meta.max_n, meta.max_v, meta.max_ell, meta.max_evv))
+
+
+def _ptr_table(ts: List[Optional[Tensor]]):
+    arr = (ctypes.c_void_p * len(ts))(*[None if t is None else ptr(t) for t in ts])
+    return arr
+
+
+class HSCNResidentFn(Function):
+    """inputs: x_local, x_virtual, ei_ll, ei_vv, ei_lv, meta, cfg, then parameters in
+    the order  [W_ll, b_ll, W_vv, b_vv, W_src, W_dst, att_src, att_dst, b_gat] x L,
+    W1, b1, W2, b2.   cfg = (head_act code, slope, compute_virtual, keep_virtual)."""
+
+    @staticmethod
+    def forward(ctx, x_local, x_virtual, ei_ll, ei_vv, ei_lv, meta: ResidentMeta, cfg, *params):
+        head_act, slope, compute_virtual, keep_virtual = cfg
+        L = (len(params) - 4) // 9
+        params = [p.contiguous() for p in params]
+        W1, b1, W2, b2 = params[9 * L:]
+        H, C = W1.shape[0], W2.shape[0]
+        x_local = x_local.contiguous()
+        x_virtual = x_virtual.contiguous()
+        N, F = x_local.shape
+        V = x_virtual.shape[0]
+        B = meta.num_graphs
+        dev = x_local.device
+        acts = torch.empty(L, N, H, dtype=torch.float32, device=dev)
+        pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
+        z = torch.empty(B, H, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, C, dtype=torch.float32, device=dev)
+        xv_out = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev) if (compute_virtual and keep_virtual) else None
+        table = _ptr_table(params[: 9 * L])
+        call("hscn_resident_fwd", ptr(x_local), ptr(x_virtual), ptr(ei_ll), ei_ll.size(1), ptr(ei_vv),
+             ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll),
+             ptr(meta.eptr_vv), ptr(meta.eptr_lv), N, V, B, F, H, L, C, head_act, float(slope), table,
+             ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_v, meta.max_ell, meta.max_evv,
+             int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(meta.flag),
+             stream())
+        ctx.meta, ctx.head_act, ctx.dims = meta, head_act, (N, F, H, L, C, B)
+        ctx.save_for_backward(x_local, ei_ll, acts, pooled, z, W1, W2, *[params[9 * l] for l in range(L)])
+        ctx.mark_non_differentiable(*([xv_out] if xv_out is not None else []))
+        if xv_out is None:
+            return pred
+        return pred, xv_out
+
+    @staticmethod
+    def backward(ctx, g_pred, *_):
+        x_local, ei_ll, acts, pooled, z, W1, W2, *W_ll = ctx.saved_tensors
+        meta: ResidentMeta = ctx.meta
+        N, F, H, L, C, B = ctx.dims
+        dev = x_local.device
+        P = int(_hip.lib().hscn_resident_param_count(F, H, L, C))
+        partials = torch.empty(B, P, dtype=torch.float32, device=dev)
+        grads = torch.empty(P, dtype=torch.float32, device=dev)
+        g_pred = g_pred.contiguous()
+        table = _ptr_table(list(W_ll))
+        call("hscn_resident_bwd", ptr(x_local), ptr(ei_ll), ei_ll.size(1), ptr(meta.lptr), ptr(meta.eptr_ll), N, B,
+             F, H, L, C, ctx.head_act, table, ptr(W1), ptr(W2), ptr(acts), ptr(pooled), ptr(z), ptr(g_pred),
+             meta.max_n, meta.max_ell, ptr(partials), ptr(grads), ptr(meta.flag), stream())
+        out: List[Optional[Tensor]] = [None] * (7 + 9 * L + 4)
+        off = 0
+        for l in range(L):
+            fin = F if l == 0 else H
+            out[7 + 9 * l] = grads[off: off + H * fin].view(H, fin)
+            off += H * fin
+            out[7 + 9 * l + 1] = grads[off: off + H]
+            off += H
+        base = 7 + 9 * L
+        out[base] = grads[off: off + H * H].view(H, H); off += H * H
+        out[base + 1] = grads[off: off + H]; off += H
+        out[base + 2] = grads[off: off + C * H].view(C, H); off += C * H
+        out[base + 3] = grads[off: off + C]
+        return tuple(out)

@@ -26,6 +26,7 @@ from ..nn import GATConv, GCNConv, GraphConv, HeteroConv, Linear
 from ..nn import functional as Fh
 from ..nn.pool import global_mean_pool, mincut_pool_sparse, to_dense_adj
 from ..structure import Relation, relation_of
+from .. import engine as _engine
 
 LL = ("local", "to", "local")
 VV = ("virtual", "to", "virtual")
@@ -118,9 +119,57 @@ class HSCN(nn.Module):
             self.convs.append(conv)
         self.lin_1 = Linear(hidden_channels, hidden_channels)
         self.lin_2 = Linear(hidden_channels, num_classes)
+        # execution engine: "auto" picks the graph-resident fused kernels when the batch
+        # qualifies (engine.py), else the per-operator (layered) path; both are HIP.
+        self.engine = "auto"
+        self.compute_virtual = True   # the reference evaluates the virtual branch although pred ignores it
+        self.keep_virtual = False     # expose the final virtual features as self.last_virtual
+        self.last_virtual: Optional[Tensor] = None
+        self.last_engine: Optional[str] = None
+
+    def _resident_plan(self, x_dict, edge_index_dict, batch):
+        if self.engine == "layered":
+            return None
+        name = _act_name(self.activation)
+        ok = (name in ACT_DICT and set(edge_index_dict) == {LL, VV, LV} and "local" in x_dict
+              and "virtual" in x_dict and x_dict["local"].is_cuda)
+        if ok:
+            for conv in self.convs:
+                c = conv.convs
+                ok = ok and isinstance(c["__".join(LL)], GCNConv) and isinstance(c["__".join(VV)], GCNConv) \
+                    and isinstance(c["__".join(LV)], GATConv)
+        meta = _engine.meta_from_batch(batch, x_dict["local"].device) if ok else None
+        H, C = self.lin_1.out_channels, self.lin_2.out_channels
+        if meta is None or not _engine.supported(x_dict["local"].size(1), H, len(self.convs), C, meta):
+            if self.engine == "resident":
+                raise RuntimeError("engine='resident' requested but the batch/model does not qualify "
+                                   "(needs a graph_hscn HeteroBatch, GAT/GCN/GCN relations, H in {16,32,64}, "
+                                   "F <= H and graphs that fit one CU's LDS)")
+            return None
+        return meta, name
+
+    def _forward_resident(self, x_dict, edge_index_dict, meta, act_name) -> Tensor:
+        params = []
+        for conv in self.convs:
+            ll, vv, lv = (conv.convs["__".join(k)] for k in (LL, VV, LV))
+            params += [ll.lin.weight, ll.bias, vv.lin.weight, vv.bias, lv.lin_src.weight, lv.lin_dst.weight,
+                       lv.att_src, lv.att_dst, lv.bias]
+        params += [self.lin_1.weight, self.lin_1.bias, self.lin_2.weight, self.lin_2.bias]
+        slope = self.convs[0].convs["__".join(LV)].negative_slope
+        cfg = (_engine.ACT[act_name], slope, self.compute_virtual, self.keep_virtual)
+        out = _engine.HSCNResidentFn.apply(x_dict["local"], x_dict["virtual"], edge_index_dict[LL],
+                                           edge_index_dict[VV], edge_index_dict[LV], meta, cfg, *params)
+        if isinstance(out, tuple):
+            out, self.last_virtual = out
+        return out
 
     def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[Tuple[str, str, str], Tensor],
                 batch) -> Tensor:
+        plan = self._resident_plan(x_dict, edge_index_dict, batch)
+        if plan is not None:
+            self.last_engine = "resident"
+            return self._forward_resident(x_dict, edge_index_dict, *plan)
+        self.last_engine = "layered"
         relu = ACT_DICT["relu"]
         for conv in self.convs:
             x_dict = conv(x_dict, edge_index_dict)

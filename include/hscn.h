@@ -214,6 +214,44 @@ int hscn_assign_argmax(const float* S, int64_t* ids, int64_t num_nodes, int K, v
 int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t num_edges, int64_t n,
                       float* adj /*[n,n]*/, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * a10  HSCN.forward / backward, graph-resident engine
+ * (reference model/hscn.py:102-114 with lv=GAT, ll=GCN, vv=GCN; the loop
+ * train/train.py:76,87 drives it).  The batch must be block-diagonal with graph
+ * g owning local nodes [lptr[g],lptr[g+1]), virtual nodes [vptr[g],vptr[g+1])
+ * and the edge slices [eptr_*[g],eptr_*[g+1]) of each relation's int64 [2,E]
+ * COO list (what PyG's collate produces).  One workgroup per graph keeps the
+ * graph's features and CSR in LDS for all L layers.
+ *   layer_params_host: HOST array of L x 9 device pointers per layer
+ *     {W_ll[H,fin], b_ll[H], W_vv[H,fin], b_vv[H], W_src[H,fin], W_dst[H,fin],
+ *      att_src[H], att_dst[H], b_gat[H]},  fin = F for layer 0, else H
+ *   acts [L,N,H]: post-ReLU local features of every layer (kept for backward)
+ *   pooled [B,H], z [B,H] (head hidden, post-activation), pred [B,C]
+ *   xv_out [V,H] or NULL: final virtual features (never used by the prediction
+ *     in the reference architecture; exposed so the virtual branch is testable)
+ *   compute_virtual 0 skips the virtual branch (it cannot change pred)
+ *   flag: bit 2 = an edge left its graph's node range, bit 4 = a graph exceeds
+ *     max_n / max_v / max_ell / max_evv (the LDS budget the launch was sized for)
+ * hscn_resident_bwd returns dL/d{W_ll, b_ll per layer, W1, b1, W2, b2} packed in
+ * that order in grads[P] (P = hscn_resident_param_count); the virtual-branch
+ * parameters receive no gradient, exactly as in the reference's autograd graph.
+ * ------------------------------------------------------------------------- */
+int hscn_resident_supported(int F, int H, int L, int C, int max_n, int max_v, int max_ell, int max_evv);
+int64_t hscn_resident_param_count(int F, int H, int L, int C);
+int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_t* ei_ll, int64_t E_ll,
+                      const int64_t* ei_vv, int64_t E_vv, const int64_t* ei_lv, int64_t E_lv,
+                      const int32_t* lptr, const int32_t* vptr, const int32_t* eptr_ll, const int32_t* eptr_vv,
+                      const int32_t* eptr_lv, int64_t N, int64_t V, int64_t B, int F, int H, int L, int C,
+                      int head_act, float slope, const void* const* layer_params_host,
+                      const float* W1, const float* b1, const float* W2, const float* b2, int max_n, int max_v,
+                      int max_ell, int max_evv, int compute_virtual, float* acts, float* pooled, float* z,
+                      float* pred, float* xv_out, int32_t* flag, void* stream);
+int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                      const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
+                      const void* const* W_ll_host, const float* W1, const float* W2, const float* acts,
+                      const float* pooled, const float* z, const float* g_pred, int max_n, int max_ell,
+                      float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,141 @@
+"""Graph-resident fused engine (csrc/resident.hip) vs the CPU oracle and vs the
+layered per-operator engine."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hetero_data as OH
+from oracle import models as OM
+from tests.helpers import ATOL, DEV, close
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(name, B, K, seed):
+    from graph_hscn.data import HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    graphs = make_dataset(name, B, seed=seed)
+    rng = np.random.default_rng(seed)
+    ids = [rng.integers(0, K, g.num_nodes) for g in graphs]
+    ob = OH.collate_hetero([OH.hetero_from_clusters(g.x, g.edge_index, g.y, i, K) for g, i in zip(graphs, ids)])
+    pb = HeteroBatch.from_data_list([hetero_from_clusters(g, i, K) for g, i in zip(graphs, ids)])
+    return ob, pb
+
+
+def _models(F, H, C, L, act="relu", seed=0):
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.model.hscn import HSCN
+    torch.manual_seed(seed)
+    om = OM.HSCN("GAT", "GCN", "GCN", OM.ACT[act], F, H, C, L)
+    with torch.no_grad():
+        for n_, p in om.named_parameters():
+            if n_.endswith("bias"):
+                p.normal_(0, 0.1)
+    pm = HSCN("GAT", "GCN", "GCN", ACT_DICT[act], F, H, C, L).to(DEV)
+    pm.load_state_dict(om.state_dict())
+    return om, pm
+
+
+@pytest.mark.parametrize("name,B,K,H,L,C,act", [
+    ("peptides_func", 6, 16, 16, 3, 10, "relu"), ("peptides_struct", 5, 32, 32, 2, 11, "elu"),
+    ("pcqm_contact", 9, 16, 16, 3, 1, "tanh"), ("pascalvoc_sp", 3, 64, 16, 2, 21, "relu"),
+    ("pcqm_contact", 7, 16, 64, 1, 10, "identity"), ("peptides_func", 40, 4, 16, 3, 10, "relu")])
+def test_resident_matches_oracle(name, B, K, H, L, C, act):
+    ob, pb = _batches(name, B, K, seed=B + K)
+    F = ob["x_dict"]["local"].size(1)
+    om, pm = _models(F, H, C, L, act, seed=B)
+    pm.engine, pm.keep_virtual = "resident", True
+    pbd = pb.to(DEV)
+    out_o = om(ob["x_dict"], ob["edge_index_dict"], ob["batch_local"], B)
+    out_d = pm(pbd.x_dict, pbd.edge_index_dict, pbd)
+    assert pm.last_engine == "resident"
+    pbd._resident_meta.check()
+    assert close(out_d, out_o, atol=ATOL, rtol=1e-5)
+    # virtual branch (unused by pred): compare the final virtual features directly
+    xo = ob["x_dict"]
+    for conv in om.convs:
+        xo = {k: v.relu() for k, v in conv(xo, ob["edge_index_dict"]).items()}
+    assert close(pm.last_virtual, xo["virtual"], atol=3e-5, rtol=1e-5)
+    g = torch.randn(B, C, generator=torch.Generator().manual_seed(1))
+    out_o.backward(g)
+    out_d.backward(g.to(DEV))
+    for (n_, po), (_, pp) in zip(om.named_parameters(), pm.named_parameters()):
+        if po.grad is None:
+            assert pp.grad is None, n_
+        else:
+            assert close(pp.grad, po.grad, atol=1e-4, rtol=1e-3), n_
+
+
+def test_resident_equals_layered_engine():
+    ob, pb = _batches("peptides_func", 12, 16, seed=3)
+    _, pm = _models(9, 16, 10, 3)
+    pbd = pb.to(DEV)
+    outs, grads = {}, {}
+    for eng in ("resident", "layered"):
+        pm.engine = eng
+        pm.zero_grad(set_to_none=True)
+        out = pm(pbd.x_dict, pbd.edge_index_dict, pbd)
+        assert pm.last_engine == eng
+        out.square().sum().backward()
+        outs[eng] = out.detach().clone()
+        grads[eng] = {n: p.grad.clone() for n, p in pm.named_parameters() if p.grad is not None}
+    assert close(outs["resident"], outs["layered"], atol=1e-6, rtol=1e-6)
+    assert grads["resident"].keys() == grads["layered"].keys()
+    for n in grads["resident"]:
+        assert close(grads["resident"][n], grads["layered"][n], atol=1e-5, rtol=1e-4), n
+
+
+def test_resident_is_reproducible_bitwise():
+    _, pb = _batches("peptides_func", 16, 16, seed=5)
+    _, pm = _models(9, 16, 10, 3)
+    pm.engine = "resident"
+    pbd = pb.to(DEV)
+    runs = []
+    for _ in range(3):
+        pm.zero_grad(set_to_none=True)
+        out = pm(pbd.x_dict, pbd.edge_index_dict, pbd)
+        out.sum().backward()
+        runs.append((out.detach().clone(), [p.grad.clone() for p in pm.parameters() if p.grad is not None]))
+    for out, gs in runs[1:]:
+        assert torch.equal(out, runs[0][0])
+        assert all(torch.equal(a, b) for a, b in zip(gs, runs[0][1]))
+
+
+def test_resident_skipping_virtual_branch_leaves_prediction_unchanged():
+    _, pb = _batches("peptides_func", 8, 16, seed=7)
+    _, pm = _models(9, 16, 10, 3)
+    pm.engine = "resident"
+    pbd = pb.to(DEV)
+    a = pm(pbd.x_dict, pbd.edge_index_dict, pbd).detach().clone()
+    pm.compute_virtual = False
+    b = pm(pbd.x_dict, pbd.edge_index_dict, pbd).detach()
+    assert torch.equal(a, b)
+
+
+def test_resident_flags_edges_that_cross_graphs():
+    _, pb = _batches("peptides_func", 4, 8, seed=9)
+    _, pm = _models(9, 16, 10, 2)
+    pm.engine = "resident"
+    pbd = pb.to(DEV)
+    ei = pbd[("local", "to", "local")].edge_index
+    ei[0, 0] = pbd["local"].num_nodes - 1          # first graph's edge now starts in the last graph
+    pm(pbd.x_dict, pbd.edge_index_dict, pbd)
+    with pytest.raises(IndexError):
+        pbd._resident_meta.check()
+
+
+def test_auto_engine_falls_back_to_layered_for_foreign_batches():
+    ob, _ = _batches("peptides_func", 3, 8, seed=1)
+    _, pm = _models(9, 16, 10, 2)
+
+    class Foreign(dict):
+        num_graphs = 3
+    fb = Foreign()
+
+    class L_:
+        batch = ob["batch_local"].to(DEV)
+    fb["local"] = L_()
+    out = pm({k: v.to(DEV) for k, v in ob["x_dict"].items()},
+             {k: v.to(DEV) for k, v in ob["edge_index_dict"].items()}, fb)
+    assert pm.last_engine == "layered" and out.shape == (3, 10)
