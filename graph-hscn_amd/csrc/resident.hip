@@ -6,8 +6,10 @@
 // fits in a fraction of one CU's 160 KB LDS, so the whole HSCN forward
 // (reference model/hscn.py:102-114: L x HeteroConv{ll GCN, vv GCN, lv GAT} + ReLU,
 // mean pool, 2-layer head) runs in ONE launch with workgroup barriers only:
-//   COO slice -> stable CSR in LDS (LDS int atomics + rank by edge id)
-//   per layer: feature transform (W row in registers, X rows broadcast from LDS),
+//   COO slice -> stable CSR in LDS (ll/vv: LDS int atomics + rank by edge id;
+//                lv: wave-ballot multisplit, its rows are whole clusters)
+//   per layer: the layer's weights staged once into LDS (transposed, coalesced),
+//              feature transform (W row in registers, X rows broadcast from LDS),
 //              ll gather-reduce, vv gather-reduce + lv segment softmax (wave per
 //              cluster, __shfl reductions), ReLU
 //   mean pool + head by wave 0.
@@ -23,7 +25,7 @@
 
 namespace {
 
-constexpr int RT = 256;  // threads per workgroup
+constexpr int RT_MAX = 1024;  // largest workgroup the kernels are instantiated for
 constexpr int MAXL = 8;
 
 struct LayerP {
@@ -59,8 +61,21 @@ struct BwdArgs {
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Phase stamps exist only in the diagnostic build (make diag -> libhscn_diag.so); the
+// shipped kernels execute none.  Values go to a buffer nothing else reads.
+#ifdef HSCN_STAMPS
+__device__ long long* g_stamp_buf = nullptr;  // [grid][64]
+#define STAMP(k)                                                                                 \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 64 + (k)] = clock64(); \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 // ---- workgroup inclusive scan of a[0..n) in LDS, in place -----------------------------
-__device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[RT/64+1]*/) {
+template <int RT>
+__device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[RT/64]*/) {
   const int per = (n + RT - 1) / RT;
   const int b = threadIdx.x * per;
   int s = 0;
@@ -78,7 +93,6 @@ __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[RT/64+1]*/) {
   int off = 0;
   for (int i = 0; i < w; ++i) off += wsum[i];
   int run = off + incl - s;
-  __syncthreads();
   for (int i = 0; i < per; ++i)
     if (b + i < n) {
       run += a[b + i];
@@ -87,10 +101,13 @@ __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[RT/64+1]*/) {
   __syncthreads();
 }
 
-// ---- stable CSR of one graph's edge slice, in LDS ------------------------------------------
+// ---- stable CSR of one graph's edge slice, in LDS: low-degree rows ------------------------
 // rowptr[0..nrows], col[ne] = other - other_off, rows keep ascending edge order.
 // cursor: [nrows+1] ints, tmp: [ne] ints.  Edges leaving the graph's node ranges
 // are dropped and *flag is raised (the batch is then not block-diagonal).
+// Placement: LDS int atomics (arrival order), then every edge ranks itself inside its
+// row by edge number -- O(degree) per edge, meant for rows of a few edges.
+template <int RT>
 __device__ void build_csr_lds(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int e0, int ne,
                               int key_off, int nrows, int other_off, int ncols, int* rowptr, int* col,
                               int* cursor, int* tmp, int* wsum, int32_t* flag) {
@@ -108,7 +125,7 @@ __device__ void build_csr_lds(const int64_t* __restrict__ key, const int64_t* __
     }
   }
   __syncthreads();
-  scan_inclusive_lds(rowptr, nrows + 1, wsum);
+  scan_inclusive_lds<RT>(rowptr, nrows + 1, wsum);
   for (int e = threadIdx.x; e < ne; e += RT) {
     const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
     if (k < 0 || k >= nrows || o < 0 || o >= ncols) continue;
@@ -127,6 +144,57 @@ __device__ void build_csr_lds(const int64_t* __restrict__ key, const int64_t* __
   __syncthreads();
 }
 
+// ---- stable CSR, few rows of high degree (local -> virtual: rows are clusters) ----------------
+// Wave-ballot multisplit: edges are cut into 64-edge chunks (one wave each, in edge order);
+// cnt[row][chunk] by ballot, one scan over (row-major, chunk-minor) gives every
+// (row, chunk) its base slot, the rank inside the chunk is popcount(ballot & lanes below).
+// O(distinct rows per chunk) per wave instead of O(degree) per edge.
+// cnt: [nrows * nchunk] ints, nchunk = ceil(ne / 64).
+template <int RT>
+__device__ void build_csr_multisplit_lds(const int64_t* __restrict__ key, const int64_t* __restrict__ other,
+                                         int e0, int ne, int key_off, int nrows, int other_off, int ncols,
+                                         int* rowptr, int* col, int* cnt, int* tmp, int* wsum, int32_t* flag) {
+  const int nchunk = (ne + 63) >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < nrows * nchunk; i += RT) cnt[i] = 0;
+  __syncthreads();
+  for (int c = threadIdx.x >> 6; c < nchunk; c += RT / 64) {
+    const int e = c * 64 + lane;
+    int k = -1;
+    if (e < ne) {
+      k = (int)(key[e0 + e] - key_off);
+      const int o = (int)(other[e0 + e] - other_off);
+      if (k < 0 || k >= nrows || o < 0 || o >= ncols) {
+        if (flag) atomicOr(flag, 2);
+        k = -1;
+      }
+    }
+    unsigned long long todo = __ballot(k >= 0);
+    int rank = 0;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k0 = __shfl(k, leader, 64);
+      const unsigned long long m = __ballot(k == k0);
+      if (k == k0) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == leader) cnt[k0 * nchunk + c] = __popcll(m);
+      todo &= ~m;
+    }
+    if (e < ne) tmp[e] = rank;
+  }
+  __syncthreads();
+  scan_inclusive_lds<RT>(cnt, nrows * nchunk, wsum);
+  for (int r = threadIdx.x; r <= nrows; r += RT) rowptr[r] = (r * nchunk > 0) ? cnt[r * nchunk - 1] : 0;
+  for (int e = threadIdx.x; e < ne; e += RT) {
+    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
+    if (k < 0 || k >= nrows || o < 0 || o >= ncols) continue;
+    const int idx = k * nchunk + (e >> 6);
+    const int base = idx > 0 ? cnt[idx - 1] : 0;
+    col[base + tmp[e]] = o;
+  }
+  __syncthreads();
+}
+
+template <int RT>
 __device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float* dinv) {
   for (int i = threadIdx.x; i < n; i += RT) {
     const int d = rowptr[i + 1] - rowptr[i];
@@ -134,15 +202,25 @@ __device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float
   }
 }
 
-// ---- Y[n][H] = X[n][H(zero padded)] * W[H][fin]^T ; optional row dot with att ---------------
-template <int H>
-__device__ void lin_lds(const float* X, const float* __restrict__ Wg, int fin, float* Y, int n,
-                        const float* __restrict__ att, float* a_out) {
+// ---- stage W[H][fin] (global, nn.Linear layout) into LDS as Wt[k][o], rows k>=fin zero ----------
+template <int H, int RT>
+__device__ __forceinline__ void stage_wt(const float* __restrict__ Wg, int fin, float* Wt) {
+  for (int idx = threadIdx.x; idx < H * fin; idx += RT) {
+    const int o = idx / fin, k = idx - o * fin;
+    Wt[k * H + o] = Wg[idx];
+  }
+  for (int idx = threadIdx.x + fin * H; idx < H * H; idx += RT) Wt[idx] = 0.f;
+}
+
+// ---- Y[n][H] = X[n][H(zero padded)] * W^T, W given transposed in LDS; optional row dot ----------
+template <int H, int RT>
+__device__ void lin_lds(const float* X, const float* Wt, float* Y, int n, const float* att, float* a_out) {
   const int o = threadIdx.x % H, r0 = threadIdx.x / H;
   constexpr int RS = RT / H;
+  if (r0 >= n) return;
   float w[H];
 #pragma unroll
-  for (int k = 0; k < H; ++k) w[k] = k < fin ? Wg[o * fin + k] : 0.f;
+  for (int k = 0; k < H; ++k) w[k] = Wt[k * H + o];
   const float at = att ? att[o] : 0.f;
   for (int i = r0; i < n; i += RS) {
     const float4* xr = reinterpret_cast<const float4*>(X + i * H);
@@ -166,9 +244,9 @@ __device__ void lin_lds(const float* X, const float* __restrict__ Wg, int fin, f
 }
 
 // ---- Out[i] = act(sum_p (dc[col[p]]*dr[i]) * Hin[col[p]] + bias) ---------------------------------
-template <int H>
+template <int H, int RT>
 __device__ void agg_gcn_lds(const int* rowptr, const int* col, const float* dr, const float* dc,
-                            const float* Hin, const float* __restrict__ bias, float* Out, int n, int relu,
+                            const float* Hin, const float* bias, float* Out, int n, int relu,
                             float* __restrict__ gout /* global rows or null */) {
   constexpr int LPR = H / 4;
   constexpr int RPB = RT / LPR;
@@ -197,9 +275,48 @@ __device__ void agg_gcn_lds(const int* rowptr, const int* col, const float* dr, 
   }
 }
 
-// relu fmaxf(x,0) maps -0 -> +0 and NaN -> 0; apply_act(RELU) is v>0?v:0 (NaN -> 0): same results.
+// LDS layout shared by host sizing and kernel carve (all counts in 4-byte words)
+struct FwdLayout {
+  size_t xa, bh, xva, xvb, hv, a_s, a_d, dinv, dinv_v, sc, wt, vecs, vec;
+  size_t rowptr, col, rowptr_lv, col_lv, rowptr_vv, col_vv, cursor, tmp, wsum, total;
+};
+__host__ __device__ inline FwdLayout fwd_layout(int H, int max_n, int max_v, int max_ell, int max_evv) {
+  FwdLayout Y;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };  // keep 16-B alignment
+  Y.xa = take((size_t)max_n * H);
+  Y.bh = take((size_t)max_n * H);
+  Y.xva = take((size_t)max_v * H);
+  Y.xvb = take((size_t)max_v * H);
+  Y.hv = take((size_t)max_v * H);
+  Y.a_s = take(max_n);
+  Y.a_d = take(max_v);
+  Y.dinv = take(max_n);
+  Y.dinv_v = take(max_v);
+  Y.sc = take(max_n);
+  Y.wt = take((size_t)4 * H * H);
+  Y.vecs = take((size_t)5 * H);
+  Y.vec = take(128);
+  Y.rowptr = take(max_n + 1);
+  Y.col = take(max_ell);
+  Y.rowptr_lv = take(max_v + 1);
+  Y.col_lv = take(max_n);
+  Y.rowptr_vv = take(max_v + 1);
+  Y.col_vv = take(max_evv);
+  const int maxrows = max_n > max_v ? max_n : max_v;
+  const int nchunk = (max_n + 63) / 64;
+  size_t cur = (size_t)maxrows + 1;
+  if ((size_t)max_v * nchunk > cur) cur = (size_t)max_v * nchunk;  // multisplit counters reuse the cursor area
+  Y.cursor = take(cur);
+  int maxe = max_ell > max_n ? max_ell : max_n;
+  maxe = maxe > max_evv ? maxe : max_evv;
+  Y.tmp = take(maxe);
+  Y.wsum = take(16);
+  Y.total = o;
+  return Y;
+}
 
-template <int H>
+template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int g = blockIdx.x;
@@ -212,37 +329,27 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
     if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
     return;
   }
-  // ---- LDS carve --------------------------------------------------------------------
-  float* xa = reinterpret_cast<float*>(smem);              // [max_n][H] current local features
-  float* bh = xa + (size_t)A.max_n * H;                    // [max_n][H] transform output
-  float* xva = bh + (size_t)A.max_n * H;                   // [max_v][H]
-  float* xvb = xva + (size_t)A.max_v * H;                  // [max_v][H]
-  float* hv = xvb + (size_t)A.max_v * H;                   // [max_v][H]
-  float* a_s = hv + (size_t)A.max_v * H;                   // [max_n]
-  float* a_d = a_s + A.max_n;                              // [max_v]
-  float* dinv = a_d + A.max_v;                             // [max_n]
-  float* dinv_v = dinv + A.max_n;                          // [max_v]
-  float* vec = dinv_v + A.max_v;                           // [2*64] pooled / z
-  int* rowptr = reinterpret_cast<int*>(vec + 128);         // [max_n+1]
-  int* col = rowptr + A.max_n + 1;                         // [max_ell]
-  int* rowptr_lv = col + A.max_ell;                        // [max_v+1]
-  int* col_lv = rowptr_lv + A.max_v + 1;                   // [max_n]
-  int* rowptr_vv = col_lv + A.max_n;                       // [max_v+1]
-  int* col_vv = rowptr_vv + A.max_v + 1;                   // [max_evv]
-  int* cursor = col_vv + A.max_evv;                        // [max(max_n,max_v)+1]
-  const int maxrows = A.max_n > A.max_v ? A.max_n : A.max_v;
-  int* tmp = cursor + maxrows + 1;                         // [max(max_ell,max_n,max_evv)]
-  int maxe = A.max_ell > A.max_n ? A.max_ell : A.max_n;
-  maxe = maxe > A.max_evv ? maxe : A.max_evv;
-  int* wsum = tmp + maxe;                                  // [8]
+  const FwdLayout Y = fwd_layout(H, A.max_n, A.max_v, A.max_ell, A.max_evv);
+  float* fb = reinterpret_cast<float*>(smem);
+  int* ib = reinterpret_cast<int*>(smem);
+  float *xa = fb + Y.xa, *bh = fb + Y.bh, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *hv = fb + Y.hv;
+  float *a_s = fb + Y.a_s, *a_d = fb + Y.a_d, *dinv = fb + Y.dinv, *dinv_v = fb + Y.dinv_v, *sc = fb + Y.sc;
+  float *wt = fb + Y.wt, *vecs = fb + Y.vecs, *vec = fb + Y.vec;
+  int *rowptr = ib + Y.rowptr, *col = ib + Y.col, *rowptr_lv = ib + Y.rowptr_lv, *col_lv = ib + Y.col_lv;
+  int *rowptr_vv = ib + Y.rowptr_vv, *col_vv = ib + Y.col_vv, *cursor = ib + Y.cursor, *tmp = ib + Y.tmp;
+  int* wsum = ib + Y.wsum;
 
   // ---- structure ----------------------------------------------------------------------
-  build_csr_lds(A.ll_dst, A.ll_src, e0, ne, n0, n, n0, n, rowptr, col, cursor, tmp, wsum, A.flag);
-  dinv_from_rowptr(rowptr, n, dinv);
+  STAMP(0);
+  build_csr_lds<RT>(A.ll_dst, A.ll_src, e0, ne, n0, n, n0, n, rowptr, col, cursor, tmp, wsum, A.flag);
+  dinv_from_rowptr<RT>(rowptr, n, dinv);
+  STAMP(1);
   if (A.compute_virtual) {
-    build_csr_lds(A.lv_dst, A.lv_src, el0, nel, v0, nv, n0, n, rowptr_lv, col_lv, cursor, tmp, wsum, A.flag);
-    build_csr_lds(A.vv_dst, A.vv_src, ev0, nev, v0, nv, v0, nv, rowptr_vv, col_vv, cursor, tmp, wsum, A.flag);
-    dinv_from_rowptr(rowptr_vv, nv, dinv_v);
+    build_csr_multisplit_lds<RT>(A.lv_dst, A.lv_src, el0, nel, v0, nv, n0, n, rowptr_lv, col_lv, cursor, tmp,
+                                 wsum, A.flag);
+    STAMP(2);
+    build_csr_lds<RT>(A.vv_dst, A.vv_src, ev0, nev, v0, nv, v0, nv, rowptr_vv, col_vv, cursor, tmp, wsum, A.flag);
+    dinv_from_rowptr<RT>(rowptr_vv, nv, dinv_v);
   }
   // ---- layer-0 inputs, zero padded to H ------------------------------------------------
   const int F = A.F;
@@ -255,20 +362,43 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
       const int i = idx / H, k = idx - i * H;
       xva[idx] = k < F ? A.x_virtual[(size_t)(v0 + i) * F + k] : 0.f;
     }
-  __syncthreads();
+  STAMP(3);
 
+  float* b_ll = vecs;
+  float* b_vv = vecs + H;
+  float* b_gat = vecs + 2 * H;
+  float* att_s = vecs + 3 * H;
+  float* att_d = vecs + 4 * H;
   for (int l = 0; l < A.L; ++l) {
     const LayerP& P = A.layer[l];
     const int fin = l == 0 ? F : H;
+    __syncthreads();  // previous layer done with wt / vecs; inputs loaded
+    stage_wt<H, RT>(P.W_ll, fin, wt);
+    if (threadIdx.x < H) b_ll[threadIdx.x] = P.b_ll[threadIdx.x];
+    if (A.compute_virtual) {
+      stage_wt<H, RT>(P.W_src, fin, wt + H * H);
+      stage_wt<H, RT>(P.W_dst, fin, wt + 2 * H * H);
+      stage_wt<H, RT>(P.W_vv, fin, wt + 3 * H * H);
+      if (threadIdx.x < H) {
+        b_vv[threadIdx.x] = P.b_vv[threadIdx.x];
+        b_gat[threadIdx.x] = P.b_gat[threadIdx.x];
+        att_s[threadIdx.x] = P.att_src[threadIdx.x];
+        att_d[threadIdx.x] = P.att_dst[threadIdx.x];
+      }
+    }
+    __syncthreads();
+    STAMP(4 + 8 * l);
     if (A.compute_virtual) {
       // local -> virtual GAT: hs = lin_src(x_local), a_s; hd = lin_dst(x_virtual) only through a_d
-      lin_lds<H>(xa, P.W_src, fin, bh, n, P.att_src, a_s);
-      lin_lds<H>(xva, P.W_dst, fin, nullptr, nv, P.att_dst, a_d);
+      lin_lds<H, RT>(xa, wt + H * H, bh, n, att_s, a_s);
+      lin_lds<H, RT>(xva, wt + 2 * H * H, nullptr, nv, att_d, a_d);
       // virtual -> virtual GCN transform
-      lin_lds<H>(xva, P.W_vv, fin, hv, nv, nullptr, nullptr);
+      lin_lds<H, RT>(xva, wt + 3 * H * H, hv, nv, nullptr, nullptr);
       __syncthreads();
-      agg_gcn_lds<H>(rowptr_vv, col_vv, dinv_v, dinv_v, hv, P.b_vv, xvb, nv, 0, nullptr);
+      STAMP(5 + 8 * l);
+      agg_gcn_lds<H, RT>(rowptr_vv, col_vv, dinv_v, dinv_v, hv, b_vv, xvb, nv, 0, nullptr);
       __syncthreads();
+      STAMP(6 + 8 * l);
       // segment softmax + weighted sum, one wave per cluster; added onto the vv output, then ReLU
       {
         constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
@@ -278,16 +408,26 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
           const int s = rowptr_lv[v], t = rowptr_lv[v + 1];
           const float ad = a_d[v];
           float m = -INFINITY;
-          for (int p = s + lane; p < t; p += 64) m = fmaxf(m, leaky(a_s[col_lv[p]] + ad, A.slope));
+          for (int p = s + lane; p < t; p += 64) {
+            const float e = leaky(a_s[col_lv[p]] + ad, A.slope);
+            sc[p] = e;
+            m = fmaxf(m, e);
+          }
           m = wave_max(m);
           float sum = 0.f;
-          for (int p = s + lane; p < t; p += 64) sum += expf(leaky(a_s[col_lv[p]] + ad, A.slope) - m);
+          for (int p = s + lane; p < t; p += 64) {
+            const float ex = expf(sc[p] - m);
+            sc[p] = ex;
+            sum += ex;
+          }
           sum = wave_sum(sum);
           const float denom = sum + 1e-16f;
+          for (int p = s + lane; p < t; p += 64) sc[p] = sc[p] / denom;
+          // LDS ops of one wave complete in order: the slot loop below sees the alphas
           float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
           for (int p = s + slot; p < t; p += S) {
             const int j = col_lv[p];
-            const float al = expf(leaky(a_s[j] + ad, A.slope) - m) / denom;
+            const float al = sc[p];
             const float4 hvv = *reinterpret_cast<const float4*>(bh + j * H + f);
             acc.x = fmaf(al, hvv.x, acc.x);
             acc.y = fmaf(al, hvv.y, acc.y);
@@ -302,7 +442,7 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
             acc.w += __shfl_xor(acc.w, off, 64);
           }
           if (slot == 0) {
-            const float4 bg = *reinterpret_cast<const float4*>(P.b_gat + f);
+            const float4 bg = *reinterpret_cast<const float4*>(b_gat + f);
             float4 prev = *reinterpret_cast<const float4*>(xvb + v * H + f);
             prev.x = fmaxf(prev.x + (acc.x + bg.x), 0.f);
             prev.y = fmaxf(prev.y + (acc.y + bg.y), 0.f);
@@ -313,17 +453,19 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
         }
       }
       __syncthreads();
+      STAMP(7 + 8 * l);
       {  // swap virtual buffers
         float* t_ = xva; xva = xvb; xvb = t_;
       }
     }
     // local -> local GCN: transform into bh, gather-reduce back into xa (xa is dead after the transform)
-    lin_lds<H>(xa, P.W_ll, fin, bh, n, nullptr, nullptr);
+    lin_lds<H, RT>(xa, wt, bh, n, nullptr, nullptr);
     __syncthreads();
-    agg_gcn_lds<H>(rowptr, col, dinv, dinv, bh, P.b_ll, xa, n, 1,
-                   A.acts + ((size_t)l * A.N + n0) * H);
-    __syncthreads();
+    STAMP(8 + 8 * l);
+    agg_gcn_lds<H, RT>(rowptr, col, dinv, dinv, bh, b_ll, xa, n, 1, A.acts + ((size_t)l * A.N + n0) * H);
+    STAMP(9 + 8 * l);
   }
+  __syncthreads();
 
   if (A.compute_virtual && A.xv_out)
     for (int idx = threadIdx.x; idx < nv * H; idx += RT) A.xv_out[(size_t)v0 * H + idx] = xva[idx];
@@ -346,38 +488,71 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
       acc.w += __shfl_xor(acc.w, off, 64);
     }
     const float cnt = (float)(n > 0 ? n : 1);
-    if (slot == 0) {
-      vec[f + 0] = acc.x / cnt; vec[f + 1] = acc.y / cnt; vec[f + 2] = acc.z / cnt; vec[f + 3] = acc.w / cnt;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
     float* pooled = vec;
     float* zz = vec + 64;
+    if (slot == 0) {
+      pooled[f + 0] = acc.x / cnt; pooled[f + 1] = acc.y / cnt; pooled[f + 2] = acc.z / cnt; pooled[f + 3] = acc.w / cnt;
+    }
+    // one wave: LDS writes above are visible to its own later reads
     if (lane < H) {
       A.pooled[(size_t)g * H + lane] = pooled[lane];
-      float acc = 0.f;
-      for (int k = 0; k < H; ++k) acc = fmaf(pooled[k], A.W1[lane * H + k], acc);
-      acc += A.b1[lane];
-      acc = apply_act(acc, A.head_act);
-      zz[lane] = acc;
-      A.z[(size_t)g * H + lane] = acc;
+      float a1 = 0.f;
+      const float4* wr = reinterpret_cast<const float4*>(A.W1 + lane * H);
+#pragma unroll
+      for (int k4 = 0; k4 < H / 4; ++k4) {
+        const float4 w4 = wr[k4];
+        a1 = fmaf(pooled[4 * k4 + 0], w4.x, a1);
+        a1 = fmaf(pooled[4 * k4 + 1], w4.y, a1);
+        a1 = fmaf(pooled[4 * k4 + 2], w4.z, a1);
+        a1 = fmaf(pooled[4 * k4 + 3], w4.w, a1);
+      }
+      a1 += A.b1[lane];
+      a1 = apply_act(a1, A.head_act);
+      zz[lane] = a1;
+      A.z[(size_t)g * H + lane] = a1;
+    }
+    for (int c = lane; c < A.C; c += 64) {
+      float a2 = 0.f;
+      const float4* wr = reinterpret_cast<const float4*>(A.W2 + c * H);
+#pragma unroll
+      for (int k4 = 0; k4 < H / 4; ++k4) {
+        const float4 w4 = wr[k4];
+        a2 = fmaf(zz[4 * k4 + 0], w4.x, a2);
+        a2 = fmaf(zz[4 * k4 + 1], w4.y, a2);
+        a2 = fmaf(zz[4 * k4 + 2], w4.z, a2);
+        a2 = fmaf(zz[4 * k4 + 3], w4.w, a2);
+      }
+      A.pred[(size_t)g * A.C + c] = a2 + A.b2[c];
     }
   }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const float* zz = vec + 64;
-    for (int c = threadIdx.x; c < A.C; c += 64) {
-      float acc = 0.f;
-      for (int k = 0; k < H; ++k) acc = fmaf(zz[k], A.W2[c * H + k], acc);
-      A.pred[(size_t)g * A.C + c] = acc + A.b2[c];
-    }
-  }
+  STAMP(63);
 }
 
 // =============================== backward =====================================================
-template <int H>
+struct BwdLayout {
+  size_t G, GH, X, dinv, vec, red, wl, rowptr_t, col_t, cursor, tmp, wsum, total;
+};
+__host__ __device__ inline BwdLayout bwd_layout(int H, int max_n, int max_ell) {
+  BwdLayout Y;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+  Y.G = take((size_t)max_n * H);
+  Y.GH = take((size_t)max_n * H);
+  Y.X = take((size_t)max_n * H);
+  Y.dinv = take(max_n);
+  Y.vec = take(256);
+  Y.red = take((size_t)RT_MAX);  // bias / weight-gradient slice partials
+  Y.wl = take((size_t)H * H);
+  Y.rowptr_t = take(max_n + 1);
+  Y.col_t = take(max_ell);
+  Y.cursor = take(max_n + 1);
+  Y.tmp = take(max_ell);
+  Y.wsum = take(16);
+  Y.total = o;
+  return Y;
+}
+
+template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int g = blockIdx.x;
@@ -389,18 +564,15 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
     for (int i = threadIdx.x; i < A.P; i += RT) part[i] = 0.f;
     return;
   }
-  float* G = reinterpret_cast<float*>(smem);            // [max_n][H]  dL/d(layer output), then pre-activation grad
-  float* GH = G + (size_t)A.max_n * H;                  // [max_n][H]  dL/d(transform output)
-  float* X = GH + (size_t)A.max_n * H;                  // [max_n][H]  layer input
-  float* dinv = X + (size_t)A.max_n * H;                // [max_n]
-  float* vec = dinv + A.max_n;                          // [4*64]: g_pred | z | g_zpre | g_pool
-  float* red = vec + 256;                               // [RT] bias-gradient partials
-  int* rowptr_t = reinterpret_cast<int*>(red + RT);     // [max_n+1]  CSR keyed by SOURCE
-  int* col_t = rowptr_t + A.max_n + 1;                  // [max_ell]
-  int* cursor = col_t + A.max_ell;                      // [max_n+1]
-  int* tmp = cursor + A.max_n + 1;                      // [max_ell]
-  int* wsum = tmp + A.max_ell;                          // [8]
+  const BwdLayout Y = bwd_layout(H, A.max_n, A.max_ell);
+  float* fb = reinterpret_cast<float*>(smem);
+  int* ib = reinterpret_cast<int*>(smem);
+  float *G = fb + Y.G, *GH = fb + Y.GH, *X = fb + Y.X, *dinv = fb + Y.dinv, *vec = fb + Y.vec;
+  float *red = fb + Y.red, *wl = fb + Y.wl;
+  int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t, *cursor = ib + Y.cursor, *tmp = ib + Y.tmp;
+  int* wsum = ib + Y.wsum;
 
+  STAMP(0);
   // in-degree (by target) -> dinv, through the cursor array
   for (int i = threadIdx.x; i <= n; i += RT) cursor[i] = 0;
   __syncthreads();
@@ -414,12 +586,12 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
     dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
   }
   __syncthreads();
-  build_csr_lds(A.ll_src, A.ll_dst, e0, ne, n0, n, n0, n, rowptr_t, col_t, cursor, tmp, wsum, A.flag);
+  build_csr_lds<RT>(A.ll_src, A.ll_dst, e0, ne, n0, n, n0, n, rowptr_t, col_t, cursor, tmp, wsum, A.flag);
+  STAMP(1);
 
-  // ---- head backward (wave 0) ---------------------------------------------------------------
-  float* gp = vec;         // g_pred [C<=64.. loop]
-  float* zz = vec + 64;    // z
-  float* gz = vec + 128;   // dL/d(lin_1 output, pre-activation)
+  // ---- head backward ---------------------------------------------------------------------------
+  float* zz = vec + 64;     // z
+  float* gz = vec + 128;    // dL/d(lin_1 output, pre-activation)
   float* gpool = vec + 192;
   // partial layout: per layer {W_ll [H*fin], b_ll [H]}, then W1 [H*H], b1 [H], W2 [C*H], b2 [C]
   int off_head = 0;
@@ -427,16 +599,13 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
   const int oW1 = off_head, ob1 = oW1 + H * H, oW2 = ob1 + H, ob2 = oW2 + A.C * H;
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
-    if (lane < H) zz[lane] = A.z[(size_t)g * H + lane];
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    // g_zpre[k] = (sum_c g_pred[c] W2[c][k]) * act'(z[k])
     if (lane < H) {
+      const float zv = A.z[(size_t)g * H + lane];
+      zz[lane] = zv;
+      // g_zpre[k] = (sum_c g_pred[c] W2[c][k]) * act'(z[k])
       float acc = 0.f;
       for (int c = 0; c < A.C; ++c) acc = fmaf(A.g_pred[(size_t)g * A.C + c], A.W2[c * H + lane], acc);
-      gz[lane] = acc * act_grad_from_output(zz[lane], A.head_act);
+      gz[lane] = acc * act_grad_from_output(zv, A.head_act);
     }
   }
   __syncthreads();
@@ -461,14 +630,15 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
     const float cnt = (float)(n > 0 ? n : 1);
     for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = gpool[idx % H] / cnt;
   }
-  __syncthreads();
+  STAMP(2);
 
   int off = off_head;
   for (int l = A.L - 1; l >= 0; --l) {
     const int fin = l == 0 ? A.F : H;
     off -= H * fin + H;
     const int oW = off, ob = off + H * fin;
-    // ReLU mask from the saved layer output; layer input -> X (zero padded)
+    __syncthreads();
+    // ReLU mask from the saved layer output; layer input -> X (zero padded); W_ll -> LDS
     const float* y = A.acts + ((size_t)l * A.N + n0) * H;
     for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = y[idx] > 0.f ? G[idx] : 0.f;
     if (l == 0) {
@@ -479,8 +649,10 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
     } else {
       const float* xin = A.acts + ((size_t)(l - 1) * A.N + n0) * H;
       for (int idx = threadIdx.x; idx < n * H; idx += RT) X[idx] = xin[idx];
+      for (int idx = threadIdx.x; idx < H * H; idx += RT) wl[idx] = A.W_ll[l][idx];
     }
     __syncthreads();
+    STAMP(3 + 6 * l);
     // bias gradient: column sums of G, RT/H row chunks then ordered fold
     {
       const int f = threadIdx.x % H, c = threadIdx.x / H;
@@ -490,45 +662,69 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
       red[threadIdx.x] = s;
     }
     // dL/d(transform output) = A_hat^T G  (transposed CSR, edge order)
-    agg_gcn_lds<H>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, nullptr);
+    agg_gcn_lds<H, RT>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, nullptr);
     __syncthreads();
+    STAMP(4 + 6 * l);
     if (threadIdx.x < H) {
       constexpr int CH = RT / H;
       float s = 0.f;
       for (int c = 0; c < CH; ++c) s += red[c * H + threadIdx.x];
       part[ob + threadIdx.x] = s;
     }
-    // weight gradient: gW[o][k] = sum_j GH[j][o] * X[j][k]
-    for (int idx = threadIdx.x; idx < H * fin; idx += RT) {
-      const int o = idx / fin, k = idx - o * fin;
-      float acc = 0.f;
-      for (int j = 0; j < n; ++j) acc = fmaf(GH[j * H + o], X[j * H + k], acc);
-      part[oW + idx] = acc;
-    }
-    // input gradient: G[j][k] = sum_o GH[j][o] * W[o][k]   (W is [H][fin], fin == H here)
-    if (l > 0) {
-      __syncthreads();  // everyone done reading G (bias sums) -- GH/X reads above do not touch G
-      const int k = threadIdx.x % H, r0 = threadIdx.x / H;
-      constexpr int RS = RT / H;
-      float w[H];
-#pragma unroll
-      for (int o = 0; o < H; ++o) w[o] = A.W_ll[l][o * H + k];
-      for (int j = r0; j < n; j += RS) {
-        const float4* gr = reinterpret_cast<const float4*>(GH + j * H);
+    __syncthreads();
+    // weight gradient: gW[o][k] = sum_j GH[j][o] * X[j][k]; rows split into NS interleaved
+    // slices per entry (NS consecutive threads), folded in slice order
+    {
+      const int ent = H * fin;
+      int NS = RT / ent;
+      NS = NS < 1 ? 1 : (NS > 4 ? 4 : NS);
+      const int per_pass = RT / NS;
+      const int local = threadIdx.x / NS, sl = threadIdx.x % NS;
+      for (int base = 0; base < ent; base += per_pass) {
+        const int idx = base + local;
+        const bool live = idx < ent && local < per_pass;
         float acc = 0.f;
-#pragma unroll
-        for (int o4 = 0; o4 < H / 4; ++o4) {
-          const float4 v = gr[o4];
-          acc = fmaf(v.x, w[4 * o4 + 0], acc);
-          acc = fmaf(v.y, w[4 * o4 + 1], acc);
-          acc = fmaf(v.z, w[4 * o4 + 2], acc);
-          acc = fmaf(v.w, w[4 * o4 + 3], acc);
+        if (live) {
+          const int o = idx / fin, k = idx - o * fin;
+          for (int j = sl; j < n; j += NS) acc = fmaf(GH[j * H + o], X[j * H + k], acc);
         }
-        G[j * H + k] = acc;
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (live && sl == 0) {
+          float s = 0.f;
+          for (int q = 0; q < NS; ++q) s += red[threadIdx.x + q];
+          part[oW + idx] = s;
+        }
+        __syncthreads();
       }
     }
-    __syncthreads();
+    STAMP(5 + 6 * l);
+    // input gradient: G[j][k] = sum_o GH[j][o] * W[o][k]   (W is [H][H] here)
+    if (l > 0) {
+      const int k = threadIdx.x % H, r0 = threadIdx.x / H;
+      constexpr int RS = RT / H;
+      if (r0 < n) {
+        float w[H];
+#pragma unroll
+        for (int o = 0; o < H; ++o) w[o] = wl[o * H + k];
+        for (int j = r0; j < n; j += RS) {
+          const float4* gr = reinterpret_cast<const float4*>(GH + j * H);
+          float acc = 0.f;
+#pragma unroll
+          for (int o4 = 0; o4 < H / 4; ++o4) {
+            const float4 v = gr[o4];
+            acc = fmaf(v.x, w[4 * o4 + 0], acc);
+            acc = fmaf(v.y, w[4 * o4 + 1], acc);
+            acc = fmaf(v.z, w[4 * o4 + 2], acc);
+            acc = fmaf(v.w, w[4 * o4 + 3], acc);
+          }
+          G[j * H + k] = acc;
+        }
+      }
+    }
+    STAMP(6 + 6 * l);
   }
+  STAMP(63);
 }
 
 // out[p] = sum_g partials[g][p], g ascending
@@ -541,26 +737,33 @@ __global__ void k_param_reduce(const float* __restrict__ partials, float* __rest
 }
 
 inline size_t fwd_lds_bytes(int H, int max_n, int max_v, int max_ell, int max_evv) {
-  const int maxrows = max_n > max_v ? max_n : max_v;
-  int maxe = max_ell > max_n ? max_ell : max_n;
-  maxe = maxe > max_evv ? maxe : max_evv;
-  size_t fl = (size_t)2 * max_n * H + (size_t)3 * max_v * H + max_n + max_v + max_n + max_v + 128;
-  size_t in = (size_t)(max_n + 1) + max_ell + (max_v + 1) + max_n + (max_v + 1) + max_evv + (maxrows + 1) + maxe + 8;
-  return (fl + in) * 4;
+  return fwd_layout(H, max_n, max_v, max_ell, max_evv).total * 4;
 }
-inline size_t bwd_lds_bytes(int H, int max_n, int max_ell) {
-  size_t fl = (size_t)3 * max_n * H + max_n + 256 + RT;
-  size_t in = (size_t)(max_n + 1) + max_ell + (max_n + 1) + max_ell + 8;
-  return (fl + in) * 4;
-}
+inline size_t bwd_lds_bytes(int H, int max_n, int max_ell) { return bwd_layout(H, max_n, max_ell).total * 4; }
 
+// Workgroup size: 16 waves (4 per SIMD) hide the LDS / global latency of the many short
+// phases; tiny graphs (PCQM-Contact, n <= 64) do not have the rows to feed them.
+template <int H, int RT>
+int launch_fwd_rt(const FwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_hscn_fwd<H, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  k_hscn_fwd<H, RT><<<(unsigned)B, RT, lds, st>>>(A);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
 template <int H>
 int launch_fwd(const FwdArgs& A, int64_t B, hipStream_t st) {
   const size_t lds = fwd_lds_bytes(H, A.max_n, A.max_v, A.max_ell, A.max_evv);
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  return A.max_n <= 64 ? launch_fwd_rt<H, 256>(A, B, lds, st) : launch_fwd_rt<H, 1024>(A, B, lds, st);
+}
+template <int H, int RT>
+int launch_bwd_rt(const BwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)k_hscn_fwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k_hscn_fwd<H><<<(unsigned)B, RT, lds, st>>>(A);
+    (void)hipFuncSetAttribute((const void*)k_hscn_bwd<H, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  k_hscn_bwd<H, RT><<<(unsigned)B, RT, lds, st>>>(A);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -568,16 +771,18 @@ template <int H>
 int launch_bwd(const BwdArgs& A, int64_t B, hipStream_t st) {
   const size_t lds = bwd_lds_bytes(H, A.max_n, A.max_ell);
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)k_hscn_bwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k_hscn_bwd<H><<<(unsigned)B, RT, lds, st>>>(A);
-  HSCN_RETURN_IF_LAUNCH_FAILED();
-  return 0;
+  return A.max_n <= 64 ? launch_bwd_rt<H, 256>(A, B, lds, st) : launch_bwd_rt<H, 1024>(A, B, lds, st);
 }
 
 }  // namespace
 
 extern "C" {
+
+#ifdef HSCN_STAMPS
+int hscn_diag_set_stamp_buffer(long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+}
+#endif
 
 int hscn_resident_supported(int F, int H, int L, int C, int max_n, int max_v, int max_ell, int max_evv) {
   if (!(H == 16 || H == 32 || H == 64) || F < 1 || F > H || L < 1 || L > MAXL || C < 1) return 0;

@@ -13,7 +13,8 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
+# HSCN_LIB: alternative build of the same ABI (the stamped diagnostic build used by tools/diag_resident.py)
+_LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
 ABI_VERSION = 1

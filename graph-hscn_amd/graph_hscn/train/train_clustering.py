@@ -1,0 +1,76 @@
+"""Stage A driver: fit the spectral-clustering net with MinCUT + orthogonality
+losses, then hard-assign every node (reference
+/root/reference/graph_hscn/train/train_clustering.py:20-70).
+
+``batch_graphs=1`` (default) is the reference's trajectory: ``gcn_norm`` with self
+loops, one optimizer step PER GRAPH (:36-50), then an assignment pass (:57-69, run
+under ``no_grad`` here -- the reference builds autograd graphs it never uses).
+``batch_graphs>1`` is an extension: B graphs per step on the device as one
+block-diagonal batch; the loss is the mean of the per-graph losses (exactly
+``dense_mincut_pool``'s own mean over its batch dimension), which changes the
+optimisation trajectory and shards across GPUs like stage C.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .. import _hip
+from ..config.config import OPTIM_DICT
+from ..data import Batch
+from ..model.hscn import SCN
+from ..nn.pool import gcn_norm
+
+
+def _assign(S: torch.Tensor) -> torch.Tensor:
+    ids = torch.empty(S.size(0), dtype=torch.int64, device=S.device)
+    _hip.call("hscn_assign_argmax", _hip.ptr(S.contiguous()), _hip.ptr(ids), S.size(0), S.size(1), _hip.stream())
+    return ids
+
+
+def _forward(model: SCN, graphs: Sequence, device) -> tuple:
+    if len(graphs) == 1:
+        g = graphs[0]
+        ei, ew = gcn_norm(g.edge_index.to(device), getattr(g, "edge_weight", None), g.num_nodes,
+                          add_self_loops=True)
+        return model(g.x.to(device).float(), ei, ew), None
+    big = Batch.from_data_list(list(graphs))
+    ei, ew = gcn_norm(big.edge_index.to(device), None, big.num_nodes, add_self_loops=True)
+    ptr = big.ptr.to(device).to(torch.int32)
+    return model(big.x.to(device).float(), ei, ew, node_ptr=ptr), big.ptr
+
+
+def train_clustering(logger, dataset, model: SCN, model_cfg, optim_cfg, training_cfg,
+                     batch_graphs: int = 1) -> List[np.ndarray]:
+    device = next(model.parameters()).device
+    if device.type != "cuda":
+        raise RuntimeError("train_clustering runs on the MI355X HIP path: move the SCN to 'cuda'")
+    optimizer = OPTIM_DICT[optim_cfg.optim_type](lr=optim_cfg.lr, weight_decay=optim_cfg.weight_decay,
+                                                 params=model.parameters())
+    n = len(dataset)
+    for epoch in range(model_cfg.cluster_epochs):
+        if logger is not None:
+            logger.info(f"Fitting clustering, epoch {epoch}...")
+        for i in range(0, n, batch_graphs):
+            graphs = [dataset[j] for j in range(i, min(i + batch_graphs, n))]
+            optimizer.zero_grad()
+            (_, mc_loss, o_loss, _), _ = _forward(model, graphs, device)
+            loss = mc_loss + o_loss
+            loss.backward()
+            optimizer.step()
+    cluster_all_lst: List[np.ndarray] = []
+    if logger is not None:
+        logger.info("Generating cluster assignments...")
+    with torch.no_grad():
+        for i in range(0, n, batch_graphs):
+            graphs = [dataset[j] for j in range(i, min(i + batch_graphs, n))]
+            (S, _, _, _), ptr = _forward(model, graphs, device)
+            ids = _assign(S).cpu().numpy()
+            if ptr is None:
+                cluster_all_lst.append(ids)
+            else:
+                p = ptr.numpy()
+                cluster_all_lst.extend(ids[p[k]:p[k + 1]] for k in range(len(graphs)))
+    return cluster_all_lst

@@ -1,0 +1,100 @@
+"""Data-parallel path on CPU with gloo, world_size 2: graphs sharded across ranks,
+flat-buffer gradient all-reduce; the result must equal the single-process
+gradient of the mean loss over the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(seed, B, K):
+    from graph_hscn.loader.synthetic import make_dataset
+    from oracle import hetero_data as OH
+    graphs = make_dataset("peptides_func", B, seed=seed)
+    rng = np.random.default_rng(seed)
+    return [OH.hetero_from_clusters(g.x, g.edge_index, g.y, rng.integers(0, K, g.num_nodes), K) for g in graphs], \
+        [g.num_nodes for g in graphs]
+
+
+def _grads(model, hs):
+    from oracle import hetero_data as OH
+    from oracle import models as OM
+    b = OH.collate_hetero(hs)
+    model.zero_grad(set_to_none=True)
+    out = model(b["x_dict"], b["edge_index_dict"], b["batch_local"], len(hs))
+    loss, _ = OM.criterion("cross_entropy", out, b["y"])
+    loss.backward()
+    return loss.detach()
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "graph-hscn_amd")]
+    from graph_hscn.distributed import FlatGradReducer, shard_bounds
+    from oracle import models as OM
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hs, sizes = _build(3, 10, 8)
+    torch.manual_seed(0)
+    model = OM.HSCN("GAT", "GCN", "GCN", OM.ACT["relu"], 9, 16, 10, 2)
+    bounds = shard_bounds(sizes, world)
+    mine = hs[bounds[rank]:bounds[rank + 1]]
+    _grads(model, mine)
+    red = FlatGradReducer(model)
+    red.reduce(len(mine))                     # total weight found by all-reduce
+    g1 = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+    _grads(model, mine)
+    red.reduce(len(mine), len(hs))            # total weight given: no host sync
+    g2 = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+    q.put((rank, g1.numpy(), g2.numpy(), [p.grad is None for p in model.parameters()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gradients_equal_single_process_gradients():
+    from oracle import models as OM
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    hs, _ = _build(3, 10, 8)
+    torch.manual_seed(0)
+    model = OM.HSCN("GAT", "GCN", "GCN", OM.ACT["relu"], 9, 16, 10, 2)
+    _grads(model, hs)
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]).numpy()
+    none_mask = [p.grad is None for p in model.parameters()]
+    for rank, g1, g2, mask in res:
+        assert mask == none_mask                      # virtual-branch params stay grad-less on every rank
+        np.testing.assert_allclose(g1, want, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(g2, want, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(res[0][1], res[1][1])  # ranks hold identical reduced gradients
+
+
+def test_reducer_is_identity_without_a_process_group():
+    from graph_hscn.distributed import FlatGradReducer
+    m = torch.nn.Linear(3, 2)
+    m(torch.randn(4, 3)).sum().backward()
+    before = [p.grad.clone() for p in m.parameters()]
+    FlatGradReducer(m).reduce(4)
+    for a, p in zip(before, m.parameters()):
+        assert torch.equal(a, p.grad)
