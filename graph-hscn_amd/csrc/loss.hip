@@ -1,0 +1,67 @@
+// Loss tail of the training step (reference graph_hscn/loss.py:6-19 called at
+// train/train.py:82): binary-cross-entropy-with-logits / L1, mean reduction, and the
+// sigmoid score, on the [B, C] prediction.  One launch produces the loss, the score and
+// dL/dpred (so the backward is a single scale), replacing ~8 elementwise/reduce launches
+// of a few microseconds each on a 1 280-element tensor.  Ordered block reduction: reproducible.
+#include "hscn_common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_criterion(const float* __restrict__ pred, const float* __restrict__ target,
+                                                   int64_t count, int kind, float* __restrict__ loss,
+                                                   float* __restrict__ score, float* __restrict__ grad) {
+  __shared__ float red[4];
+  const float inv = 1.0f / (float)count;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < count; i += 256) {
+    const float x = pred[i], y = target[i];
+    const float sg = 1.0f / (1.0f + expf(-x));
+    float l, g;
+    if (kind == 0) {  // BCE with logits: max(x,0) - x*y + log1p(exp(-|x|))
+      l = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+      g = (sg - y) * inv;
+    } else {          // L1
+      const float d = x - y;
+      l = fabsf(d);
+      g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv;
+    }
+    s += l;
+    if (score) score[i] = sg;
+    grad[i] = g;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
+}
+
+__global__ void k_scale(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const float s = g[0];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = s * x[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int hscn_criterion_fwd(const float* pred, const float* target, int64_t count, int kind, float* loss, float* score,
+                       float* grad, void* stream_) {
+  if (count < 1 || !pred || !target || !loss || !grad || (kind != 0 && kind != 1)) return HSCN_E_BADARG;
+  k_criterion<<<1, 256, 0, hscn_stream(stream_)>>>(pred, target, count, kind, loss, score, grad);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_scale(const float* g, const float* x, float* y, int64_t count, void* stream_) {
+  if (count < 0 || (count > 0 && (!g || !x || !y))) return HSCN_E_BADARG;
+  if (count == 0) return 0;
+  unsigned nb = hscn_blocks(count, 256);
+  if (nb > 1024) nb = 1024;
+  k_scale<<<nb, 256, 0, hscn_stream(stream_)>>>(g, x, y, count);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // extern "C"

@@ -5,22 +5,35 @@
 // of each relation's edge list.  A Peptides graph (n <= 444, e <= ~1000, H = 16)
 // fits in a fraction of one CU's 160 KB LDS, so the whole HSCN forward
 // (reference model/hscn.py:102-114: L x HeteroConv{ll GCN, vv GCN, lv GAT} + ReLU,
-// mean pool, 2-layer head) runs in ONE launch with workgroup barriers only:
-//   COO slice -> stable CSR in LDS (ll/vv: LDS int atomics + rank by edge id;
-//                lv: wave-ballot multisplit, its rows are whole clusters)
-//   per layer: the layer's weights staged once into LDS (transposed, coalesced),
-//              feature transform (W row in registers, X rows broadcast from LDS),
-//              ll gather-reduce, vv gather-reduce + lv segment softmax (wave per
-//              cluster, __shfl reductions), ReLU
-//   mean pool + head by wave 0.
-// HBM traffic is the algorithmic minimum: inputs once, per-layer local
-// activations once (kept for the backward), predictions.  The backward is the
-// mirror image (transposed CSR in LDS, per-graph parameter-gradient partials,
-// then one ordered reduction over graphs -- no float atomics).
+// mean pool, 2-layer head) runs in ONE launch with workgroup barriers only.
 //
-// Numerics: same operation order as the layered kernels (spmm.hip / linear.hip):
-// k-ascending fmaf chains in the transforms, edge-order separately rounded
-// multiply/add in the gather-reduce.
+// The kernel is latency-bound (a few MB for the whole batch), so
+// it is organised around the number of dependent steps, not around bandwidth:
+//   prologue : every global input of the graph (features, the three COO slices, layer-0
+//              and head weights) is requested before anything is consumed: one HBM
+//              round trip instead of one per array;
+//   structure: COO slices -> stable CSR in LDS.  Wave group A builds local->local while
+//              group B builds virtual->virtual (LDS int atomics + rank by edge number),
+//              then all waves build local->virtual with a wave-ballot multisplit (its
+//              rows are whole clusters);
+//   layers   : two barriers per layer.  Phase 1: group A transforms for the ll relation,
+//              group B for the lv / vv relations (register-blocked: a lane owns 2-4
+//              outputs of a row, W columns in registers, X row broadcast from LDS).
+//              Phase 2: group A gather-reduces ll (+bias, ReLU, activations to HBM for
+//              the backward), group B runs one wave per cluster: vv gather-reduce +
+//              lv segment softmax (__shfl reductions) + ReLU.  The next layer's weights
+//              are fetched into registers at the top of the layer and parked in the
+//              other LDS weight buffer under this layer's math;
+//   epilogue : mean pool over all waves, head by wave 0.
+// The virtual branch cannot influence the prediction in the reference architecture
+// ("local" only receives ll); it is computed for fidelity and runs beside the ll path.
+//
+// The backward mirrors it (transposed CSR in LDS, wave-tile outer-product weight
+// gradients with DPP row reductions, per-graph parameter-gradient partials, then one
+// ordered reduction over graphs): no float atomics, bitwise reproducible.
+//
+// Numerics: k-ascending fmaf chains in the transforms, edge-order separately rounded
+// multiply/add in the gather-reduce (same as the layered kernels).
 #include "hscn_common.h"
 
 namespace {
@@ -43,6 +56,7 @@ struct FwdArgs {
   int32_t* flag;
   int64_t N, V;
   int F, L, C, head_act, max_n, max_v, max_ell, max_evv, compute_virtual;
+  int spec;  // 1: ll path and virtual branch run concurrently on two wave groups (needs a 3rd n x H buffer)
   float slope;
 };
 
@@ -73,25 +87,42 @@ __device__ long long* g_stamp_buf = nullptr;  // [grid][64]
 #define STAMP(k) do {} while (0)
 #endif
 
-// ---- workgroup inclusive scan of a[0..n) in LDS, in place -----------------------------
-template <int RT>
-__device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[RT/64]*/) {
-  const int per = (n + RT - 1) / RT;
-  const int b = threadIdx.x * per;
+// A wave group: a contiguous range of waves of the workgroup that works on its own arrays
+// between the workgroup-wide barriers (every group executes the same barrier sequence).
+struct Grp {
+  int t;   // thread index inside the group
+  int nt;  // threads in the group
+  int w;   // wave index inside the group
+  int nw;  // waves in the group
+};
+
+// sum over the 16 lanes of a DPP row (all 16 lanes receive the total): VALU only, no LDS
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// ---- group inclusive scan of a[0..n) in LDS, in place (two workgroup barriers) -----------------
+__device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp& G) {
+  const int per = (n + G.nt - 1) / G.nt;
+  const int b = G.t * per;
   int s = 0;
   for (int i = 0; i < per; ++i)
     if (b + i < n) s += a[b + i];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   int incl = s;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  if (lane == 63) wsum[w] = incl;
+  if (lane == 63) wsum[G.w] = incl;
   __syncthreads();
   int off = 0;
-  for (int i = 0; i < w; ++i) off += wsum[i];
+  for (int i = 0; i < G.w; ++i) off += wsum[i];
   int run = off + incl - s;
   for (int i = 0; i < per; ++i)
     if (b + i < n) {
@@ -101,45 +132,37 @@ __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[RT/64]*/) {
   __syncthreads();
 }
 
-// ---- stable CSR of one graph's edge slice, in LDS: low-degree rows ------------------------
-// rowptr[0..nrows], col[ne] = other - other_off, rows keep ascending edge order.
-// cursor: [nrows+1] ints, tmp: [ne] ints.  Edges leaving the graph's node ranges
-// are dropped and *flag is raised (the batch is then not block-diagonal).
-// Placement: LDS int atomics (arrival order), then every edge ranks itself inside its
-// row by edge number -- O(degree) per edge, meant for rows of a few edges.
-template <int RT>
-__device__ void build_csr_lds(const int64_t* __restrict__ key, const int64_t* __restrict__ other, int e0, int ne,
-                              int key_off, int nrows, int other_off, int ncols, int* rowptr, int* col,
-                              int* cursor, int* tmp, int* wsum, int32_t* flag) {
-  for (int i = threadIdx.x; i <= nrows; i += RT) {
+// ---- stable CSR from staged edges (local ids; key -1 = dropped): low-degree rows --------------
+// rowptr[0..nrows], col[ne]; rows keep ascending edge order.  Placement by LDS int atomics
+// (arrival order), then every edge ranks itself inside its row by edge number: O(degree) per
+// edge, meant for rows of a few edges.  cursor: [nrows+1], tmp: [ne].  Six barriers.
+__device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, int* rowptr, int* col, int* cursor,
+                              int* tmp, int* wsum, const Grp& G) {
+  for (int i = G.t; i <= nrows; i += G.nt) {
     rowptr[i] = 0;
     cursor[i] = 0;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < ne; e += RT) {
-    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
-    if (k < 0 || k >= nrows || o < 0 || o >= ncols) {
-      if (flag) atomicOr(flag, 2);
-    } else {
-      atomicAdd(&rowptr[k + 1], 1);
-    }
+  for (int e = G.t; e < ne; e += G.nt) {
+    const int k = ek[e];
+    if (k >= 0) atomicAdd(&rowptr[k + 1], 1);
   }
   __syncthreads();
-  scan_inclusive_lds<RT>(rowptr, nrows + 1, wsum);
-  for (int e = threadIdx.x; e < ne; e += RT) {
-    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
-    if (k < 0 || k >= nrows || o < 0 || o >= ncols) continue;
+  scan_inclusive_lds(rowptr, nrows + 1, wsum, G);
+  for (int e = G.t; e < ne; e += G.nt) {
+    const int k = ek[e];
+    if (k < 0) continue;
     const int p = atomicAdd(&cursor[k], 1);
     tmp[rowptr[k] + p] = e;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < ne; e += RT) {
-    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
-    if (k < 0 || k >= nrows || o < 0 || o >= ncols) continue;
+  for (int e = G.t; e < ne; e += G.nt) {
+    const int k = ek[e];
+    if (k < 0) continue;
     const int s = rowptr[k], t = rowptr[k + 1];
     int rank = 0;
     for (int q = s; q < t; ++q) rank += (tmp[q] < e) ? 1 : 0;
-    col[s + rank] = o;
+    col[s + rank] = eo[e];
   }
   __syncthreads();
 }
@@ -148,27 +171,16 @@ __device__ void build_csr_lds(const int64_t* __restrict__ key, const int64_t* __
 // Wave-ballot multisplit: edges are cut into 64-edge chunks (one wave each, in edge order);
 // cnt[row][chunk] by ballot, one scan over (row-major, chunk-minor) gives every
 // (row, chunk) its base slot, the rank inside the chunk is popcount(ballot & lanes below).
-// O(distinct rows per chunk) per wave instead of O(degree) per edge.
-// cnt: [nrows * nchunk] ints, nchunk = ceil(ne / 64).
-template <int RT>
-__device__ void build_csr_multisplit_lds(const int64_t* __restrict__ key, const int64_t* __restrict__ other,
-                                         int e0, int ne, int key_off, int nrows, int other_off, int ncols,
-                                         int* rowptr, int* col, int* cnt, int* tmp, int* wsum, int32_t* flag) {
+// cnt: [nrows * ceil(ne/64)] ints, tmp: [ne].  Five barriers.
+__device__ void build_csr_multisplit_lds(const int* ek, const int* eo, int ne, int nrows, int* rowptr, int* col,
+                                         int* cnt, int* tmp, int* wsum, const Grp& G) {
   const int nchunk = (ne + 63) >> 6;
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < nrows * nchunk; i += RT) cnt[i] = 0;
+  for (int i = G.t; i < nrows * nchunk; i += G.nt) cnt[i] = 0;
   __syncthreads();
-  for (int c = threadIdx.x >> 6; c < nchunk; c += RT / 64) {
+  for (int c = G.w; c < nchunk; c += G.nw) {
     const int e = c * 64 + lane;
-    int k = -1;
-    if (e < ne) {
-      k = (int)(key[e0 + e] - key_off);
-      const int o = (int)(other[e0 + e] - other_off);
-      if (k < 0 || k >= nrows || o < 0 || o >= ncols) {
-        if (flag) atomicOr(flag, 2);
-        k = -1;
-      }
-    }
+    const int k = e < ne ? ek[e] : -1;
     unsigned long long todo = __ballot(k >= 0);
     int rank = 0;
     while (todo) {
@@ -182,75 +194,124 @@ __device__ void build_csr_multisplit_lds(const int64_t* __restrict__ key, const 
     if (e < ne) tmp[e] = rank;
   }
   __syncthreads();
-  scan_inclusive_lds<RT>(cnt, nrows * nchunk, wsum);
-  for (int r = threadIdx.x; r <= nrows; r += RT) rowptr[r] = (r * nchunk > 0) ? cnt[r * nchunk - 1] : 0;
-  for (int e = threadIdx.x; e < ne; e += RT) {
-    const int k = (int)(key[e0 + e] - key_off), o = (int)(other[e0 + e] - other_off);
-    if (k < 0 || k >= nrows || o < 0 || o >= ncols) continue;
+  scan_inclusive_lds(cnt, nrows * nchunk, wsum, G);
+  for (int r = G.t; r <= nrows; r += G.nt) rowptr[r] = (r * nchunk > 0) ? cnt[r * nchunk - 1] : 0;
+  for (int e = G.t; e < ne; e += G.nt) {
+    const int k = ek[e];
+    if (k < 0) continue;
     const int idx = k * nchunk + (e >> 6);
     const int base = idx > 0 ? cnt[idx - 1] : 0;
-    col[base + tmp[e]] = o;
+    col[base + tmp[e]] = eo[e];
   }
   __syncthreads();
 }
 
-template <int RT>
-__device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float* dinv) {
-  for (int i = threadIdx.x; i < n; i += RT) {
+__device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float* dinv, const Grp& G) {
+  for (int i = G.t; i < n; i += G.nt) {
     const int d = rowptr[i + 1] - rowptr[i];
     dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
   }
 }
 
-// ---- stage W[H][fin] (global, nn.Linear layout) into LDS as Wt[k][o], rows k>=fin zero ----------
+// ---- layer weights: global -> registers (prefetch) -> LDS (transposed Wt[k][o], rows k>=fin zero) ----
+// The 4 matrices of a layer ([H][fin] each, nn.Linear layout: W_ll, W_src, W_dst, W_vv) and 5
+// H-vectors (b_ll, b_vv, b_gat, att_src, att_dst) form one flat index space so every thread holds
+// WPT = ceil((4*H*H + 5*H)/RT) prefetched values.
 template <int H, int RT>
-__device__ __forceinline__ void stage_wt(const float* __restrict__ Wg, int fin, float* Wt) {
-  for (int idx = threadIdx.x; idx < H * fin; idx += RT) {
-    const int o = idx / fin, k = idx - o * fin;
-    Wt[k * H + o] = Wg[idx];
-  }
-  for (int idx = threadIdx.x + fin * H; idx < H * H; idx += RT) Wt[idx] = 0.f;
-}
-
-// ---- Y[n][H] = X[n][H(zero padded)] * W^T, W given transposed in LDS; optional row dot ----------
-template <int H, int RT>
-__device__ void lin_lds(const float* X, const float* Wt, float* Y, int n, const float* att, float* a_out) {
-  const int o = threadIdx.x % H, r0 = threadIdx.x / H;
-  constexpr int RS = RT / H;
-  if (r0 >= n) return;
-  float w[H];
+struct WStage {
+  static constexpr int TOTAL = 4 * H * H + 5 * H;
+  static constexpr int WPT = (TOTAL + RT - 1) / RT;
+  float v[WPT];
+  __device__ __forceinline__ void fetch(const LayerP& P, bool cv, int fin) {
 #pragma unroll
-  for (int k = 0; k < H; ++k) w[k] = Wt[k * H + o];
-  const float at = att ? att[o] : 0.f;
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      float val = 0.f;
+      if (idx < 4 * H * H) {
+        const int m = idx / (H * H), d = idx - m * H * H;
+        const int k = d / H, o = d - k * H;
+        const float* src = m == 0 ? P.W_ll : (m == 1 ? P.W_src : (m == 2 ? P.W_dst : P.W_vv));
+        if (k < fin && (m == 0 || cv)) val = src[o * fin + k];
+      } else if (idx < TOTAL) {
+        const int j = idx - 4 * H * H;
+        const int q = j / H;
+        const float* src = q == 0 ? P.b_ll : (q == 1 ? P.b_vv : (q == 2 ? P.b_gat : (q == 3 ? P.att_src : P.att_dst)));
+        if (q == 0 || cv) val = src[j - q * H];
+      }
+      v[i] = val;
+    }
+  }
+  __device__ __forceinline__ void store(float* dst) const {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      if (idx < TOTAL) dst[idx] = v[i];
+    }
+  }
+};
+
+// ---- Y[n][H] = X[n][H(zero padded)] * W^T, W transposed in LDS; a lane owns OPT outputs of a row ----
+template <int H, int OPT>
+__device__ void lin_blk(const float* X, const float* Wt, float* Y, int n, const float* att, float* a_out,
+                        const Grp& G) {
+  constexpr int LPR = H / OPT;
+  const int RS = G.nt / LPR;
+  const int og = G.t % LPR, r0 = G.t / LPR;
+  const int o0 = og * OPT;
+  if (r0 >= n) return;
+  float w[OPT][H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+#pragma unroll
+    for (int q = 0; q < OPT; ++q) w[q][k] = Wt[k * H + o0 + q];
+  }
+  float at[OPT];
+#pragma unroll
+  for (int q = 0; q < OPT; ++q) at[q] = att ? att[o0 + q] : 0.f;
   for (int i = r0; i < n; i += RS) {
     const float4* xr = reinterpret_cast<const float4*>(X + i * H);
-    float acc = 0.f;
+    float acc[OPT];
+#pragma unroll
+    for (int q = 0; q < OPT; ++q) acc[q] = 0.f;
 #pragma unroll
     for (int k4 = 0; k4 < H / 4; ++k4) {
       const float4 x = xr[k4];
-      acc = fmaf(x.x, w[4 * k4 + 0], acc);
-      acc = fmaf(x.y, w[4 * k4 + 1], acc);
-      acc = fmaf(x.z, w[4 * k4 + 2], acc);
-      acc = fmaf(x.w, w[4 * k4 + 3], acc);
-    }
-    if (Y) Y[i * H + o] = acc;
-    if (att) {
-      float d = acc * at;
 #pragma unroll
-      for (int off = H >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-      if (o == 0) a_out[i] = d;
+      for (int q = 0; q < OPT; ++q) {
+        acc[q] = fmaf(x.x, w[q][4 * k4 + 0], acc[q]);
+        acc[q] = fmaf(x.y, w[q][4 * k4 + 1], acc[q]);
+        acc[q] = fmaf(x.z, w[q][4 * k4 + 2], acc[q]);
+        acc[q] = fmaf(x.w, w[q][4 * k4 + 3], acc[q]);
+      }
+    }
+    if (Y) {
+#pragma unroll
+      for (int q = 0; q < OPT; ++q) Y[i * H + o0 + q] = acc[q];
+    }
+    if (att) {
+      float d = 0.f;
+#pragma unroll
+      for (int q = 0; q < OPT; ++q) d = fmaf(acc[q], at[q], d);
+#pragma unroll
+      for (int off = LPR >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      if (og == 0) a_out[i] = d;
     }
   }
 }
 
+template <int H>
+struct Blk {  // outputs per lane in lin_blk: W columns (OPT*H floats) must stay in registers at 16 waves/CU
+  static constexpr int OPT = H <= 16 ? 2 : 1;
+};
+
 // ---- Out[i] = act(sum_p (dc[col[p]]*dr[i]) * Hin[col[p]] + bias) ---------------------------------
-template <int H, int RT>
+template <int H>
 __device__ void agg_gcn_lds(const int* rowptr, const int* col, const float* dr, const float* dc,
                             const float* Hin, const float* bias, float* Out, int n, int relu,
-                            float* __restrict__ gout /* global rows or null */) {
+                            float* __restrict__ gout /* global rows or null */, const Grp& G) {
   constexpr int LPR = H / 4;
-  constexpr int RPB = RT / LPR;
-  const int rl = threadIdx.x / LPR, f = (threadIdx.x % LPR) * 4;
+  const int RPB = G.nt / LPR;
+  const int rl = G.t / LPR, f = (G.t % LPR) * 4;
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) b = *reinterpret_cast<const float4*>(bias + f);
   for (int i = rl; i < n; i += RPB) {
@@ -277,25 +338,41 @@ __device__ void agg_gcn_lds(const int* rowptr, const int* col, const float* dr, 
 
 // LDS layout shared by host sizing and kernel carve (all counts in 4-byte words)
 struct FwdLayout {
-  size_t xa, bh, xva, xvb, hv, a_s, a_d, dinv, dinv_v, sc, wt, vecs, vec;
-  size_t rowptr, col, rowptr_lv, col_lv, rowptr_vv, col_vv, cursor, tmp, wsum, total;
+  size_t xa, bh, bs, xva, xvb, hv, a_s, a_d, sc, dinv, dinv_v, wt, headw, part, vec;
+  size_t rowptr, col, rowptr_lv, col_lv, rowptr_vv, col_vv, cursorA, tmpA, cursorB, tmpB, wsum;
+  size_t ek_ll, eo_ll, ek_lv, eo_lv, ek_vv, eo_vv, total;
 };
-__host__ __device__ inline FwdLayout fwd_layout(int H, int max_n, int max_v, int max_ell, int max_evv) {
+__host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max_v, int max_ell, int max_evv,
+                                                int spec) {
   FwdLayout Y;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };  // keep 16-B alignment
   Y.xa = take((size_t)max_n * H);
-  Y.bh = take((size_t)max_n * H);
+  // transform outputs bh | bs; the staged COO slices (needed only before layer 0) overlay them
+  const size_t stage = (size_t)2 * (((size_t)max_ell + 3) / 4 * 4 + ((size_t)max_n + 3) / 4 * 4 +
+                                    ((size_t)max_evv + 3) / 4 * 4);
+  size_t two = (size_t)(spec ? 2 : 1) * max_n * H;
+  const size_t region = take(two > stage ? two : stage);
+  Y.bh = region;
+  Y.bs = spec ? region + (size_t)max_n * H : region;  // sequential mode: bs aliases bh
+  {
+    size_t p = region;
+    auto sub = [&](size_t n) { size_t r = p; p += (n + 3) & ~(size_t)3; return r; };
+    Y.ek_ll = sub(max_ell); Y.eo_ll = sub(max_ell);
+    Y.ek_lv = sub(max_n);   Y.eo_lv = sub(max_n);
+    Y.ek_vv = sub(max_evv); Y.eo_vv = sub(max_evv);
+  }
   Y.xva = take((size_t)max_v * H);
   Y.xvb = take((size_t)max_v * H);
   Y.hv = take((size_t)max_v * H);
   Y.a_s = take(max_n);
   Y.a_d = take(max_v);
+  Y.sc = take(max_n);
   Y.dinv = take(max_n);
   Y.dinv_v = take(max_v);
-  Y.sc = take(max_n);
-  Y.wt = take((size_t)4 * H * H);
-  Y.vecs = take((size_t)5 * H);
+  Y.wt = take((size_t)(H <= 16 ? 2 : 1) * (4 * H * H + 5 * H));  // layer weights (double-buffered when small)
+  Y.headw = take((size_t)H * H + H + (size_t)C * H + C);
+  Y.part = take((size_t)(RT_MAX / 64) * H);           // one H-vector per wave (pool partials)
   Y.vec = take(128);
   Y.rowptr = take(max_n + 1);
   Y.col = take(max_ell);
@@ -303,15 +380,14 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int max_n, int max_v, int
   Y.col_lv = take(max_n);
   Y.rowptr_vv = take(max_v + 1);
   Y.col_vv = take(max_evv);
-  const int maxrows = max_n > max_v ? max_n : max_v;
+  Y.cursorA = take(max_n + 1);
+  Y.tmpA = take(max_ell);
   const int nchunk = (max_n + 63) / 64;
-  size_t cur = (size_t)maxrows + 1;
-  if ((size_t)max_v * nchunk > cur) cur = (size_t)max_v * nchunk;  // multisplit counters reuse the cursor area
-  Y.cursor = take(cur);
-  int maxe = max_ell > max_n ? max_ell : max_n;
-  maxe = maxe > max_evv ? maxe : max_evv;
-  Y.tmp = take(maxe);
-  Y.wsum = take(16);
+  size_t cb = (size_t)max_v + 1;
+  if ((size_t)max_v * nchunk > cb) cb = (size_t)max_v * nchunk;  // multisplit counters
+  Y.cursorB = take(cb);
+  Y.tmpB = take(max_n > max_evv ? max_n : max_evv);
+  Y.wsum = take(32);
   Y.total = o;
   return Y;
 }
@@ -319,6 +395,9 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int max_n, int max_v, int
 template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int OPT = Blk<H>::OPT;
+  constexpr int NW = RT / 64;
+  constexpr int WSZ = 4 * H * H + 5 * H;
   const int g = blockIdx.x;
   const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
@@ -329,154 +408,294 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
     if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
     return;
   }
-  const FwdLayout Y = fwd_layout(H, A.max_n, A.max_v, A.max_ell, A.max_evv);
+  const FwdLayout Y = fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
-  float *xa = fb + Y.xa, *bh = fb + Y.bh, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *hv = fb + Y.hv;
-  float *a_s = fb + Y.a_s, *a_d = fb + Y.a_d, *dinv = fb + Y.dinv, *dinv_v = fb + Y.dinv_v, *sc = fb + Y.sc;
-  float *wt = fb + Y.wt, *vecs = fb + Y.vecs, *vec = fb + Y.vec;
+  float *xa = fb + Y.xa, *bh = fb + Y.bh, *bs = fb + Y.bs, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *hv = fb + Y.hv;
+  float *a_s = fb + Y.a_s, *a_d = fb + Y.a_d, *sc = fb + Y.sc, *dinv = fb + Y.dinv, *dinv_v = fb + Y.dinv_v;
+  float *wt = fb + Y.wt, *headw = fb + Y.headw, *part = fb + Y.part, *vec = fb + Y.vec;
   int *rowptr = ib + Y.rowptr, *col = ib + Y.col, *rowptr_lv = ib + Y.rowptr_lv, *col_lv = ib + Y.col_lv;
-  int *rowptr_vv = ib + Y.rowptr_vv, *col_vv = ib + Y.col_vv, *cursor = ib + Y.cursor, *tmp = ib + Y.tmp;
+  int *rowptr_vv = ib + Y.rowptr_vv, *col_vv = ib + Y.col_vv;
   int* wsum = ib + Y.wsum;
-
-  // ---- structure ----------------------------------------------------------------------
-  STAMP(0);
-  build_csr_lds<RT>(A.ll_dst, A.ll_src, e0, ne, n0, n, n0, n, rowptr, col, cursor, tmp, wsum, A.flag);
-  dinv_from_rowptr<RT>(rowptr, n, dinv);
-  STAMP(1);
-  if (A.compute_virtual) {
-    build_csr_multisplit_lds<RT>(A.lv_dst, A.lv_src, el0, nel, v0, nv, n0, n, rowptr_lv, col_lv, cursor, tmp,
-                                 wsum, A.flag);
-    STAMP(2);
-    build_csr_lds<RT>(A.vv_dst, A.vv_src, ev0, nev, v0, nv, v0, nv, rowptr_vv, col_vv, cursor, tmp, wsum, A.flag);
-    dinv_from_rowptr<RT>(rowptr_vv, nv, dinv_v);
-  }
-  // ---- layer-0 inputs, zero padded to H ------------------------------------------------
+  const bool cv = A.compute_virtual != 0;
   const int F = A.F;
-  for (int idx = threadIdx.x; idx < n * H; idx += RT) {
-    const int i = idx / H, k = idx - i * H;
-    xa[idx] = k < F ? A.x_local[(size_t)(n0 + i) * F + k] : 0.f;
-  }
-  if (A.compute_virtual)
-    for (int idx = threadIdx.x; idx < nv * H; idx += RT) {
-      const int i = idx / H, k = idx - i * H;
-      xva[idx] = k < F ? A.x_virtual[(size_t)(v0 + i) * F + k] : 0.f;
-    }
-  STAMP(3);
 
-  float* b_ll = vecs;
-  float* b_vv = vecs + H;
-  float* b_gat = vecs + 2 * H;
-  float* att_s = vecs + 3 * H;
-  float* att_d = vecs + 4 * H;
-  for (int l = 0; l < A.L; ++l) {
-    const LayerP& P = A.layer[l];
-    const int fin = l == 0 ? F : H;
-    __syncthreads();  // previous layer done with wt / vecs; inputs loaded
-    stage_wt<H, RT>(P.W_ll, fin, wt);
-    if (threadIdx.x < H) b_ll[threadIdx.x] = P.b_ll[threadIdx.x];
-    if (A.compute_virtual) {
-      stage_wt<H, RT>(P.W_src, fin, wt + H * H);
-      stage_wt<H, RT>(P.W_dst, fin, wt + 2 * H * H);
-      stage_wt<H, RT>(P.W_vv, fin, wt + 3 * H * H);
-      if (threadIdx.x < H) {
-        b_vv[threadIdx.x] = P.b_vv[threadIdx.x];
-        b_gat[threadIdx.x] = P.b_gat[threadIdx.x];
-        att_s[threadIdx.x] = P.att_src[threadIdx.x];
-        att_d[threadIdx.x] = P.att_dst[threadIdx.x];
-      }
-    }
-    __syncthreads();
-    STAMP(4 + 8 * l);
-    if (A.compute_virtual) {
-      // local -> virtual GAT: hs = lin_src(x_local), a_s; hd = lin_dst(x_virtual) only through a_d
-      lin_lds<H, RT>(xa, wt + H * H, bh, n, att_s, a_s);
-      lin_lds<H, RT>(xva, wt + 2 * H * H, nullptr, nv, att_d, a_d);
-      // virtual -> virtual GCN transform
-      lin_lds<H, RT>(xva, wt + 3 * H * H, hv, nv, nullptr, nullptr);
-      __syncthreads();
-      STAMP(5 + 8 * l);
-      agg_gcn_lds<H, RT>(rowptr_vv, col_vv, dinv_v, dinv_v, hv, b_vv, xvb, nv, 0, nullptr);
-      __syncthreads();
-      STAMP(6 + 8 * l);
-      // segment softmax + weighted sum, one wave per cluster; added onto the vv output, then ReLU
-      {
-        constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
-        constexpr int S = 64 / LPR;
-        const int lane = threadIdx.x & 63, slot = lane / LPR, f = (lane % LPR) * 4;
-        for (int v = threadIdx.x >> 6; v < nv; v += RT / 64) {
-          const int s = rowptr_lv[v], t = rowptr_lv[v + 1];
-          const float ad = a_d[v];
-          float m = -INFINITY;
-          for (int p = s + lane; p < t; p += 64) {
-            const float e = leaky(a_s[col_lv[p]] + ad, A.slope);
-            sc[p] = e;
-            m = fmaxf(m, e);
-          }
-          m = wave_max(m);
-          float sum = 0.f;
-          for (int p = s + lane; p < t; p += 64) {
-            const float ex = expf(sc[p] - m);
-            sc[p] = ex;
-            sum += ex;
-          }
-          sum = wave_sum(sum);
-          const float denom = sum + 1e-16f;
-          for (int p = s + lane; p < t; p += 64) sc[p] = sc[p] / denom;
-          // LDS ops of one wave complete in order: the slot loop below sees the alphas
-          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int p = s + slot; p < t; p += S) {
-            const int j = col_lv[p];
-            const float al = sc[p];
-            const float4 hvv = *reinterpret_cast<const float4*>(bh + j * H + f);
-            acc.x = fmaf(al, hvv.x, acc.x);
-            acc.y = fmaf(al, hvv.y, acc.y);
-            acc.z = fmaf(al, hvv.z, acc.z);
-            acc.w = fmaf(al, hvv.w, acc.w);
-          }
+  // wave groups: with the virtual branch on, the upper half of the waves works on it
+  const int wave = threadIdx.x >> 6;
+  const int NA = cv ? NW / 2 : NW;  // structure build always splits when the virtual branch is on
+  const bool inB = wave >= NA;
+  const Grp ALL{(int)threadIdx.x, RT, wave, NW};
+  const Grp GA{(int)threadIdx.x, NA * 64, wave, NA};
+  const Grp GB{(int)threadIdx.x - NA * 64, (NW - NA) * 64, wave - NA, NW - NA};
+
+  // ---- prologue: request every global input of this graph, then consume -----------------------
+  STAMP(0);
+  WStage<H, RT> ws;
+  ws.fetch(A.layer[0], cv, F);
+  constexpr int EPT = 4;   // edges per thread held in registers (covers RT*EPT edges per relation)
+  constexpr int XPT = 8;   // feature words per thread held in registers
+  int kll[EPT], oll[EPT], klv[EPT], olv[EPT], kvv[EPT], ovv[EPT];
+  float xr[XPT], xvr[2], hw0 = 0.f, hw1 = 0.f;
 #pragma unroll
-          for (int off = 32; off >= LPR; off >>= 1) {
-            acc.x += __shfl_xor(acc.x, off, 64);
-            acc.y += __shfl_xor(acc.y, off, 64);
-            acc.z += __shfl_xor(acc.z, off, 64);
-            acc.w += __shfl_xor(acc.w, off, 64);
-          }
-          if (slot == 0) {
-            const float4 bg = *reinterpret_cast<const float4*>(b_gat + f);
-            float4 prev = *reinterpret_cast<const float4*>(xvb + v * H + f);
-            prev.x = fmaxf(prev.x + (acc.x + bg.x), 0.f);
-            prev.y = fmaxf(prev.y + (acc.y + bg.y), 0.f);
-            prev.z = fmaxf(prev.z + (acc.z + bg.z), 0.f);
-            prev.w = fmaxf(prev.w + (acc.w + bg.w), 0.f);
-            *reinterpret_cast<float4*>(xvb + v * H + f) = prev;
-          }
-        }
+  for (int i = 0; i < EPT; ++i) {
+    const int e = threadIdx.x + i * RT;
+    kll[i] = oll[i] = klv[i] = olv[i] = kvv[i] = ovv[i] = -1;
+    if (e < ne) { kll[i] = (int)(A.ll_dst[e0 + e] - n0); oll[i] = (int)(A.ll_src[e0 + e] - n0); }
+    if (cv && e < nel) { klv[i] = (int)(A.lv_dst[el0 + e] - v0); olv[i] = (int)(A.lv_src[el0 + e] - n0); }
+    if (cv && e < nev) { kvv[i] = (int)(A.vv_dst[ev0 + e] - v0); ovv[i] = (int)(A.vv_src[ev0 + e] - v0); }
+  }
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    const int r = idx / H, k = idx - r * H;
+    xr[i] = (idx < n * H && k < F) ? A.x_local[(size_t)(n0 + r) * F + k] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    const int r = idx / H, k = idx - r * H;
+    xvr[i] = (cv && idx < nv * H && k < F) ? A.x_virtual[(size_t)(v0 + r) * F + k] : 0.f;
+  }
+  {  // head weights: W1 [H][H] | b1 [H] | W2 [C][H] | b2 [C]   (natural layout), two words per thread
+    const int HT = H * H + H + A.C * H + A.C;
+    auto hsrc = [&](int idx) -> float {
+      if (idx < H * H) return A.W1[idx];
+      idx -= H * H;
+      if (idx < H) return A.b1[idx];
+      idx -= H;
+      if (idx < A.C * H) return A.W2[idx];
+      return A.b2[idx - A.C * H];
+    };
+    if ((int)threadIdx.x < HT) hw0 = hsrc(threadIdx.x);
+    if ((int)threadIdx.x + RT < HT) hw1 = hsrc(threadIdx.x + RT);
+    // anything beyond 2*RT words (H = 64 or very wide heads) is copied directly
+    for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = hsrc(idx);
+  }
+  // ---- consume: validate + park in LDS ---------------------------------------------------------
+  {
+    int *ek_ll = ib + Y.ek_ll, *eo_ll = ib + Y.eo_ll, *ek_lv = ib + Y.ek_lv, *eo_lv = ib + Y.eo_lv;
+    int *ek_vv = ib + Y.ek_vv, *eo_vv = ib + Y.eo_vv;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * RT;
+      if (e < ne) {
+        int k = kll[i];
+        if (k < 0 || k >= n || oll[i] < 0 || oll[i] >= n) { bad = true; k = -1; }
+        ek_ll[e] = k; eo_ll[e] = oll[i];
       }
-      __syncthreads();
-      STAMP(7 + 8 * l);
-      {  // swap virtual buffers
-        float* t_ = xva; xva = xvb; xvb = t_;
+      if (cv && e < nel) {
+        int k = klv[i];
+        if (k < 0 || k >= nv || olv[i] < 0 || olv[i] >= n) { bad = true; k = -1; }
+        ek_lv[e] = k; eo_lv[e] = olv[i];
+      }
+      if (cv && e < nev) {
+        int k = kvv[i];
+        if (k < 0 || k >= nv || ovv[i] < 0 || ovv[i] >= nv) { bad = true; k = -1; }
+        ek_vv[e] = k; eo_vv[e] = ovv[i];
       }
     }
-    // local -> local GCN: transform into bh, gather-reduce back into xa (xa is dead after the transform)
-    lin_lds<H, RT>(xa, wt, bh, n, nullptr, nullptr);
-    __syncthreads();
-    STAMP(8 + 8 * l);
-    agg_gcn_lds<H, RT>(rowptr, col, dinv, dinv, bh, b_ll, xa, n, 1, A.acts + ((size_t)l * A.N + n0) * H);
-    STAMP(9 + 8 * l);
+    // slices longer than RT*EPT edges (not the LRGB case): straight copy
+    for (int e = threadIdx.x + EPT * RT; e < ne; e += RT) {
+      int k = (int)(A.ll_dst[e0 + e] - n0); const int o = (int)(A.ll_src[e0 + e] - n0);
+      if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; }
+      ek_ll[e] = k; eo_ll[e] = o;
+    }
+    if (cv) {
+      for (int e = threadIdx.x + EPT * RT; e < nel; e += RT) {
+        int k = (int)(A.lv_dst[el0 + e] - v0); const int o = (int)(A.lv_src[el0 + e] - n0);
+        if (k < 0 || k >= nv || o < 0 || o >= n) { bad = true; k = -1; }
+        ek_lv[e] = k; eo_lv[e] = o;
+      }
+      for (int e = threadIdx.x + EPT * RT; e < nev; e += RT) {
+        int k = (int)(A.vv_dst[ev0 + e] - v0); const int o = (int)(A.vv_src[ev0 + e] - v0);
+        if (k < 0 || k >= nv || o < 0 || o >= nv) { bad = true; k = -1; }
+        ek_vv[e] = k; eo_vv[e] = o;
+      }
+    }
+    if (bad && A.flag) atomicOr(A.flag, 2);
+  }
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx < n * H) xa[idx] = xr[i];
+  }
+  for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) {
+    const int r = idx / H, k = idx - r * H;
+    xa[idx] = k < F ? A.x_local[(size_t)(n0 + r) * F + k] : 0.f;
+  }
+  if (cv) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      if (idx < nv * H) xva[idx] = xvr[i];
+    }
+    for (int idx = threadIdx.x + 2 * RT; idx < nv * H; idx += RT) {
+      const int r = idx / H, k = idx - r * H;
+      xva[idx] = k < F ? A.x_virtual[(size_t)(v0 + r) * F + k] : 0.f;
+    }
+  }
+  {
+    const int HT = H * H + H + A.C * H + A.C;
+    if ((int)threadIdx.x < HT) headw[threadIdx.x] = hw0;
+    if ((int)threadIdx.x + RT < HT) headw[threadIdx.x + RT] = hw1;
+  }
+  ws.store(wt);
+  __syncthreads();
+  STAMP(1);
+  // ---- structure: group A builds ll while group B builds vv; then everyone builds lv ----------
+  if (cv) {
+    if (!inB) {
+      build_csr_lds(ib + Y.ek_ll, ib + Y.eo_ll, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, wsum, GA);
+      dinv_from_rowptr(rowptr, n, dinv, GA);
+    } else {
+      build_csr_lds(ib + Y.ek_vv, ib + Y.eo_vv, nev, nv, rowptr_vv, col_vv, ib + Y.cursorB, ib + Y.tmpB, wsum + 16,
+                    GB);
+      dinv_from_rowptr(rowptr_vv, nv, dinv_v, GB);
+    }
+    STAMP(2);
+    build_csr_multisplit_lds(ib + Y.ek_lv, ib + Y.eo_lv, nel, nv, rowptr_lv, col_lv, ib + Y.cursorB, ib + Y.tmpB,
+                             wsum, ALL);
+  } else {
+    build_csr_lds(ib + Y.ek_ll, ib + Y.eo_ll, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, wsum, ALL);
+    dinv_from_rowptr(rowptr, n, dinv, ALL);
+    STAMP(2);
   }
   __syncthreads();
+  STAMP(3);
 
-  if (A.compute_virtual && A.xv_out)
+  for (int l = 0; l < A.L; ++l) {
+    constexpr bool DB = H <= 16;               // two weight buffers: the next layer's land under this layer's math
+    float* W = wt + (DB ? (l & 1) * WSZ : 0);
+    float* Wn = wt + (DB ? ((l + 1) & 1) * WSZ : 0);
+    const float* b_ll = W + 4 * H * H;
+    const float* b_vv = b_ll + H;
+    const float* b_gat = b_ll + 2 * H;
+    const float* att_s = b_ll + 3 * H;
+    const float* att_d = b_ll + 4 * H;
+    const bool more = l + 1 < A.L;
+    // fetch the next layer's weights now, park them in LDS under this layer's math
+    if (more && DB) ws.fetch(A.layer[l + 1], cv, H);
+    STAMP(4 + 4 * l);
+    auto transforms_ll = [&](const Grp& G_) { lin_blk<H, OPT>(xa, W, bh, n, nullptr, nullptr, G_); };
+    auto transforms_virtual = [&](const Grp& G_) {
+      lin_blk<H, OPT>(xa, W + H * H, bs, n, att_s, a_s, G_);               // lv source side (+ a_src)
+      lin_blk<H, OPT>(xva, W + 2 * H * H, nullptr, nv, att_d, a_d, G_);    // lv target side only through a_dst
+      lin_blk<H, OPT>(xva, W + 3 * H * H, hv, nv, nullptr, nullptr, G_);   // vv
+    };
+    auto reduce_ll = [&](const Grp& G_) {
+      agg_gcn_lds<H>(rowptr, col, dinv, dinv, bh, b_ll, xa, n, 1, A.acts + ((size_t)l * A.N + n0) * H, G_);
+    };
+    // one wave per cluster: vv gather-reduce for its row + segment softmax over its members
+    auto reduce_virtual = [&](const Grp& G_) {
+      constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
+      constexpr int S = 64 / LPR;
+      const int lane = threadIdx.x & 63, slot = lane / LPR, f = (lane % LPR) * 4;
+      for (int v = G_.w; v < nv; v += G_.nw) {
+        const int s = rowptr_lv[v], t = rowptr_lv[v + 1];
+        const float ad = a_d[v];
+        float m = -INFINITY;
+        for (int p = s + lane; p < t; p += 64) {
+          const float e = leaky(a_s[col_lv[p]] + ad, A.slope);
+          sc[p] = e;
+          m = fmaxf(m, e);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int p = s + lane; p < t; p += 64) {
+          const float ex = expf(sc[p] - m);
+          sc[p] = ex;
+          sum += ex;
+        }
+        sum = wave_sum(sum);
+        const float denom = sum + 1e-16f;
+        for (int p = s + lane; p < t; p += 64) sc[p] = sc[p] / denom;
+        // LDS operations of one wave complete in order: the slot loop sees the alphas
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = s + slot; p < t; p += S) {
+          const int j = col_lv[p];
+          const float al = sc[p];
+          const float4 hvv = *reinterpret_cast<const float4*>(bs + j * H + f);
+          acc.x = fmaf(al, hvv.x, acc.x);
+          acc.y = fmaf(al, hvv.y, acc.y);
+          acc.z = fmaf(al, hvv.z, acc.z);
+          acc.w = fmaf(al, hvv.w, acc.w);
+        }
+#pragma unroll
+        for (int off = 32; off >= LPR; off >>= 1) {
+          acc.x += __shfl_xor(acc.x, off, 64);
+          acc.y += __shfl_xor(acc.y, off, 64);
+          acc.z += __shfl_xor(acc.z, off, 64);
+          acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        if (slot == 0) {
+          // virtual -> virtual GCN row v (edge order, separately rounded), + b_vv
+          const int s2 = rowptr_vv[v], t2 = rowptr_vv[v + 1];
+          const float di = dinv_v[v];
+          float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int p = s2; p < t2; ++p) {
+            const int j = col_vv[p];
+            const float w_ = mul_rn(dinv_v[j], di);
+            const float4 x = *reinterpret_cast<const float4*>(hv + j * H + f);
+            a.x = add_rn(a.x, mul_rn(w_, x.x));
+            a.y = add_rn(a.y, mul_rn(w_, x.y));
+            a.z = add_rn(a.z, mul_rn(w_, x.z));
+            a.w = add_rn(a.w, mul_rn(w_, x.w));
+          }
+          const float4 bv = *reinterpret_cast<const float4*>(b_vv + f);
+          const float4 bg = *reinterpret_cast<const float4*>(b_gat + f);
+          a.x = fmaxf((a.x + bv.x) + (acc.x + bg.x), 0.f);
+          a.y = fmaxf((a.y + bv.y) + (acc.y + bg.y), 0.f);
+          a.z = fmaxf((a.z + bv.z) + (acc.z + bg.z), 0.f);
+          a.w = fmaxf((a.w + bv.w) + (acc.w + bg.w), 0.f);
+          *reinterpret_cast<float4*>(xvb + v * H + f) = a;
+        }
+      }
+    };
+    if (cv && A.spec) {
+      // two barriers per layer: the ll path (group A) and the virtual branch (group B) side by side
+      if (!inB) transforms_ll(GA); else transforms_virtual(GB);
+      if (more && DB) ws.store(Wn);
+      __syncthreads();
+      STAMP(5 + 4 * l);
+      if (!inB) reduce_ll(GA); else reduce_virtual(GB);
+      __syncthreads();
+    } else {
+      // one n x H transform buffer: the virtual branch first, then the ll path
+      if (cv) {
+        transforms_virtual(ALL);
+        __syncthreads();
+        reduce_virtual(ALL);
+        __syncthreads();
+      }
+      transforms_ll(ALL);
+      if (more && DB) ws.store(Wn);
+      __syncthreads();
+      STAMP(5 + 4 * l);
+      reduce_ll(ALL);
+      __syncthreads();
+    }
+    if (more && !DB) {  // single weight buffer: everybody is done with it now
+      ws.fetch(A.layer[l + 1], cv, H);
+      ws.store(Wn);
+      __syncthreads();
+    }
+    STAMP(6 + 4 * l);
+    if (cv) {  // swap virtual buffers
+      float* t_ = xva; xva = xvb; xvb = t_;
+    }
+  }
+
+  if (cv && A.xv_out)
     for (int idx = threadIdx.x; idx < nv * H; idx += RT) A.xv_out[(size_t)v0 * H + idx] = xva[idx];
 
-  // ---- global_mean_pool + head, wave 0 ---------------------------------------------------
-  if (threadIdx.x < 64) {
+  // ---- global_mean_pool: every wave sums a strided row set, wave 0 folds in wave order -----------
+  {
     constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
     constexpr int S = 64 / LPR;
-    const int lane = threadIdx.x, slot = lane / LPR, f = (lane % LPR) * 4;
+    const int lane = threadIdx.x & 63, slot = lane / LPR, f = (lane % LPR) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = slot; i < n; i += S) {
+    for (int i = wave * S + slot; i < n; i += NW * S) {
       const float4 v = *reinterpret_cast<const float4*>(xa + i * H + f);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
@@ -487,42 +706,55 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
       acc.z += __shfl_xor(acc.z, off, 64);
       acc.w += __shfl_xor(acc.w, off, 64);
     }
-    const float cnt = (float)(n > 0 ? n : 1);
+    if (slot == 0) *reinterpret_cast<float4*>(part + wave * H + f) = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
     float* pooled = vec;
     float* zz = vec + 64;
-    if (slot == 0) {
-      pooled[f + 0] = acc.x / cnt; pooled[f + 1] = acc.y / cnt; pooled[f + 2] = acc.z / cnt; pooled[f + 3] = acc.w / cnt;
-    }
-    // one wave: LDS writes above are visible to its own later reads
+    const float cnt = (float)(n > 0 ? n : 1);
     if (lane < H) {
-      A.pooled[(size_t)g * H + lane] = pooled[lane];
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += part[w * H + lane];
+      s = s / cnt;
+      pooled[lane] = s;
+      A.pooled[(size_t)g * H + lane] = s;
+    }
+    // one wave: its LDS writes are visible to its own later reads
+    if (lane < H) {
       float a1 = 0.f;
-      const float4* wr = reinterpret_cast<const float4*>(A.W1 + lane * H);
+      const float4* wr = reinterpret_cast<const float4*>(headw + lane * H);
 #pragma unroll
       for (int k4 = 0; k4 < H / 4; ++k4) {
         const float4 w4 = wr[k4];
-        a1 = fmaf(pooled[4 * k4 + 0], w4.x, a1);
-        a1 = fmaf(pooled[4 * k4 + 1], w4.y, a1);
-        a1 = fmaf(pooled[4 * k4 + 2], w4.z, a1);
-        a1 = fmaf(pooled[4 * k4 + 3], w4.w, a1);
+        const float4 p4 = *reinterpret_cast<const float4*>(pooled + 4 * k4);
+        a1 = fmaf(p4.x, w4.x, a1);
+        a1 = fmaf(p4.y, w4.y, a1);
+        a1 = fmaf(p4.z, w4.z, a1);
+        a1 = fmaf(p4.w, w4.w, a1);
       }
-      a1 += A.b1[lane];
+      a1 += headw[H * H + lane];
       a1 = apply_act(a1, A.head_act);
       zz[lane] = a1;
       A.z[(size_t)g * H + lane] = a1;
     }
+    const float* W2l = headw + H * H + H;
+    const float* b2l = W2l + A.C * H;
     for (int c = lane; c < A.C; c += 64) {
       float a2 = 0.f;
-      const float4* wr = reinterpret_cast<const float4*>(A.W2 + c * H);
+      const float4* wr = reinterpret_cast<const float4*>(W2l + c * H);
 #pragma unroll
       for (int k4 = 0; k4 < H / 4; ++k4) {
         const float4 w4 = wr[k4];
-        a2 = fmaf(zz[4 * k4 + 0], w4.x, a2);
-        a2 = fmaf(zz[4 * k4 + 1], w4.y, a2);
-        a2 = fmaf(zz[4 * k4 + 2], w4.z, a2);
-        a2 = fmaf(zz[4 * k4 + 3], w4.w, a2);
+        const float4 z4 = *reinterpret_cast<const float4*>(zz + 4 * k4);
+        a2 = fmaf(z4.x, w4.x, a2);
+        a2 = fmaf(z4.y, w4.y, a2);
+        a2 = fmaf(z4.z, w4.z, a2);
+        a2 = fmaf(z4.w, w4.w, a2);
       }
-      A.pred[(size_t)g * A.C + c] = a2 + A.b2[c];
+      A.pred[(size_t)g * A.C + c] = a2 + b2l[c];
     }
   }
   STAMP(63);
@@ -530,24 +762,30 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
 
 // =============================== backward =====================================================
 struct BwdLayout {
-  size_t G, GH, X, dinv, vec, red, wl, rowptr_t, col_t, cursor, tmp, wsum, total;
+  size_t G, GH, X, dinv, vec, red, wl, headw, rowptr_t, col_t, cursor, tmp, wsum, ek, eo, total;
 };
-__host__ __device__ inline BwdLayout bwd_layout(int H, int max_n, int max_ell) {
+__host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max_ell) {
   BwdLayout Y;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
   Y.G = take((size_t)max_n * H);
-  Y.GH = take((size_t)max_n * H);
+  // GH is first written in layer L-1; before that its space holds the staged COO slice
+  const size_t st = (size_t)2 * (((size_t)max_ell + 3) / 4 * 4);
+  const size_t gh = (size_t)max_n * H;
+  Y.GH = take(gh > st ? gh : st);
+  Y.ek = Y.GH;
+  Y.eo = Y.GH + ((size_t)max_ell + 3) / 4 * 4;
   Y.X = take((size_t)max_n * H);
   Y.dinv = take(max_n);
-  Y.vec = take(256);
-  Y.red = take((size_t)RT_MAX);  // bias / weight-gradient slice partials
+  Y.vec = take(256 + 64);
+  Y.red = take((size_t)RT_MAX);  // per pass: NW waves x 4 tiles x 16 entries
   Y.wl = take((size_t)H * H);
+  Y.headw = take((size_t)H * H + (size_t)C * H + C);  // W1 | W2 | g_pred row
   Y.rowptr_t = take(max_n + 1);
   Y.col_t = take(max_ell);
   Y.cursor = take(max_n + 1);
   Y.tmp = take(max_ell);
-  Y.wsum = take(16);
+  Y.wsum = take(32);
   Y.total = o;
   return Y;
 }
@@ -555,6 +793,8 @@ __host__ __device__ inline BwdLayout bwd_layout(int H, int max_n, int max_ell) {
 template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int OPT = Blk<H>::OPT;
+  constexpr int NW = RT / 64;
   const int g = blockIdx.x;
   const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
@@ -564,182 +804,313 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
     for (int i = threadIdx.x; i < A.P; i += RT) part[i] = 0.f;
     return;
   }
-  const BwdLayout Y = bwd_layout(H, A.max_n, A.max_ell);
+  const BwdLayout Y = bwd_layout(H, A.C, A.max_n, A.max_ell);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   float *G = fb + Y.G, *GH = fb + Y.GH, *X = fb + Y.X, *dinv = fb + Y.dinv, *vec = fb + Y.vec;
-  float *red = fb + Y.red, *wl = fb + Y.wl;
+  float *red = fb + Y.red, *wl = fb + Y.wl, *headw = fb + Y.headw;
   int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t, *cursor = ib + Y.cursor, *tmp = ib + Y.tmp;
-  int* wsum = ib + Y.wsum;
+  int *wsum = ib + Y.wsum, *ek = ib + Y.ek, *eo = ib + Y.eo;
+  const int L = A.L;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Grp ALL{(int)threadIdx.x, RT, wave, NW};
 
+  // ---- prologue: request all global inputs of the first phases at once ------------------------
   STAMP(0);
-  // in-degree (by target) -> dinv, through the cursor array
+  float* W1l = headw;
+  float* W2l = headw + H * H;
+  float* gpl = W2l + A.C * H;
+  float* zz = vec + 64;      // z
+  float* gz = vec + 128;     // dL/d(lin_1 output, pre-activation)
+  float* gpool = vec + 192;
+  float* pol = vec + 256;    // pooled
+  constexpr int EPT = 4, XPT = 8;
+  int ks[EPT], os[EPT];
+  float yr[XPT], hw0 = 0.f, hw1 = 0.f, zv = 0.f, pv = 0.f;
+  const int HT = H * H + A.C * H + A.C;
+  auto hsrc = [&](int idx) -> float {
+    if (idx < H * H) return A.W1[idx];
+    idx -= H * H;
+    if (idx < A.C * H) return A.W2[idx];
+    return A.g_pred[(size_t)g * A.C + (idx - A.C * H)];
+  };
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = threadIdx.x + i * RT;
+    ks[i] = os[i] = -1;
+    if (e < ne) { ks[i] = (int)(A.ll_src[e0 + e] - n0); os[i] = (int)(A.ll_dst[e0 + e] - n0); }  // key = SOURCE
+  }
+  const float* yL = A.acts + ((size_t)(L - 1) * A.N + n0) * H;
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    yr[i] = idx < n * H ? yL[idx] : 0.f;
+  }
+  if ((int)threadIdx.x < HT) hw0 = hsrc(threadIdx.x);
+  if ((int)threadIdx.x + RT < HT) hw1 = hsrc(threadIdx.x + RT);
+  for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = hsrc(idx);
+  if (threadIdx.x < H) {
+    zv = A.z[(size_t)g * H + threadIdx.x];
+    pv = A.pooled[(size_t)g * H + threadIdx.x];
+  }
+  {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * RT;
+      if (e < ne) {
+        int k = ks[i];
+        if (k < 0 || k >= n || os[i] < 0 || os[i] >= n) { bad = true; k = -1; }
+        ek[e] = k; eo[e] = os[i];
+      }
+    }
+    for (int e = threadIdx.x + EPT * RT; e < ne; e += RT) {
+      int k = (int)(A.ll_src[e0 + e] - n0); const int o = (int)(A.ll_dst[e0 + e] - n0);
+      if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; }
+      ek[e] = k; eo[e] = o;
+    }
+    if (bad && A.flag) atomicOr(A.flag, 2);
+  }
+  // last layer's output (ReLU mask source) -> X; it is also the next layer's input further down
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx < n * H) X[idx] = yr[i];
+  }
+  for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) X[idx] = yL[idx];
+  if ((int)threadIdx.x < HT) headw[threadIdx.x] = hw0;
+  if ((int)threadIdx.x + RT < HT) headw[threadIdx.x + RT] = hw1;
+  if (threadIdx.x < H) {
+    zz[threadIdx.x] = zv;
+    pol[threadIdx.x] = pv;
+  }
   for (int i = threadIdx.x; i <= n; i += RT) cursor[i] = 0;
   __syncthreads();
-  for (int e = threadIdx.x; e < ne; e += RT) {
-    const int d = (int)(A.ll_dst[e0 + e] - n0), s = (int)(A.ll_src[e0 + e] - n0);
-    if (d >= 0 && d < n && s >= 0 && s < n) atomicAdd(&cursor[d], 1);
-  }
+  STAMP(1);
+  // in-degree (by target) -> dinv
+  for (int e = threadIdx.x; e < ne; e += RT)
+    if (ek[e] >= 0) atomicAdd(&cursor[eo[e]], 1);
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += RT) {
     const int d = cursor[i];
     dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
   }
   __syncthreads();
-  build_csr_lds<RT>(A.ll_src, A.ll_dst, e0, ne, n0, n, n0, n, rowptr_t, col_t, cursor, tmp, wsum, A.flag);
-  STAMP(1);
+  build_csr_lds(ek, eo, ne, n, rowptr_t, col_t, cursor, tmp, wsum, ALL);
+  STAMP(2);
 
   // ---- head backward ---------------------------------------------------------------------------
-  float* zz = vec + 64;     // z
-  float* gz = vec + 128;    // dL/d(lin_1 output, pre-activation)
-  float* gpool = vec + 192;
   // partial layout: per layer {W_ll [H*fin], b_ll [H]}, then W1 [H*H], b1 [H], W2 [C*H], b2 [C]
   int off_head = 0;
-  for (int l = 0; l < A.L; ++l) off_head += H * (l == 0 ? A.F : H) + H;
+  for (int l = 0; l < L; ++l) off_head += H * (l == 0 ? A.F : H) + H;
   const int oW1 = off_head, ob1 = oW1 + H * H, oW2 = ob1 + H, ob2 = oW2 + A.C * H;
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    if (lane < H) {
-      const float zv = A.z[(size_t)g * H + lane];
-      zz[lane] = zv;
-      // g_zpre[k] = (sum_c g_pred[c] W2[c][k]) * act'(z[k])
-      float acc = 0.f;
-      for (int c = 0; c < A.C; ++c) acc = fmaf(A.g_pred[(size_t)g * A.C + c], A.W2[c * H + lane], acc);
-      gz[lane] = acc * act_grad_from_output(zv, A.head_act);
-    }
+  if (threadIdx.x < H) {
+    // g_zpre[k] = (sum_c g_pred[c] W2[c][k]) * act'(z[k])
+    float acc = 0.f;
+    for (int c = 0; c < A.C; ++c) acc = fmaf(gpl[c], W2l[c * H + threadIdx.x], acc);
+    gz[threadIdx.x] = acc * act_grad_from_output(zz[threadIdx.x], A.head_act);
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < A.C * H; idx += RT) {
     const int c = idx / H, k = idx - c * H;
-    part[oW2 + idx] = A.g_pred[(size_t)g * A.C + c] * zz[k];
+    part[oW2 + idx] = gpl[c] * zz[k];
   }
-  for (int c = threadIdx.x; c < A.C; c += RT) part[ob2 + c] = A.g_pred[(size_t)g * A.C + c];
+  for (int c = threadIdx.x; c < A.C; c += RT) part[ob2 + c] = gpl[c];
   for (int idx = threadIdx.x; idx < H * H; idx += RT) {
     const int o = idx / H, k = idx - o * H;
-    part[oW1 + idx] = gz[o] * A.pooled[(size_t)g * H + k];
+    part[oW1 + idx] = gz[o] * pol[k];
   }
   if (threadIdx.x < H) {
     part[ob1 + threadIdx.x] = gz[threadIdx.x];
     float acc = 0.f;
-    for (int o = 0; o < H; ++o) acc = fmaf(gz[o], A.W1[o * H + threadIdx.x], acc);
+#pragma unroll
+    for (int o = 0; o < H; ++o) acc = fmaf(gz[o], W1l[o * H + threadIdx.x], acc);
     gpool[threadIdx.x] = acc;
   }
   __syncthreads();
-  // dL/d x_L[i][f] = g_pool[f] / n
+  // dL/d x_L[i][f] = g_pool[f] / n, masked by ReLU of the saved output (in X)
   {
     const float cnt = (float)(n > 0 ? n : 1);
-    for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = gpool[idx % H] / cnt;
+    for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = X[idx] > 0.f ? gpool[idx % H] / cnt : 0.f;
   }
-  STAMP(2);
+  STAMP(3);
 
   int off = off_head;
-  for (int l = A.L - 1; l >= 0; --l) {
+  for (int l = L - 1; l >= 0; --l) {
     const int fin = l == 0 ? A.F : H;
     off -= H * fin + H;
     const int oW = off, ob = off + H * fin;
-    __syncthreads();
-    // ReLU mask from the saved layer output; layer input -> X (zero padded); W_ll -> LDS
-    const float* y = A.acts + ((size_t)l * A.N + n0) * H;
-    for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = y[idx] > 0.f ? G[idx] : 0.f;
-    if (l == 0) {
-      for (int idx = threadIdx.x; idx < n * H; idx += RT) {
-        const int i = idx / H, k = idx - i * H;
-        X[idx] = k < fin ? A.x_local[(size_t)(n0 + i) * fin + k] : 0.f;
-      }
-    } else {
-      const float* xin = A.acts + ((size_t)(l - 1) * A.N + n0) * H;
-      for (int idx = threadIdx.x; idx < n * H; idx += RT) X[idx] = xin[idx];
-      for (int idx = threadIdx.x; idx < H * H; idx += RT) wl[idx] = A.W_ll[l][idx];
+    __syncthreads();  // G (masked) complete; X free to be overwritten
+    // layer input -> X (zero padded) and this layer's W_ll -> LDS.  The loads are issued first and
+    // parked in LDS after the gather-reduce: their HBM latency hides under it.
+    float xr[XPT], wr_[(H * H + RT - 1) / RT];
+    const float* xin = l == 0 ? A.x_local + (size_t)n0 * fin : A.acts + ((size_t)(l - 1) * A.N + n0) * H;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      const int r = idx / H, k = idx - r * H;
+      xr[i] = (idx < n * H && k < fin) ? xin[(size_t)r * fin + k] : 0.f;
     }
-    __syncthreads();
-    STAMP(3 + 6 * l);
-    // bias gradient: column sums of G, RT/H row chunks then ordered fold
-    {
-      const int f = threadIdx.x % H, c = threadIdx.x / H;
-      constexpr int CH = RT / H;
+#pragma unroll
+    for (int i = 0; i < (H * H + RT - 1) / RT; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      wr_[i] = (l > 0 && idx < H * H) ? A.W_ll[l][idx] : 0.f;
+    }
+    // bias gradient: wave per feature column, lanes split the rows, wave fold
+    for (int f = wave; f < H; f += NW) {
       float s = 0.f;
-      for (int i = c; i < n; i += CH) s += G[i * H + f];
-      red[threadIdx.x] = s;
+      for (int i = lane; i < n; i += 64) s += G[i * H + f];
+      s = wave_sum(s);
+      if (lane == 0) part[ob + f] = s;
     }
     // dL/d(transform output) = A_hat^T G  (transposed CSR, edge order)
-    agg_gcn_lds<H, RT>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, nullptr);
-    __syncthreads();
-    STAMP(4 + 6 * l);
-    if (threadIdx.x < H) {
-      constexpr int CH = RT / H;
-      float s = 0.f;
-      for (int c = 0; c < CH; ++c) s += red[c * H + threadIdx.x];
-      part[ob + threadIdx.x] = s;
+    agg_gcn_lds<H>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, nullptr, ALL);
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      if (idx < n * H) X[idx] = xr[i];
+    }
+    for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) {
+      const int r = idx / H, k = idx - r * H;
+      X[idx] = k < fin ? xin[(size_t)r * fin + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < (H * H + RT - 1) / RT; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      if (idx < H * H) wl[idx] = wr_[i];
     }
     __syncthreads();
-    // weight gradient: gW[o][k] = sum_j GH[j][o] * X[j][k]; rows split into NS interleaved
-    // slices per entry (NS consecutive threads), folded in slice order
+    STAMP(4 + 4 * l);
+    // weight gradient gW[o][k] = sum_j GH[j][o] * X[j][k]: 4x4 tiles of (o,k); a 16-lane DPP row
+    // owns a tile, its lanes and NRG wave-groups split the rows; 16 register accumulators per
+    // lane, DPP row fold, then the NRG partials are folded in order through LDS.
     {
-      const int ent = H * fin;
-      int NS = RT / ent;
-      NS = NS < 1 ? 1 : (NS > 4 ? 4 : NS);
-      const int per_pass = RT / NS;
-      const int local = threadIdx.x / NS, sl = threadIdx.x % NS;
-      for (int base = 0; base < ent; base += per_pass) {
-        const int idx = base + local;
-        const bool live = idx < ent && local < per_pass;
-        float acc = 0.f;
+      constexpr int TPD = H / 4;            // tiles per dimension
+      constexpr int NT = TPD * TPD;         // tiles
+      constexpr int TPW = 4;                // tiles per wave (one per DPP row)
+      const int row = lane >> 4, l16 = lane & 15;
+      const int ntg = (NT + TPW - 1) / TPW;                 // tile groups
+      const int NRG = NW / ntg > 0 ? (NW / ntg > 4 ? 4 : NW / ntg) : 1;  // row groups (waves per tile group)
+      for (int tg0 = 0; tg0 < ntg; tg0 += NW / NRG) {
+        const int tg = tg0 + wave / NRG, rg = wave % NRG;
+        const int tile = tg * TPW + row;
+        const bool live = tg < ntg && tile < NT && wave < (NW / NRG) * NRG;
+        float acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+        const int o4 = live ? (tile / TPD) * 4 : 0, k4 = live ? (tile % TPD) * 4 : 0;
         if (live) {
-          const int o = idx / fin, k = idx - o * fin;
-          for (int j = sl; j < n; j += NS) acc = fmaf(GH[j * H + o], X[j * H + k], acc);
+          for (int j = rg * 16 + l16; j < n; j += 16 * NRG) {
+            const float4 gv = *reinterpret_cast<const float4*>(GH + j * H + o4);
+            const float4 xv = *reinterpret_cast<const float4*>(X + j * H + k4);
+            const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+            const float xb[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(ga[a], xb[b], acc[a][b]);
+          }
         }
-        red[threadIdx.x] = acc;
+        float mine = 0.f;  // after the row fold lane l16 keeps entry (a,b) = (l16>>2, l16&3)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const float v = row16_sum(acc[a][b]);
+            if (l16 == a * 4 + b) mine = v;
+          }
+        const int tpp = (NW / NRG) * TPW;  // tiles per pass
+        if (live) red[(rg * tpp + (tile - tg0 * TPW)) * 16 + l16] = mine;
         __syncthreads();
-        if (live && sl == 0) {
-          float s = 0.f;
-          for (int q = 0; q < NS; ++q) s += red[threadIdx.x + q];
-          part[oW + idx] = s;
+        for (int idx = threadIdx.x; idx < (NW / NRG) * TPW * 16; idx += RT) {
+          const int t_ = tg0 * TPW + idx / 16, e_ = idx & 15;
+          if (t_ < NT) {
+            float s = 0.f;
+            for (int r = 0; r < NRG; ++r) s += red[(r * tpp + idx / 16) * 16 + e_];
+            const int oo = (t_ / TPD) * 4 + (e_ >> 2), kk = (t_ % TPD) * 4 + (e_ & 3);
+            if (kk < fin) part[oW + oo * fin + kk] = s;
+          }
         }
         __syncthreads();
       }
     }
-    STAMP(5 + 6 * l);
-    // input gradient: G[j][k] = sum_o GH[j][o] * W[o][k]   (W is [H][H] here)
+    STAMP(5 + 4 * l);
+    // input gradient: G[j][k] = relu'(x_l[j][k]) * sum_o GH[j][o] * W[o][k]   (W is [H][H] here;
+    // x_l = this layer's input = previous layer's output, already in X)
     if (l > 0) {
-      const int k = threadIdx.x % H, r0 = threadIdx.x / H;
-      constexpr int RS = RT / H;
+      constexpr int LPR = H / OPT;
+      constexpr int RS = RT / LPR;
+      const int kg = threadIdx.x % LPR, r0 = threadIdx.x / LPR;
+      const int k0 = kg * OPT;
       if (r0 < n) {
-        float w[H];
+        float w[OPT][H];
 #pragma unroll
-        for (int o = 0; o < H; ++o) w[o] = wl[o * H + k];
+        for (int o = 0; o < H; ++o)
+#pragma unroll
+          for (int q = 0; q < OPT; ++q) w[q][o] = wl[o * H + k0 + q];
         for (int j = r0; j < n; j += RS) {
           const float4* gr = reinterpret_cast<const float4*>(GH + j * H);
-          float acc = 0.f;
+          float acc[OPT];
+#pragma unroll
+          for (int q = 0; q < OPT; ++q) acc[q] = 0.f;
 #pragma unroll
           for (int o4 = 0; o4 < H / 4; ++o4) {
             const float4 v = gr[o4];
-            acc = fmaf(v.x, w[4 * o4 + 0], acc);
-            acc = fmaf(v.y, w[4 * o4 + 1], acc);
-            acc = fmaf(v.z, w[4 * o4 + 2], acc);
-            acc = fmaf(v.w, w[4 * o4 + 3], acc);
+#pragma unroll
+            for (int q = 0; q < OPT; ++q) {
+              acc[q] = fmaf(v.x, w[q][4 * o4 + 0], acc[q]);
+              acc[q] = fmaf(v.y, w[q][4 * o4 + 1], acc[q]);
+              acc[q] = fmaf(v.z, w[q][4 * o4 + 2], acc[q]);
+              acc[q] = fmaf(v.w, w[q][4 * o4 + 3], acc[q]);
+            }
           }
-          G[j * H + k] = acc;
+#pragma unroll
+          for (int q = 0; q < OPT; ++q) G[j * H + k0 + q] = X[j * H + k0 + q] > 0.f ? acc[q] : 0.f;
         }
       }
     }
-    STAMP(6 + 6 * l);
+    STAMP(6 + 4 * l);
   }
   STAMP(63);
 }
 
-// out[p] = sum_g partials[g][p], g ascending
-__global__ void k_param_reduce(const float* __restrict__ partials, float* __restrict__ out, int B, int P) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+// out[p] = sum_g partials[g][p]: a block owns 32 parameters x 8 contiguous graph slices (coalesced
+// over p), each slice summed in graph order, slices folded in slice order -> fixed summation tree
+__global__ void __launch_bounds__(256) k_param_reduce(const float* __restrict__ partials, float* __restrict__ out,
+                                                      int B, int P) {
+  __shared__ float red[8][32];
+  const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int p = blockIdx.x * 32 + pl;
+  const int per = (B + 7) / 8;
+  const int g0 = sl * per, g1 = (g0 + per) < B ? (g0 + per) : B;
   float s = 0.f;
-  for (int g = 0; g < B; ++g) s += partials[(size_t)g * P + p];
-  out[p] = s;
+  if (p < P) {
+    int g = g0;
+    for (; g + 4 <= g1; g += 4) {  // four loads in flight, added in graph order
+      const float a = partials[(size_t)g * P + p], b = partials[(size_t)(g + 1) * P + p];
+      const float c = partials[(size_t)(g + 2) * P + p], d = partials[(size_t)(g + 3) * P + p];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; g < g1; ++g) s += partials[(size_t)g * P + p];
+  }
+  red[sl][pl] = s;
+  __syncthreads();
+  if (sl == 0 && p < P) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][pl];
+    out[p] = t;
+  }
 }
 
-inline size_t fwd_lds_bytes(int H, int max_n, int max_v, int max_ell, int max_evv) {
-  return fwd_layout(H, max_n, max_v, max_ell, max_evv).total * 4;
+inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int spec) {
+  return fwd_layout(H, C, max_n, max_v, max_ell, max_evv, spec).total * 4;
 }
-inline size_t bwd_lds_bytes(int H, int max_n, int max_ell) { return bwd_layout(H, max_n, max_ell).total * 4; }
+inline size_t bwd_lds_bytes(int H, int C, int max_n, int max_ell) {
+  return bwd_layout(H, C, max_n, max_ell).total * 4;
+}
 
 // Workgroup size: 16 waves (4 per SIMD) hide the LDS / global latency of the many short
 // phases; tiny graphs (PCQM-Contact, n <= 64) do not have the rows to feed them.
@@ -753,8 +1124,11 @@ int launch_fwd_rt(const FwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
   return 0;
 }
 template <int H>
-int launch_fwd(const FwdArgs& A, int64_t B, hipStream_t st) {
-  const size_t lds = fwd_lds_bytes(H, A.max_n, A.max_v, A.max_ell, A.max_evv);
+int launch_fwd(FwdArgs& A, int64_t B, hipStream_t st) {
+  // concurrent wave groups need a third n x H buffer: use them when it fits (and leaves the CU usable)
+  A.spec = A.compute_virtual &&
+           fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, 1) <= 160 * 1024 ? 1 : 0;
+  const size_t lds = fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec);
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
   return A.max_n <= 64 ? launch_fwd_rt<H, 256>(A, B, lds, st) : launch_fwd_rt<H, 1024>(A, B, lds, st);
 }
@@ -769,7 +1143,7 @@ int launch_bwd_rt(const BwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
 }
 template <int H>
 int launch_bwd(const BwdArgs& A, int64_t B, hipStream_t st) {
-  const size_t lds = bwd_lds_bytes(H, A.max_n, A.max_ell);
+  const size_t lds = bwd_lds_bytes(H, A.C, A.max_n, A.max_ell);
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
   return A.max_n <= 64 ? launch_bwd_rt<H, 256>(A, B, lds, st) : launch_bwd_rt<H, 1024>(A, B, lds, st);
 }
@@ -785,10 +1159,10 @@ int hscn_diag_set_stamp_buffer(long long* buf) {
 #endif
 
 int hscn_resident_supported(int F, int H, int L, int C, int max_n, int max_v, int max_ell, int max_evv) {
-  if (!(H == 16 || H == 32 || H == 64) || F < 1 || F > H || L < 1 || L > MAXL || C < 1) return 0;
+  if (!(H == 16 || H == 32 || H == 64) || F < 1 || F > H || L < 1 || L > MAXL || C < 1 || C > 4096) return 0;
   if (max_n < 0 || max_v < 0 || max_ell < 0 || max_evv < 0) return 0;
-  if (fwd_lds_bytes(H, max_n, max_v, max_ell, max_evv) > 160 * 1024) return 0;
-  if (bwd_lds_bytes(H, max_n, max_ell) > 160 * 1024) return 0;
+  if (fwd_lds_bytes(H, C, max_n, max_v, max_ell, max_evv, 0) > 160 * 1024) return 0;
+  if (bwd_lds_bytes(H, C, max_n, max_ell) > 160 * 1024) return 0;
   return 1;
 }
 
@@ -832,7 +1206,7 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
   A.acts = acts; A.pooled = pooled; A.z = z; A.pred = pred; A.xv_out = xv_out; A.flag = flag;
   A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_v = max_v; A.max_ell = max_ell; A.max_evv = max_evv;
-  A.compute_virtual = compute_virtual; A.slope = slope;
+  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0;
   hipStream_t st = hscn_stream(stream_);
   switch (H) {
     case 16: return launch_fwd<16>(A, B, st);
@@ -871,7 +1245,7 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
     case 64: rc = launch_bwd<64>(A, B, st); break;
   }
   if (rc) return rc;
-  k_param_reduce<<<hscn_blocks(A.P, 256), 256, 0, st>>>(partials, grads, (int)B, A.P);
+  k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -215,6 +215,17 @@ int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t num_edges,
                       float* adj /*[n,n]*/, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Loss tail (reference graph_hscn/loss.py:6-19, called at train/train.py:82) on the
+ * [B,C] prediction, kind 0 = BCEWithLogits(mean), 1 = L1(mean):
+ *   loss[0] = mean loss, score = sigmoid(pred) (may be NULL), grad = dloss/dpred.
+ * hscn_scale: y = g[0] * x (the backward of the loss given the upstream scalar).
+ * ------------------------------------------------------------------------- */
+int hscn_criterion_fwd(const float* pred, const float* target, int64_t count, int kind,
+                       float* loss /*[1]*/, float* score /*[count] or NULL*/, float* grad /*[count]*/,
+                       void* stream);
+int hscn_scale(const float* g /*[1]*/, const float* x, float* y, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * a10  HSCN.forward / backward, graph-resident engine
  * (reference model/hscn.py:102-114 with lv=GAT, ll=GCN, vv=GCN; the loop
  * train/train.py:76,87 drives it).  The batch must be block-diagonal with graph

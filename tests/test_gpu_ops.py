@@ -252,3 +252,19 @@ def test_ops_refuse_cpu_tensors():
     from graph_hscn.nn import functional as Fh
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Fh.linear(torch.randn(4, 4), torch.randn(4, 4))
+
+
+@pytest.mark.parametrize("loss_fn,C", [("cross_entropy", 10), ("l1", 11)])
+def test_fused_criterion_matches_reference_loss(loss_fn, C):
+    from graph_hscn.loss import criterion
+    from oracle.models import criterion as ocrit
+    g = torch.Generator().manual_seed(C)
+    pred = torch.randn(128, C, generator=g) * 3
+    true = (torch.rand(128, C, generator=g) < 0.2).float() if loss_fn == "cross_entropy" else torch.randn(128, C, generator=g)
+    po, pd = pred.clone().requires_grad_(), pred.to(DEV).requires_grad_()
+    lo, so = ocrit(loss_fn, po, true)
+    ld, sd = criterion(loss_fn, pd, true.to(DEV))
+    (lo * 1.7).backward()
+    (ld * 1.7).backward()
+    assert abs(lo.item() - ld.item()) < 1e-6 and close(sd, so, atol=1e-6)
+    assert close(pd.grad, po.grad, atol=1e-8, rtol=1e-5)

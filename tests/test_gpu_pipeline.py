@@ -1,0 +1,39 @@
+"""End-to-end stage order of the reference's main.py:100-119 on the HIP path:
+SCN -> train_clustering -> generate_hetero_data -> hetero_loaders -> HSCN -> train."""
+import logging
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stage_a_b_c_pipeline_runs_and_learns():
+    from graph_hscn.config.config import DataConfig, HSCNConfig, OptimConfig, TrainingConfig
+    from graph_hscn.loader.hetero_data import generate_hetero_data, hetero_loaders
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import SCN, build_hscn
+    from graph_hscn.train.train import train
+    from graph_hscn.train.train_clustering import train_clustering
+    torch.manual_seed(0)
+    log = logging.getLogger("t")
+    graphs = make_dataset("peptides_func", 24, seed=0)
+    mc = HSCNConfig("relu", num_clusters=8, cluster_epochs=1)
+    oc = OptimConfig("adam", lr=0.01)
+    tc = TrainingConfig("hscn", "cross_entropy", "ap", epochs=3, eval_period=1, patience=10)
+    dc = DataConfig("peptides_func", batch_size=8)
+    scn = SCN(mc.mp_units, "elu", 9, mc.num_clusters).to("cuda")
+    clusters = train_clustering(log, graphs, scn, mc, oc, tc)                       # reference trajectory: 1 graph / step
+    assert len(clusters) == 24
+    assert all(c.shape[0] == g.num_nodes and c.dtype == np.int64 for c, g in zip(clusters, graphs))
+    assert all(0 <= c.min() and c.max() < 8 for c in clusters)
+    clusters_b = train_clustering(log, graphs, SCN(mc.mp_units, "elu", 9, 8).to("cuda"), mc, oc, tc, batch_graphs=8)
+    assert len(clusters_b) == 24 and all(c.shape[0] == g.num_nodes for c, g in zip(clusters_b, graphs))
+    split = {"train": torch.arange(0, 16), "val": torch.arange(16, 20), "test": torch.arange(20, 24)}
+    hs = generate_hetero_data(clusters, graphs, split, dc, mc, log)
+    loaders = hetero_loaders(dc, hs, split)
+    model = build_hscn(mc, 9, 10).to("cuda")
+    hist = train(log, oc, tc, loaders, model)
+    assert len(hist) == 3 and hist[-1][0] < hist[0][0]                              # loss goes down
+    assert model.last_engine == "resident"

@@ -42,10 +42,10 @@ def main():
     sizes = np.diff(hb_host["local"].ptr.numpy())
     total = st[:, 63] - st[:, 0]
     order = np.argsort(total)
-    names = {0: "start", 1: "ll csr", 2: "lv+vv csr", 3: "load x"}
+    names = {0: "start", 1: "prologue loads", 2: "ll | vv csr", 3: "lv csr"}
     for l in range(3):
-        names.update({4 + 8 * l: f"L{l} begin", 5 + 8 * l: f"L{l} lin src/dst/vv", 6 + 8 * l: f"L{l} vv agg",
-                      7 + 8 * l: f"L{l} gat", 8 + 8 * l: f"L{l} lin ll", 9 + 8 * l: f"L{l} ll agg"})
+        names.update({4 + 4 * l: f"L{l} begin", 5 + 4 * l: f"L{l} transforms (A: ll | B: lv,vv)",
+                      6 + 4 * l: f"L{l} reduce (A: ll | B: gat+vv)"})
     names[63] = "pool+head"
     keys = sorted(names)
     for tag, g in (("slowest", order[-1]), ("median", order[len(order) // 2]), ("fastest", order[0])):
@@ -61,12 +61,11 @@ def main():
     out.sum().backward()
     torch.cuda.synchronize()
     st = buf.cpu().numpy()
-    bn = {0: "start", 1: "dinv + csr^T", 2: "head bwd"}
+    bn = {0: "start", 1: "prologue loads", 2: "dinv + csr^T", 3: "head bwd"}
     for l in (2, 1, 0):
-        bn.update({3 + 6 * l: f"L{l} mask+load X,W", 4 + 6 * l: f"L{l} bias part + A^T G", 5 + 6 * l: f"L{l} gW",
-                   6 + 6 * l: f"L{l} gX"})
+        bn.update({4 + 4 * l: f"L{l} load X,W + bias + A^T G", 5 + 4 * l: f"L{l} gW", 6 + 4 * l: f"L{l} gX"})
     bn[63] = "end"
-    order_keys = [0, 1, 2] + [k + 6 * l for l in (2, 1, 0) for k in (3, 4, 5, 6)] + [63]
+    order_keys = [0, 1, 2, 3] + [k + 4 * l for l in (2, 1, 0) for k in (4, 5, 6)] + [63]
     total = st[:, 63] - st[:, 0]
     order = np.argsort(total)
     for tag, g in (("bwd slowest", order[-1]), ("bwd median", order[len(order) // 2])):
