@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--structure", default="per-step", choices=["per-step", "cached"],
                     help="per-step: COO->CSR build is inside every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streaming-spmm", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -322,6 +323,15 @@ def main():
                         "frac": ll_b / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": ll_b, "avg_launch_us": t * 1e6, "launches_timed": n_l}
 
+    # ---- the streaming (layered-engine) ll SpMM at a bandwidth-resident shape:
+    # the same generator tiled to 4096 graphs, hidden 128 -- the shape where "HBM roofline" means something
+    streaming = None
+    if rank == 0 and not args.no_streaming_spmm:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_spmm
+        streaming = bench_spmm.measure(32, 128, 20, dev=dev)
+        streaming["peak_GBs"] = HBM_PEAK_GBS
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(hb_host, args, C, loss_fn, args.cpu_seconds)
@@ -340,7 +350,7 @@ def main():
                        "virtual_nodes_per_gpu": int(hb["virtual"].num_nodes),
                        "mode": args.mode, "engine": model.last_engine, "structure_build": args.structure,
                        "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "streaming_spmm_scaled": streaming,
         }
         if cpu:
             out["vs_cpu_baseline"] = value / cpu["value"]

@@ -8,6 +8,7 @@
 // accumulate in CSR slot order with separately rounded multiply and add: the
 // order and rounding of the CPU reference's gather -> scale -> index_add_.
 #include "hscn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -44,31 +45,61 @@ struct Vec<1> {
 };
 
 // MODE 0: w = dinv_c[col]*dinv_r[row] (GCN)   MODE 1: w = wts[eid ? eid[p] : p] or 1
-template <int VEC, int MODE>
+// A lane owns NV consecutive VEC-wide pieces of its row (NV=2 at width >= 64: twice the bytes in
+// flight per lane -- the gather is latency-bound, three dependent loads deep: rowptr -> col -> h).
+template <int VEC, int MODE, int NV>
 __global__ void __launch_bounds__(SP_THREADS)
 k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
        const float* __restrict__ dinv_r, const float* __restrict__ dinv_c, const float* __restrict__ wts,
        const float* __restrict__ h, const float* __restrict__ bias, float* __restrict__ out,
-       int64_t num_rows, int width, int LPR, int RPB, int accumulate, int act) {
+       int64_t num_rows, int width, int LPR, int RPB, int accumulate, int act, int64_t rows_per_block,
+       int xcd_map) {
   using V = Vec<VEC>;
   const int rl = threadIdx.x / LPR;
-  const int f = (threadIdx.x - rl * LPR) * VEC;
+  const int f = (threadIdx.x - rl * LPR) * VEC * NV;
   if (rl >= RPB) return;
-  for (int64_t r = (int64_t)blockIdx.x * RPB + rl; r < num_rows; r += (int64_t)gridDim.x * RPB) {
+  // rows_per_block > 0: every block owns one contiguous row range; with xcd_map the ranges of the
+  // blocks that share an XCD (blockIdx % 8, round-robin dispatch) are adjacent, so a gathered
+  // neighbour row is usually in that XCD's L2.  rows_per_block == 0: grid-stride over rows.
+  int64_t r_begin, r_end, r_step;
+  if (rows_per_block > 0) {
+    const int64_t nb = gridDim.x;
+    const int64_t vb = (xcd_map && nb % 8 == 0) ? ((int64_t)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8)
+                                                 : (int64_t)blockIdx.x;
+    r_begin = vb * rows_per_block + rl;
+    r_end = vb * rows_per_block + rows_per_block;
+    if (r_end > num_rows) r_end = num_rows;
+    r_step = RPB;
+  } else {
+    r_begin = (int64_t)blockIdx.x * RPB + rl;
+    r_end = num_rows;
+    r_step = (int64_t)gridDim.x * RPB;
+  }
+  for (int64_t r = r_begin; r < r_end; r += r_step) {
     const int s = rowptr[r], t = rowptr[r + 1];
-    typename V::T acc = V::zero();
+    typename V::T acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = V::zero();
     float dr = 0.f;
     if (MODE == 0) dr = dinv_r[r];
+#pragma unroll 2
     for (int p = s; p < t; ++p) {
       const int j = col[p];
       float w;
       if (MODE == 0) w = mul_rn(dinv_c[j], dr);
       else w = wts ? wts[eid ? eid[p] : p] : 1.0f;
-      acc = V::axpy(w, V::load(h + (size_t)j * width + f), acc);
+      const float* hj = h + (size_t)j * width + f;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) acc[q] = V::axpy(w, V::load(hj + q * VEC), acc[q]);
     }
-    if (bias) acc = V::add(acc, V::load(bias + f));
-    if (accumulate) acc = V::add(acc, V::load(out + (size_t)r * width + f));
-    V::store(out + (size_t)r * width + f, V::act(acc, act));
+    float* o = out + (size_t)r * width + f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      typename V::T a = acc[q];
+      if (bias) a = V::add(a, V::load(bias + f + q * VEC));
+      if (accumulate) a = V::add(a, V::load(o + q * VEC));
+      V::store(o + q * VEC, V::act(a, act));
+    }
   }
 }
 
@@ -76,18 +107,37 @@ template <int MODE>
 int launch_spmm(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const float* dinv_r,
                 const float* dinv_c, const float* wts, const float* h, const float* bias, float* out,
                 int64_t num_rows, int width, int accumulate, int act, hipStream_t st) {
+  static const int xcd_map = getenv("HSCN_SPMM_XCD") ? atoi(getenv("HSCN_SPMM_XCD")) : 0;
+  static const int passes = getenv("HSCN_SPMM_PASSES") ? atoi(getenv("HSCN_SPMM_PASSES")) : 0;  // 0 = grid-stride
+  static const int nv_env = getenv("HSCN_SPMM_NV") ? atoi(getenv("HSCN_SPMM_NV")) : 0;
   const int VEC = (width % 4 == 0) ? 4 : 1;
-  const int LPR = width / VEC;
+  // measured on MI355X (tools/bench_spmm.py, 4096 Peptides graphs): NV=2 lifts H=128 from 3.0 to
+  // 4.1 TB/s; NV=4 falls back to 3.2 TB/s; contiguous / XCD-grouped row ranges do not beat grid-stride
+  int NV = (VEC == 4 && width % 8 == 0 && width >= 64) ? 2 : 1;
+  if (nv_env == 4 && width % 16 == 0 && width >= 128) NV = 4;
+  else if (nv_env == 1) NV = 1;
+  const int LPR = width / (VEC * NV);
   if (LPR > SP_THREADS) return HSCN_E_UNSUPPORTED;
   const int RPB = SP_THREADS / LPR;
-  int64_t nb = (num_rows + RPB - 1) / RPB;
-  if (nb > 8192) nb = 8192;
-  if (VEC == 4)
-    k_spmm<4, MODE><<<(unsigned)nb, SP_THREADS, 0, st>>>(rowptr, col, eid, dinv_r, dinv_c, wts, h, bias, out,
-                                                         num_rows, width, LPR, RPB, accumulate, act);
-  else
-    k_spmm<1, MODE><<<(unsigned)nb, SP_THREADS, 0, st>>>(rowptr, col, eid, dinv_r, dinv_c, wts, h, bias, out,
-                                                         num_rows, width, LPR, RPB, accumulate, act);
+  int64_t nb, rpb = 0;
+  if (passes > 0) {
+    nb = (num_rows + (int64_t)RPB * passes - 1) / ((int64_t)RPB * passes);
+    if (nb > 65536) nb = 65536;
+    nb = (nb + 7) / 8 * 8;
+    rpb = (num_rows + nb - 1) / nb;
+    rpb = (rpb + RPB - 1) / RPB * RPB;
+  } else {
+    nb = (num_rows + RPB - 1) / RPB;
+    if (nb > 8192) nb = 8192;
+  }
+#define HSCN_SPMM_LAUNCH(V_, N_)                                                                              \
+  k_spmm<V_, MODE, N_><<<(unsigned)nb, SP_THREADS, 0, st>>>(rowptr, col, eid, dinv_r, dinv_c, wts, h, bias, out, \
+                                                            num_rows, width, LPR, RPB, accumulate, act, rpb, xcd_map)
+  if (VEC == 4 && NV == 4) HSCN_SPMM_LAUNCH(4, 4);
+  else if (VEC == 4 && NV == 2) HSCN_SPMM_LAUNCH(4, 2);
+  else if (VEC == 4) HSCN_SPMM_LAUNCH(4, 1);
+  else HSCN_SPMM_LAUNCH(1, 1);
+#undef HSCN_SPMM_LAUNCH
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
