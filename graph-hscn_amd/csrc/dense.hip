@@ -1,0 +1,338 @@
+// Dense route of dense_mincut_pool (reference model/hscn.py:61-63):
+// the cluster-assignment contractions  A S,  S^T (A S),  S^T S,  S^T X  on the matrix cores.
+//
+// gfx950 has an exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: D = A*B + C as a k-ordered fmaf
+// chain, no reduced-precision step), so the 1e-5 parity bar holds without any split-precision
+// trick.  One batched kernel serves all four products: a workgroup owns a 64 x N tile of one
+// batch element (4 waves x 16 rows, N/16 accumulator tiles each), A and B tiles are staged
+// through LDS with coalesced 16-byte global loads (zero padded at the ragged edges), the
+// optional transpose of A (S^T ...) is a different LDS read pattern, not a different load.
+// MFMA-bound only at PascalVOC-SP sizes (n ~ 480, K = 64: 33 MFLOP per graph); at Peptides
+// sizes the sparse route (mincut.hip) does 8x less work.
+#include "hscn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GM = 64;   // rows of C per workgroup
+constexpr int GK = 32;   // reduction depth per LDS stage
+constexpr int GNMAX = 64;
+
+// C[b] (M x N) = op(A[b]) (M x Kd) * B[b] (Kd x N);  op = transpose when TA (A stored Kd x M)
+template <int TA>
+__global__ void __launch_bounds__(256)
+k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, int M, int N, int Kd,
+        int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int NT /* N tiles of 16 */) {
+  constexpr int AST = GK + 4;                        // padded row stride of the [m][k] image (bank spread, 16-B aligned)
+  __shared__ __align__(16) float As[GM * AST];     // TA=0: [m][k];  TA=1: [k][m] (stride GM)
+  __shared__ __align__(16) float Bs[GK * GNMAX];   // [k][n]
+  const int b = blockIdx.y;
+  const int m0 = blockIdx.x * GM;
+  A += (size_t)b * sA;
+  Bm += (size_t)b * sB;
+  C += (size_t)b * sC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  f32x4 acc[GNMAX / 16];
+#pragma unroll
+  for (int t = 0; t < GNMAX / 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int NP = NT * 16;
+
+  for (int k0 = 0; k0 < Kd; k0 += GK) {
+    __syncthreads();
+    if (TA == 0) {
+      // A tile rows m0..m0+63, cols k0..k0+31: 64 x 32 floats = 512 float4, two per thread
+      for (int idx = threadIdx.x; idx < GM * GK / 4; idx += 256) {
+        const int r = idx / (GK / 4), c4 = (idx % (GK / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gr = m0 + r, gc = k0 + c4;
+        if (gr < M) {
+          const float* p = A + (size_t)gr * lda + gc;
+          if (gc + 3 < Kd && ((lda & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+          else {
+            if (gc < Kd) v.x = p[0];
+            if (gc + 1 < Kd) v.y = p[1];
+            if (gc + 2 < Kd) v.z = p[2];
+            if (gc + 3 < Kd) v.w = p[3];
+          }
+        }
+        *reinterpret_cast<float4*>(&As[r * AST + c4]) = v;
+      }
+    } else {
+      // A stored [Kd][M]: tile rows k0..k0+31, cols m0..m0+63 -> LDS [k][m]
+      for (int idx = threadIdx.x; idx < GK * GM / 4; idx += 256) {
+        const int r = idx / (GM / 4), c4 = (idx % (GM / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gr = k0 + r, gc = m0 + c4;
+        if (gr < Kd) {
+          const float* p = A + (size_t)gr * lda + gc;
+          if (gc + 3 < M && ((lda & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+          else {
+            if (gc < M) v.x = p[0];
+            if (gc + 1 < M) v.y = p[1];
+            if (gc + 2 < M) v.z = p[2];
+            if (gc + 3 < M) v.w = p[3];
+          }
+        }
+        *reinterpret_cast<float4*>(&As[r * GM + c4]) = v;
+      }
+    }
+    // B tile rows k0..k0+31, cols 0..NP-1
+    for (int idx = threadIdx.x; idx < GK * NP / 4; idx += 256) {
+      const int r = idx / (NP / 4), c4 = (idx % (NP / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gr = k0 + r;
+      if (gr < Kd) {
+        const float* p = Bm + (size_t)gr * ldb + c4;
+        if (c4 + 3 < N && ((ldb & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (c4 < N) v.x = p[0];
+          if (c4 + 1 < N) v.y = p[1];
+          if (c4 + 2 < N) v.z = p[2];
+          if (c4 + 3 < N) v.w = p[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&Bs[r * GNMAX + c4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      // A operand: lane holds A[i = lane&15][k = lane>>4]
+      const float a = TA ? As[(kk + lk) * GM + wave * 16 + li] : As[(wave * 16 + li) * AST + kk + lk];
+#pragma unroll
+      for (int t = 0; t < GNMAX / 16; ++t) {
+        if (t < NT) {
+          const float bv = Bs[(kk + lk) * GNMAX + t * 16 + li];  // B[k = lane>>4][j = lane&15]
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C/D layout: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int t = 0; t < GNMAX / 16; ++t) {
+    if (t < NT) {
+      const int col = t * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wave * 16 + lk * 4 + r;
+        if (row < M && col < N) C[(size_t)row * ldc + col] = acc[t][r];
+      }
+    }
+  }
+}
+
+__global__ void k_softmax_rows_d(const float* __restrict__ logits, float* __restrict__ S, int64_t n, int K) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = logits + i * K;
+  float m = r[0];
+  for (int k = 1; k < K; ++k) m = fmaxf(m, r[k]);
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) sum += expf(r[k] - m);
+  for (int k = 0; k < K; ++k) S[i * K + k] = expf(r[k] - m) / sum;
+}
+
+// deg[b][i] = sum_k adj[b][i][k]   (wave per row, ordered fold)
+__global__ void k_rowsum(const float* __restrict__ adj, float* __restrict__ deg, int64_t rows, int n) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = adj + row * n;
+  float s = 0.f;
+  for (int k = lane; k < n; k += 64) s += p[k];
+  s = wave_sum(s);
+  if (lane == 0) deg[row] = s;
+}
+
+// per graph: num = tr(oa), den = sum_i deg_i |S_i|^2, |ss|_F, ortho; normalise oa in place
+__global__ void __launch_bounds__(256)
+k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, const float* __restrict__ ss,
+                 float* __restrict__ oa, float* __restrict__ stats, int n, int K) {
+  extern __shared__ float lds[];
+  float* dn = lds;          // [K]
+  float* red = lds + K;     // [4]
+  const int g = blockIdx.x;
+  const int KK = K * K;
+  const float* Sg = S + (size_t)g * n * K;
+  const float* dg = deg + (size_t)g * n;
+  const float* ssg = ss + (size_t)g * KK;
+  float* oag = oa + (size_t)g * KK;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    float num = 0.f;
+    for (int a = lane; a < K; a += 64) num += oag[a * K + a];
+    num = wave_sum(num);
+    float den = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      float q = 0.f;
+      for (int k = 0; k < K; ++k) q = fmaf(Sg[(size_t)i * K + k], Sg[(size_t)i * K + k], q);
+      den = fmaf(dg[i], q, den);
+    }
+    den = wave_sum(den);
+    float n2 = 0.f;
+    for (int i = lane; i < KK; i += 64) n2 += ssg[i] * ssg[i];
+    n2 = wave_sum(n2);
+    const float nrm = sqrtf(n2);
+    const float isk = 1.0f / sqrtf((float)K);
+    float o2 = 0.f;
+    for (int i = lane; i < KK; i += 64) {
+      const int a = i / K, b = i - a * K;
+      const float q = ssg[i] / nrm - (a == b ? isk : 0.f);
+      o2 += q * q;
+    }
+    o2 = wave_sum(o2);
+    if (lane == 0) {
+      stats[g * 4 + 0] = num;
+      stats[g * 4 + 1] = den;
+      stats[g * 4 + 2] = nrm;
+      stats[g * 4 + 3] = sqrtf(o2);
+    }
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < K; a += 256) {
+    float s = 0.f;
+    for (int b = 0; b < K; ++b) s += (a == b) ? 0.f : oag[a * K + b];
+    dn[a] = sqrtf(s) + 1e-15f;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+    const int a = idx / K, b = idx - a * K;
+    oag[idx] = (a == b) ? 0.f : (oag[idx] / dn[b]) / dn[a];
+  }
+  (void)red;
+}
+
+__global__ void k_losses_d(const float* __restrict__ stats, float* __restrict__ losses, int G) {
+  float mc = 0.f, o = 0.f;
+  for (int g = threadIdx.x; g < G; g += 64) {
+    mc += -(stats[g * 4 + 0] / stats[g * 4 + 1]);
+    o += stats[g * 4 + 3];
+  }
+  mc = wave_sum(mc);
+  o = wave_sum(o);
+  if (threadIdx.x == 0) {
+    losses[0] = mc / (float)G;
+    losses[1] = o / (float)G;
+  }
+}
+
+// g_logits from (AS + A^T S), deg, S, ss, stats (same algebra as the sparse route's backward)
+__global__ void __launch_bounds__(256)
+k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const float* __restrict__ AtS,
+            const float* __restrict__ deg, const float* __restrict__ stats, const float* __restrict__ ss,
+            const float* __restrict__ g_losses, float* __restrict__ g_logits, int n, int K, int G) {
+  extern __shared__ float lds[];
+  const int KK = K * K;
+  float* Gss = lds;         // [K][K]
+  float* red = lds + KK;    // [2]
+  const int g = blockIdx.x;
+  const float num = stats[g * 4 + 0], den = stats[g * 4 + 1], nrm = stats[g * 4 + 2], o = stats[g * 4 + 3];
+  const float gmc = g_losses[0] / (float)G, go = g_losses[1] / (float)G;
+  const float isk = 1.0f / sqrtf((float)K);
+  const float* ssg = ss + (size_t)g * KK;
+  if (threadIdx.x < 64) {
+    float v = 0.f;
+    if (o > 0.f)
+      for (int i = threadIdx.x; i < KK; i += 64) {
+        const int a = i / K, b = i - a * K;
+        v += ((ssg[i] / nrm - (a == b ? isk : 0.f)) / o) * ssg[i];
+      }
+    v = wave_sum(v);
+    if (threadIdx.x == 0) red[0] = v;
+  }
+  __syncthreads();
+  const float inner = red[0];
+  for (int i = threadIdx.x; i < KK; i += 256) {
+    const int a = i / K, b = i - a * K;
+    const float gq = o > 0.f ? (ssg[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
+    Gss[i] = (gq - inner / (nrm * nrm) * ssg[i]) / nrm;
+  }
+  __syncthreads();
+  const float c_num = -gmc / den, c_den = gmc * num / (den * den);
+  const size_t base = (size_t)g * n * K;
+  // one thread per node row (K <= 64: the row lives in registers twice over the loop)
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float* Si = S + base + (size_t)i * K;
+    const float di = deg[(size_t)g * n + i];
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) {
+      float orth = 0.f;
+      for (int a = 0; a < K; ++a) orth = fmaf(Si[a], Gss[a * K + k], orth);
+      const float dS = c_num * (AS[base + (size_t)i * K + k] + AtS[base + (size_t)i * K + k]) +
+                       c_den * 2.f * di * Si[k] + go * 2.f * orth;
+      g_logits[base + (size_t)i * K + k] = dS;  // parked; rescaled below
+      dot = fmaf(dS, Si[k], dot);
+    }
+    for (int k = 0; k < K; ++k) {
+      const float dS = g_logits[base + (size_t)i * K + k];
+      g_logits[base + (size_t)i * K + k] = Si[k] * (dS - dot);
+    }
+  }
+}
+
+int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N, int Kd, int64_t lda, int64_t ldb,
+          int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int transA, hipStream_t st) {
+  if (N < 1 || N > GNMAX) return HSCN_E_UNSUPPORTED;
+  const int NT = (N + 15) / 16;
+  dim3 grid((M + GM - 1) / GM, (unsigned)batch);
+  if (transA)
+    k_bgemm<1><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, NT);
+  else
+    k_bgemm<0><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, NT);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hscn_bgemm_f32(const float* A, const float* B, float* C, int64_t batch, int M, int N, int Kd, int64_t lda,
+                   int64_t ldb, int64_t ldc, int64_t strideA, int64_t strideB, int64_t strideC, int transA,
+                   void* stream_) {
+  if (batch < 0 || M < 0 || N < 1 || Kd < 0) return HSCN_E_BADARG;
+  if (batch == 0 || M == 0) return 0;
+  if (!A || !B || !C) return HSCN_E_BADARG;
+  return bgemm(A, B, C, batch, M, N, Kd, lda, ldb, ldc, strideA, strideB, strideC, transA, hscn_stream(stream_));
+}
+
+int hscn_mincut_dense_fwd(const float* x, const float* adj, const float* logits, int64_t B, int n, int K, int F,
+                          float* S, float* AS, float* deg, float* stats, float* ss, float* pooled_x,
+                          float* pooled_adj, float* losses, void* stream_) {
+  if (B < 1 || n < 1 || K < 1 || K > GNMAX || F < 0 || F > GNMAX) return HSCN_E_BADARG;
+  if (!adj || !logits || !S || !AS || !deg || !stats || !ss || !pooled_adj || !losses) return HSCN_E_BADARG;
+  hipStream_t st = hscn_stream(stream_);
+  const int64_t rows = B * n;
+  k_softmax_rows_d<<<hscn_blocks(rows, 256), 256, 0, st>>>(logits, S, rows, K);
+  k_rowsum<<<hscn_blocks(rows, 4), 256, 0, st>>>(adj, deg, rows, n);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  int rc;
+  // A S
+  if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st))) return rc;
+  // S^T (A S)  -> pooled_adj (raw), S^T S -> ss, S^T X -> pooled_x
+  if ((rc = bgemm(S, AS, pooled_adj, B, K, K, n, K, K, K, (int64_t)n * K, (int64_t)n * K, (int64_t)K * K, 1, st))) return rc;
+  if ((rc = bgemm(S, S, ss, B, K, K, n, K, K, K, (int64_t)n * K, (int64_t)n * K, (int64_t)K * K, 1, st))) return rc;
+  if (x && pooled_x && F > 0)
+    if ((rc = bgemm(S, x, pooled_x, B, K, F, n, K, F, F, (int64_t)n * K, (int64_t)n * F, (int64_t)K * F, 1, st))) return rc;
+  k_dense_finalize<<<(unsigned)B, 256, (K + 4) * 4, st>>>(S, deg, ss, pooled_adj, stats, n, K);
+  k_losses_d<<<1, 64, 0, st>>>(stats, losses, (int)B);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_mincut_dense_bwd(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
+                          const float* ss, const float* g_losses, int64_t B, int n, int K, float* AtS,
+                          float* g_logits, void* stream_) {
+  if (B < 1 || n < 1 || K < 1 || K > GNMAX) return HSCN_E_BADARG;
+  if (!adj || !S || !AS || !deg || !stats || !ss || !g_losses || !AtS || !g_logits) return HSCN_E_BADARG;
+  hipStream_t st = hscn_stream(stream_);
+  int rc;
+  if ((rc = bgemm(adj, S, AtS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 1, st))) return rc;
+  k_dense_bwd<<<(unsigned)B, 256, (K * K + 4) * 4, st>>>(S, AS, AtS, deg, stats, ss, g_losses, g_logits, n, K, (int)B);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // extern "C"

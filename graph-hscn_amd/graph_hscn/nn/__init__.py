@@ -1,9 +1,9 @@
 """Operator surface mirroring the torch_geometric names the reference imports
 (model/hscn.py:6-14, config/config.py:8, train/train_clustering.py:6)."""
 from .conv import GATConv, GCNConv, GraphConv, HeteroConv, Linear
-from .pool import gcn_norm, global_mean_pool, mincut_pool_sparse, to_dense_adj
+from .pool import dense_mincut_pool, gcn_norm, global_mean_pool, mincut_pool_sparse, to_dense_adj
 
 __all__ = [
     "GATConv", "GCNConv", "GraphConv", "HeteroConv", "Linear",
-    "gcn_norm", "global_mean_pool", "mincut_pool_sparse", "to_dense_adj",
+    "dense_mincut_pool", "gcn_norm", "global_mean_pool", "mincut_pool_sparse", "to_dense_adj",
 ]

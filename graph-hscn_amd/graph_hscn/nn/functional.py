@@ -319,3 +319,44 @@ class MinCutSparseFn(Function):
              ptr(col_csr.rowptr), ptr(col_csr.col), ptr(node_ptr), ptr(gl), ptr(g_logits), S.shape[0], ctx.G,
              S.shape[1], stream())
         return g_logits, None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# MinCUT pooling, dense route (matrix cores)
+# --------------------------------------------------------------------------- #
+class MinCutDenseFn(Function):
+    """(logits [B,n,K], x [B,n,F] | None, adj [B,n,n]) -> (S, losses[2], pooled_x, pooled_adj).
+    Gradients flow from the two losses to ``logits``."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, x: Optional[Tensor], adj: Tensor):
+        logits, x, adj = _c(logits), _c(x), _c(adj)
+        B, n, K = logits.shape
+        dev = logits.device
+        Fx = x.shape[2] if x is not None else 0
+        S = torch.empty_like(logits)
+        AS = torch.empty_like(logits)
+        deg = torch.empty(B, n, dtype=torch.float32, device=dev)
+        stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        ss = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+        px = torch.empty(B, K, Fx, dtype=torch.float32, device=dev) if x is not None else None
+        padj = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        call("hscn_mincut_dense_fwd", ptr(x), ptr(adj), ptr(logits), B, n, K, Fx, ptr(S), ptr(AS), ptr(deg),
+             ptr(stats), ptr(ss), ptr(px), ptr(padj), ptr(losses), stream())
+        ctx.save_for_backward(adj, S, AS, deg, stats, ss)
+        ctx.mark_non_differentiable(S, padj)
+        if px is not None:
+            ctx.mark_non_differentiable(px)
+        return S, losses, px, padj
+
+    @staticmethod
+    def backward(ctx, gS, g_losses, g_px, g_padj):
+        adj, S, AS, deg, stats, ss = ctx.saved_tensors
+        B, n, K = S.shape
+        gl = _c(g_losses) if g_losses is not None else torch.zeros(2, dtype=torch.float32, device=S.device)
+        AtS = torch.empty_like(S)
+        g_logits = torch.empty_like(S)
+        call("hscn_mincut_dense_bwd", ptr(adj), ptr(S), ptr(AS), ptr(deg), ptr(stats), ptr(ss), ptr(gl), B, n, K,
+             ptr(AtS), ptr(g_logits), stream())
+        return g_logits, None, None

@@ -83,3 +83,18 @@ def mincut_pool_sparse(x: Optional[Tensor], edge_index: Union[Tensor, Relation],
     G = int(node_ptr.numel()) - 1
     S, losses, px, padj = Fh.MinCutSparseFn.apply(s, x, rel, node_ptr.to(torch.int32).contiguous(), G)
     return S, px, padj, losses[0], losses[1]
+
+
+def dense_mincut_pool(x: Tensor, adj: Tensor, s: Tensor, mask: Optional[Tensor] = None):
+    """torch_geometric.nn.dense_mincut_pool (reference model/hscn.py:63) on a
+    DENSE adjacency ``[B,n,n]`` (2-D inputs are treated as batch 1): the cluster-assignment
+    contractions run on the matrix cores with exact-fp32 MFMA (csrc/dense.hip).
+    Returns ``(out [B,K,F], out_adj [B,K,K], mincut_loss, ortho_loss)``; the losses carry
+    gradients to ``s``."""
+    if mask is not None:
+        raise NotImplementedError("the hot path never passes a mask (hscn.py:63)")
+    x = x.unsqueeze(0) if x.dim() == 2 else x
+    adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
+    s = s.unsqueeze(0) if s.dim() == 2 else s
+    S, losses, px, padj = Fh.MinCutDenseFn.apply(s, x, adj)
+    return px, padj, losses[0], losses[1]

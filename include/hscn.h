@@ -205,6 +205,27 @@ int hscn_mincut_sparse_bwd(const float* S, const float* stats, const float* ss,
                            const float* g_losses /*[2] device*/, float* g_logits,
                            int64_t num_nodes, int64_t num_graphs, int K, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * a6  dense_mincut_pool, dense route on the matrix cores (reference model/hscn.py:61-63
+ * with the dense [B,n,n] adjacency PyG's to_dense_adj builds; BASELINE config 4).
+ * hscn_bgemm_f32: C[b] (M x N) = op(A[b]) * B[b] with exact-fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32), N <= 64, transA: A stored [Kd, M].
+ * hscn_mincut_dense_fwd runs softmax, deg = A 1, A S, S^T(A S), S^T S, S^T X, the two
+ * losses and the normalised coarse adjacency; AS [B,n,K] and deg [B,n] are kept for the
+ * backward, which adds A^T S and returns dL/dlogits given g_losses = {dL/dmincut, dL/dortho}.
+ * ------------------------------------------------------------------------- */
+int hscn_bgemm_f32(const float* A, const float* B, float* C, int64_t batch, int M, int N, int Kd,
+                   int64_t lda, int64_t ldb, int64_t ldc, int64_t strideA, int64_t strideB, int64_t strideC,
+                   int transA, void* stream);
+int hscn_mincut_dense_fwd(const float* x /*[B,n,F] or NULL*/, const float* adj /*[B,n,n]*/,
+                          const float* logits /*[B,n,K]*/, int64_t B, int n, int K, int F,
+                          float* S, float* AS, float* deg, float* stats /*[B,4]*/, float* ss /*[B,K,K]*/,
+                          float* pooled_x /*[B,K,F] or NULL*/, float* pooled_adj /*[B,K,K]*/, float* losses /*[2]*/,
+                          void* stream);
+int hscn_mincut_dense_bwd(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
+                          const float* ss, const float* g_losses /*[2] device*/, int64_t B, int n, int K,
+                          float* AtS_workspace /*[B,n,K]*/, float* g_logits /*[B,n,K]*/, void* stream);
+
 /* a7  cluster assignment (reference train/train_clustering.py:68):
  * ids[i] = first index of the row maximum of S[i,:]. */
 int hscn_assign_argmax(const float* S, int64_t* ids, int64_t num_nodes, int K, void* stream);

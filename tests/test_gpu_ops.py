@@ -268,3 +268,40 @@ def test_fused_criterion_matches_reference_loss(loss_fn, C):
     (ld * 1.7).backward()
     assert abs(lo.item() - ld.item()) < 1e-6 and close(sd, so, atol=1e-6)
     assert close(pd.grad, po.grad, atol=1e-8, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,n,K,F", [(1, 12, 4, 16), (3, 151, 16, 16), (2, 479, 64, 14), (4, 64, 32, 9), (2, 100, 5, 3)])
+def test_dense_mincut_pool_mfma_matches_oracle(B, n, K, F):
+    from graph_hscn.nn import dense_mincut_pool
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    adj = (torch.rand(B, n, n, generator=g) < 4.0 / n).float()
+    adj = ((adj + adj.transpose(1, 2)) > 0).float() + torch.eye(n)        # symmetric binary A + I
+    adj[0, 0, 1] += 1.0                                                    # and one asymmetric multi-edge
+    s = torch.randn(B, n, K, generator=g)
+    x = torch.randn(B, n, F, generator=g)
+    so = s.clone().requires_grad_()
+    out_o, oadj_o, mc_o, oo_o = P.dense_mincut_pool(x, adj, so)
+    (mc_o * 1.3 + oo_o * 0.7).backward()
+    sd = s.to(DEV).requires_grad_()
+    out_d, oadj_d, mc_d, oo_d = dense_mincut_pool(x.to(DEV), adj.to(DEV), sd)
+    (mc_d * 1.3 + oo_d * 0.7).backward()
+    assert abs(mc_d.item() - mc_o.item()) < ATOL and abs(oo_d.item() - oo_o.item()) < ATOL
+    assert close(out_d, out_o, atol=1e-4, rtol=1e-5)
+    assert close(oadj_d, oadj_o, atol=1e-5, rtol=1e-4)
+    assert close(sd.grad, so.grad, atol=1e-6, rtol=1e-3)
+
+
+def test_bgemm_mfma_asymmetric_operands():
+    """A = I-like and an asymmetric B catch a transposed C write (fragment-layout check)."""
+    from graph_hscn import _hip
+    for (M, N, Kd, ta) in [(64, 16, 64, 0), (70, 33, 45, 0), (37, 64, 129, 1), (16, 5, 7, 1)]:
+        g = torch.Generator().manual_seed(M + N)
+        A = torch.randn(2, Kd, M, generator=g) if ta else torch.randn(2, M, Kd, generator=g)
+        Bm = torch.randn(2, Kd, N, generator=g)
+        Bm += torch.arange(N).float() * 0.5 + torch.arange(Kd).float().view(-1, 1)      # asymmetric
+        want = (A.transpose(1, 2) if ta else A) @ Bm
+        Ad, Bd = A.to(DEV), Bm.to(DEV)
+        C = torch.empty(2, M, N, device=DEV)
+        _hip.call("hscn_bgemm_f32", _hip.ptr(Ad), _hip.ptr(Bd), _hip.ptr(C), 2, M, N, Kd, Ad.stride(1), N, N,
+                  Ad.stride(0), Kd * N, M * N, ta, _hip.stream())
+        assert close(C, want, atol=2e-4, rtol=1e-5), (M, N, Kd, ta)
