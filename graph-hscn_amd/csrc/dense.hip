@@ -14,6 +14,13 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 16-byte global load from a 4-byte aligned address (rows of an odd-width matrix): gfx950 global
+// memory takes dword-aligned dwordx4 accesses
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+__device__ __forceinline__ float4 ld4u(const float* p) {
+  const F4U v = *reinterpret_cast<const F4U*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 constexpr int GM = 64;   // rows of C per workgroup
 constexpr int GK = 32;   // reduction depth per LDS stage
@@ -49,7 +56,7 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
         const int gr = m0 + r, gc = k0 + c4;
         if (gr < M) {
           const float* p = A + (size_t)gr * lda + gc;
-          if (gc + 3 < Kd && ((lda & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+          if (gc + 3 < Kd) v = ld4u(p);
           else {
             if (gc < Kd) v.x = p[0];
             if (gc + 1 < Kd) v.y = p[1];
@@ -67,7 +74,7 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
         const int gr = k0 + r, gc = m0 + c4;
         if (gr < Kd) {
           const float* p = A + (size_t)gr * lda + gc;
-          if (gc + 3 < M && ((lda & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+          if (gc + 3 < M) v = ld4u(p);
           else {
             if (gc < M) v.x = p[0];
             if (gc + 1 < M) v.y = p[1];
@@ -85,7 +92,7 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
       const int gr = k0 + r;
       if (gr < Kd) {
         const float* p = Bm + (size_t)gr * ldb + c4;
-        if (c4 + 3 < N && ((ldb & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+        if (c4 + 3 < N) v = ld4u(p);
         else {
           if (c4 < N) v.x = p[0];
           if (c4 + 1 < N) v.y = p[1];
@@ -218,18 +225,15 @@ __global__ void k_losses_d(const float* __restrict__ stats, float* __restrict__ 
   }
 }
 
-// g_logits from (AS + A^T S), deg, S, ss, stats (same algebra as the sparse route's backward)
+// Gss[g] = d ortho_g / d (S^T S)  (K x K, symmetric), scaled by 2 * dL/dortho / G
 __global__ void __launch_bounds__(256)
-k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const float* __restrict__ AtS,
-            const float* __restrict__ deg, const float* __restrict__ stats, const float* __restrict__ ss,
-            const float* __restrict__ g_losses, float* __restrict__ g_logits, int n, int K, int G) {
-  extern __shared__ float lds[];
-  const int KK = K * K;
-  float* Gss = lds;         // [K][K]
-  float* red = lds + KK;    // [2]
+k_dense_gss(const float* __restrict__ stats, const float* __restrict__ ss, const float* __restrict__ g_losses,
+            float* __restrict__ Gss, int K, int G) {
+  __shared__ float red[1];
   const int g = blockIdx.x;
-  const float num = stats[g * 4 + 0], den = stats[g * 4 + 1], nrm = stats[g * 4 + 2], o = stats[g * 4 + 3];
-  const float gmc = g_losses[0] / (float)G, go = g_losses[1] / (float)G;
+  const int KK = K * K;
+  const float nrm = stats[g * 4 + 2], o = stats[g * 4 + 3];
+  const float go2 = 2.f * g_losses[1] / (float)G;
   const float isk = 1.0f / sqrtf((float)K);
   const float* ssg = ss + (size_t)g * KK;
   if (threadIdx.x < 64) {
@@ -247,28 +251,44 @@ k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const flo
   for (int i = threadIdx.x; i < KK; i += 256) {
     const int a = i / K, b = i - a * K;
     const float gq = o > 0.f ? (ssg[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
-    Gss[i] = (gq - inner / (nrm * nrm) * ssg[i]) / nrm;
+    Gss[(size_t)g * KK + i] = go2 * ((gq - inner / (nrm * nrm) * ssg[i]) / nrm);
   }
-  __syncthreads();
-  const float c_num = -gmc / den, c_den = gmc * num / (den * den);
-  const size_t base = (size_t)g * n * K;
-  // one thread per node row (K <= 64: the row lives in registers twice over the loop)
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float* Si = S + base + (size_t)i * K;
-    const float di = deg[(size_t)g * n + i];
+}
+
+// g_logits[i,:] = S_i * (dS_i - <dS_i, S_i>),  dS = c_num (AS + A^T S) + c_den 2 deg S + S Gss'
+// (SG = S Gss' comes from the batched GEMM); K/4 lanes per row, row dot by __shfl_xor
+__global__ void __launch_bounds__(256)
+k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const float* __restrict__ AtS,
+            const float* __restrict__ SG, const float* __restrict__ deg, const float* __restrict__ stats,
+            const float* __restrict__ g_losses, float* __restrict__ g_logits, int n, int K, int G, int LPRp) {
+  const int64_t rows = (int64_t)G * n;
+  const int RPB = 256 / LPRp;
+  const int rl = threadIdx.x / LPRp, fl = threadIdx.x % LPRp;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rl; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const int g = (int)(r / n);
+    const float num = stats[g * 4 + 0], den = stats[g * 4 + 1];
+    const float gmc = g_losses[0] / (float)G;
+    const float c_num = -gmc / den, c_den = gmc * num / (den * den);
+    const float di = deg[r];
+    const size_t base = (size_t)r * K;
+    float dS[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
     float dot = 0.f;
-    for (int k = 0; k < K; ++k) {
-      float orth = 0.f;
-      for (int a = 0; a < K; ++a) orth = fmaf(Si[a], Gss[a * K + k], orth);
-      const float dS = c_num * (AS[base + (size_t)i * K + k] + AtS[base + (size_t)i * K + k]) +
-                       c_den * 2.f * di * Si[k] + go * 2.f * orth;
-      g_logits[base + (size_t)i * K + k] = dS;  // parked; rescaled below
-      dot = fmaf(dS, Si[k], dot);
+    for (int k0 = fl * 4; k0 < K; k0 += LPRp * 4) {   // one pass when K <= 4*LPRp (always: LPRp = pow2ceil(K/4))
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + q;
+        if (k < K) {
+          sv[q] = S[base + k];
+          dS[q] = c_num * (AS[base + k] + AtS[base + k]) + c_den * 2.f * di * sv[q] + SG[base + k];
+          dot = fmaf(dS[q], sv[q], dot);
+        }
+      }
     }
-    for (int k = 0; k < K; ++k) {
-      const float dS = g_logits[base + (size_t)i * K + k];
-      g_logits[base + (size_t)i * K + k] = Si[k] * (dS - dot);
-    }
+    for (int off = LPRp >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    const int k0 = fl * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (k0 + q < K) g_logits[base + k0 + q] = sv[q] * (dS[q] - dot);
   }
 }
 
@@ -324,13 +344,22 @@ int hscn_mincut_dense_fwd(const float* x, const float* adj, const float* logits,
 
 int hscn_mincut_dense_bwd(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
                           const float* ss, const float* g_losses, int64_t B, int n, int K, float* AtS,
-                          float* g_logits, void* stream_) {
+                          float* sg_ws, float* gss_ws, float* g_logits, void* stream_) {
   if (B < 1 || n < 1 || K < 1 || K > GNMAX) return HSCN_E_BADARG;
-  if (!adj || !S || !AS || !deg || !stats || !ss || !g_losses || !AtS || !g_logits) return HSCN_E_BADARG;
+  if (!adj || !S || !AS || !deg || !stats || !ss || !g_losses || !AtS || !sg_ws || !gss_ws || !g_logits)
+    return HSCN_E_BADARG;
   hipStream_t st = hscn_stream(stream_);
   int rc;
   if ((rc = bgemm(adj, S, AtS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 1, st))) return rc;
-  k_dense_bwd<<<(unsigned)B, 256, (K * K + 4) * 4, st>>>(S, AS, AtS, deg, stats, ss, g_losses, g_logits, n, K, (int)B);
+  // Gss' (scaled) -> gss_ws [B,K,K];  SG = S Gss' -> g_logits (used as scratch, then overwritten row by row)
+  k_dense_gss<<<(unsigned)B, 256, 0, st>>>(stats, ss, g_losses, gss_ws, K, (int)B);
+  if ((rc = bgemm(S, gss_ws, sg_ws, B, n, K, K, K, K, K, (int64_t)n * K, (int64_t)K * K, (int64_t)n * K, 0, st))) return rc;
+  int LPRp = 1;
+  while (LPRp * 4 < K) LPRp <<= 1;
+  const int64_t rows = B * n;
+  int64_t nb = (rows + 256 / LPRp - 1) / (256 / LPRp);
+  if (nb > 8192) nb = 8192;
+  k_dense_bwd<<<(unsigned)nb, 256, 0, st>>>(S, AS, AtS, sg_ws, deg, stats, g_losses, g_logits, n, K, (int)B, LPRp);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

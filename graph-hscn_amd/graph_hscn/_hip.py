@@ -47,7 +47,7 @@ _SIGNATURES = {
     "hscn_bgemm_f32": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64,
                                c_int64, c_int, P]),
     "hscn_mincut_dense_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
-    "hscn_mincut_dense_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, P, P, P]),
+    "hscn_mincut_dense_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, P, P, P, P, P]),
     "hscn_assign_argmax": (c_int, [P, P, c_int64, c_int, P]),
     "hscn_to_dense_adj": (c_int, [P, P, c_int64, c_int64, P, P]),
     "hscn_criterion_fwd": (c_int, [P, P, c_int64, c_int, P, P, P, P]),

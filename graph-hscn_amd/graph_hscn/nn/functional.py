@@ -356,7 +356,9 @@ class MinCutDenseFn(Function):
         B, n, K = S.shape
         gl = _c(g_losses) if g_losses is not None else torch.zeros(2, dtype=torch.float32, device=S.device)
         AtS = torch.empty_like(S)
+        SG = torch.empty_like(S)
+        Gss = torch.empty_like(ss)
         g_logits = torch.empty_like(S)
         call("hscn_mincut_dense_bwd", ptr(adj), ptr(S), ptr(AS), ptr(deg), ptr(stats), ptr(ss), ptr(gl), B, n, K,
-             ptr(AtS), ptr(g_logits), stream())
+             ptr(AtS), ptr(SG), ptr(Gss), ptr(g_logits), stream())
         return g_logits, None, None

@@ -224,7 +224,8 @@ int hscn_mincut_dense_fwd(const float* x /*[B,n,F] or NULL*/, const float* adj /
                           void* stream);
 int hscn_mincut_dense_bwd(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
                           const float* ss, const float* g_losses /*[2] device*/, int64_t B, int n, int K,
-                          float* AtS_workspace /*[B,n,K]*/, float* g_logits /*[B,n,K]*/, void* stream);
+                          float* AtS_workspace /*[B,n,K]*/, float* SG_workspace /*[B,n,K]*/,
+                          float* Gss_workspace /*[B,K,K]*/, float* g_logits /*[B,n,K]*/, void* stream);
 
 /* a7  cluster assignment (reference train/train_clustering.py:68):
  * ids[i] = first index of the row maximum of S[i,:]. */
