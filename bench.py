@@ -332,6 +332,22 @@ def main():
         streaming = bench_spmm.measure(32, 128, 20, dev=dev)
         streaming["peak_GBs"] = HBM_PEAK_GBS
 
+    # HBM traffic from the committed PMC passes (profiles/r01_pmc_traffic.json; separate rocprofv3 runs,
+    # the counters cannot be read from inside this process)
+    if rank == 0:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            default_shape = (args.workload == "peptides_func" and B == 128 and args.hidden == 16 and args.layers == 3)
+            if roofline and default_shape:
+                key = "k_hscn_fwd" if "k_hscn_fwd" in roofline["kernel"] else ("k_hscn_bwd" if "k_hscn_bwd" in roofline["kernel"] else None)
+                if key and key in pmc:
+                    roofline["traffic"] = pmc[key]["traffic_bytes"]
+                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
+            if streaming and "k_spmm_scaled_H128" in pmc:
+                streaming["traffic"] = pmc["k_spmm_scaled_H128"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(hb_host, args, C, loss_fn, args.cpu_seconds)

@@ -35,6 +35,7 @@
 // Numerics: k-ascending fmaf chains in the transforms, edge-order separately rounded
 // multiply/add in the gather-reduce (same as the layered kernels).
 #include "hscn_common.h"
+#include "resident_common.h"
 
 namespace {
 
@@ -72,146 +73,6 @@ struct BwdArgs {
   int64_t N;
   int F, L, C, head_act, max_n, max_ell, P;
 };
-
-__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
-
-// Phase stamps exist only in the diagnostic build (make diag -> libhscn_diag.so); the
-// shipped kernels execute none.  Values go to a buffer nothing else reads.
-#ifdef HSCN_STAMPS
-__device__ long long* g_stamp_buf = nullptr;  // [grid][64]
-#define STAMP(k)                                                                                 \
-  do {                                                                                           \
-    if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 64 + (k)] = clock64(); \
-  } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-
-// A wave group: a contiguous range of waves of the workgroup that works on its own arrays
-// between the workgroup-wide barriers (every group executes the same barrier sequence).
-struct Grp {
-  int t;   // thread index inside the group
-  int nt;  // threads in the group
-  int w;   // wave index inside the group
-  int nw;  // waves in the group
-};
-
-// sum over the 16 lanes of a DPP row (all 16 lanes receive the total): VALU only, no LDS
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
-  return v;
-}
-
-// ---- group inclusive scan of a[0..n) in LDS, in place (two workgroup barriers) -----------------
-__device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp& G) {
-  const int per = (n + G.nt - 1) / G.nt;
-  const int b = G.t * per;
-  int s = 0;
-  for (int i = 0; i < per; ++i)
-    if (b + i < n) s += a[b + i];
-  const int lane = threadIdx.x & 63;
-  int incl = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) wsum[G.w] = incl;
-  __syncthreads();
-  int off = 0;
-  for (int i = 0; i < G.w; ++i) off += wsum[i];
-  int run = off + incl - s;
-  for (int i = 0; i < per; ++i)
-    if (b + i < n) {
-      run += a[b + i];
-      a[b + i] = run;
-    }
-  __syncthreads();
-}
-
-// ---- stable CSR from staged edges (local ids; key -1 = dropped): low-degree rows --------------
-// rowptr[0..nrows], col[ne]; rows keep ascending edge order.  Placement by LDS int atomics
-// (arrival order), then every edge ranks itself inside its row by edge number: O(degree) per
-// edge, meant for rows of a few edges.  cursor: [nrows+1], tmp: [ne].  Six barriers.
-__device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, int* rowptr, int* col, int* cursor,
-                              int* tmp, int* wsum, const Grp& G) {
-  for (int i = G.t; i <= nrows; i += G.nt) {
-    rowptr[i] = 0;
-    cursor[i] = 0;
-  }
-  __syncthreads();
-  for (int e = G.t; e < ne; e += G.nt) {
-    const int k = ek[e];
-    if (k >= 0) atomicAdd(&rowptr[k + 1], 1);
-  }
-  __syncthreads();
-  scan_inclusive_lds(rowptr, nrows + 1, wsum, G);
-  for (int e = G.t; e < ne; e += G.nt) {
-    const int k = ek[e];
-    if (k < 0) continue;
-    const int p = atomicAdd(&cursor[k], 1);
-    tmp[rowptr[k] + p] = e;
-  }
-  __syncthreads();
-  for (int e = G.t; e < ne; e += G.nt) {
-    const int k = ek[e];
-    if (k < 0) continue;
-    const int s = rowptr[k], t = rowptr[k + 1];
-    int rank = 0;
-    for (int q = s; q < t; ++q) rank += (tmp[q] < e) ? 1 : 0;
-    col[s + rank] = eo[e];
-  }
-  __syncthreads();
-}
-
-// ---- stable CSR, few rows of high degree (local -> virtual: rows are clusters) ----------------
-// Wave-ballot multisplit: edges are cut into 64-edge chunks (one wave each, in edge order);
-// cnt[row][chunk] by ballot, one scan over (row-major, chunk-minor) gives every
-// (row, chunk) its base slot, the rank inside the chunk is popcount(ballot & lanes below).
-// cnt: [nrows * ceil(ne/64)] ints, tmp: [ne].  Five barriers.
-__device__ void build_csr_multisplit_lds(const int* ek, const int* eo, int ne, int nrows, int* rowptr, int* col,
-                                         int* cnt, int* tmp, int* wsum, const Grp& G) {
-  const int nchunk = (ne + 63) >> 6;
-  const int lane = threadIdx.x & 63;
-  for (int i = G.t; i < nrows * nchunk; i += G.nt) cnt[i] = 0;
-  __syncthreads();
-  for (int c = G.w; c < nchunk; c += G.nw) {
-    const int e = c * 64 + lane;
-    const int k = e < ne ? ek[e] : -1;
-    unsigned long long todo = __ballot(k >= 0);
-    int rank = 0;
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int k0 = __shfl(k, leader, 64);
-      const unsigned long long m = __ballot(k == k0);
-      if (k == k0) rank = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == leader) cnt[k0 * nchunk + c] = __popcll(m);
-      todo &= ~m;
-    }
-    if (e < ne) tmp[e] = rank;
-  }
-  __syncthreads();
-  scan_inclusive_lds(cnt, nrows * nchunk, wsum, G);
-  for (int r = G.t; r <= nrows; r += G.nt) rowptr[r] = (r * nchunk > 0) ? cnt[r * nchunk - 1] : 0;
-  for (int e = G.t; e < ne; e += G.nt) {
-    const int k = ek[e];
-    if (k < 0) continue;
-    const int idx = k * nchunk + (e >> 6);
-    const int base = idx > 0 ? cnt[idx - 1] : 0;
-    col[base + tmp[e]] = eo[e];
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float* dinv, const Grp& G) {
-  for (int i = G.t; i < n; i += G.nt) {
-    const int d = rowptr[i + 1] - rowptr[i];
-    dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
-  }
-}
 
 // ---- layer weights: global -> registers (prefetch) -> LDS (transposed Wt[k][o], rows k>=fin zero) ----
 // The 4 matrices of a layer ([H][fin] each, nn.Linear layout: W_ll, W_src, W_dst, W_vv) and 5
@@ -1074,35 +935,6 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
     STAMP(6 + 4 * l);
   }
   STAMP(63);
-}
-
-// out[p] = sum_g partials[g][p]: a block owns 32 parameters x 8 contiguous graph slices (coalesced
-// over p), each slice summed in graph order, slices folded in slice order -> fixed summation tree
-__global__ void __launch_bounds__(256) k_param_reduce(const float* __restrict__ partials, float* __restrict__ out,
-                                                      int B, int P) {
-  __shared__ float red[8][32];
-  const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int p = blockIdx.x * 32 + pl;
-  const int per = (B + 7) / 8;
-  const int g0 = sl * per, g1 = (g0 + per) < B ? (g0 + per) : B;
-  float s = 0.f;
-  if (p < P) {
-    int g = g0;
-    for (; g + 4 <= g1; g += 4) {  // four loads in flight, added in graph order
-      const float a = partials[(size_t)g * P + p], b = partials[(size_t)(g + 1) * P + p];
-      const float c = partials[(size_t)(g + 2) * P + p], d = partials[(size_t)(g + 3) * P + p];
-      s += a; s += b; s += c; s += d;
-    }
-    for (; g < g1; ++g) s += partials[(size_t)g * P + p];
-  }
-  red[sl][pl] = s;
-  __syncthreads();
-  if (sl == 0 && p < P) {
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) t += red[q][pl];
-    out[p] = t;
-  }
 }
 
 inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int spec) {

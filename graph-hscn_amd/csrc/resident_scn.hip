@@ -1,0 +1,536 @@
+// Graph-resident stage A: gcn_norm + SCN.forward + MinCUT/orthogonality losses, and the
+// backward, one workgroup per graph with everything in LDS.
+//
+// Reference: the per-graph body of train/train_clustering.py:37-50 --
+//   gcn_norm(edge_index, None, n, add_self_loops=True)                      (:37-42)
+//   SCN.forward: GraphConv(F->H) + act, Linear(H->K), to_dense_adj, dense_mincut_pool
+//                                                                            (model/hscn.py:56-64)
+// for mp_units=[H], mlp_units=[] (the only configuration the reference instantiates,
+// main.py:101-105; other shapes use the layered operators).  The reference does this with
+// ~60 small tensor ops and a dense [n,n] adjacency per graph; here the self-looped,
+// normalised graph never materialises:
+//   * rows of the target-keyed CSR give the in-degree, deg = indeg + 1 (the added self loop),
+//     w_e = deg_src^-1/2 * 1 * deg_dst^-1/2, loop weight deg_i^-1 -- applied on the fly, loop last
+//     (PyG appends the loops after the edges, so edge order = CSR order then loop);
+//   * MinCUT uses the BINARY A + I (model/hscn.py:61 drops the weights):
+//       tr(S^T A S) = sum_i S_i . ((A S)_i + S_i),  tr(S^T D S) = sum_i (outdeg_i + 1) |S_i|^2.
+// Existing self loops in the input (none in LRGB) become the unit self loop, as
+// add_remaining_self_loops does for unit weights.
+// Ordered reductions only; per-graph parameter-gradient partials + one ordered fold.
+#include "hscn_common.h"
+#include "resident_common.h"
+
+namespace {
+
+constexpr int SRT = 512;  // threads per workgroup
+constexpr int FP = 16;    // input features are zero padded to 16 in LDS
+
+struct ScnArgs {
+  const float* x;              // [N,F]
+  const int64_t *src, *dst;    // raw COO (no self loops needed)
+  const int32_t *nptr, *eptr;  // node / edge ranges per graph
+  const float *W_rel, *b_rel, *W_root, *W_mlp, *b_mlp;
+  float *S, *y, *stats, *ss;   // outputs: [N,K], [N,H], [B,4], [B,K,K]
+  const float* g_losses;       // backward only: [2] device
+  float* partials;             // backward only: [B,P]
+  int32_t* flag;
+  int64_t N;
+  int F, K, act, max_n, max_e, B, P;
+};
+
+struct ScnLayout {
+  size_t R1, R2, R3, dinv, dout, wt, red, vecs, rowptr_d, col_d, rowptr_s, col_s, cursor, tmp, wsum, ek, eo, total;
+};
+// R1: x | agg  (2 * n * FP), later S (n * K) in the forward; R2: y (n * H); R3 (backward): dS / dlogits (n * K)
+__host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max_e, int bwd) {
+  ScnLayout Y;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+  const size_t xa = (size_t)2 * max_n * FP, sk = (size_t)max_n * K;
+  Y.R1 = take(bwd ? xa + sk : (xa > sk ? xa : sk));   // backward keeps x, agg AND S
+  const size_t st = (size_t)2 * (((size_t)max_e + 3) / 4 * 4);
+  const size_t yh = (size_t)max_n * H;
+  Y.R2 = take(yh > st ? yh : st);                      // y; the staged COO slice overlays it first
+  Y.ek = Y.R2;
+  Y.eo = Y.R2 + ((size_t)max_e + 3) / 4 * 4;
+  Y.R3 = take(bwd ? sk : 0);
+  Y.dinv = take(max_n);
+  Y.dout = take(max_n);
+  Y.wt = take((size_t)2 * H * FP + H + (size_t)K * H + K + (size_t)K * K);  // W_rel^T | W_root^T | b_rel | W_mlp^T | b_mlp | Gss
+  Y.red = take(1024);
+  Y.vecs = take(64);
+  Y.rowptr_d = take(max_n + 1);
+  Y.col_d = take(max_e);
+  Y.rowptr_s = take(max_n + 1);
+  Y.col_s = take(max_e);
+  Y.cursor = take(max_n + 1);
+  Y.tmp = take(max_e);
+  Y.wsum = take(32);
+  Y.total = o;
+  return Y;
+}
+
+// gW[o][k] (O x Kc, row stride ldo) += sum_j Gm[j][o] * Xm[j][k] over the graph's n rows:
+// 4x4 tiles, a 16-lane DPP row per tile, rows split over the row's lanes; written to out.
+// O, Kc multiples of 4 (zero padded columns allowed); kmax: only k < kmax is stored.
+template <int NW>
+__device__ void outer_sum(const float* Gm, int ldg, int O, const float* Xm, int ldx, int Kc, int n, float* out,
+                          int ldo, int kmax) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane >> 4, l16 = lane & 15;
+  const int tk = Kc / 4, nt = (O / 4) * tk;
+  for (int t0 = wave * 4; t0 < nt; t0 += NW * 4) {
+    const int tile = t0 + row;
+    const bool live = tile < nt;
+    const int o4 = live ? (tile / tk) * 4 : 0, k4 = live ? (tile % tk) * 4 : 0;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    if (live)
+      for (int j = l16; j < n; j += 16) {
+        const float4 gv = *reinterpret_cast<const float4*>(Gm + (size_t)j * ldg + o4);
+        const float4 xv = *reinterpret_cast<const float4*>(Xm + (size_t)j * ldx + k4);
+        const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+        const float xb[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(ga[a], xb[b], acc[a][b]);
+      }
+    float mine = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float v = row16_sum(acc[a][b]);
+        if (l16 == a * 4 + b) mine = v;
+      }
+    if (live) {
+      const int oo = o4 + (l16 >> 2), kk = k4 + (l16 & 3);
+      if (kk < kmax) out[(size_t)oo * ldo + kk] = mine;
+    }
+  }
+}
+
+// column sums of M[n][C] -> out[C]: wave per column, lanes split rows
+template <int NW>
+__device__ void col_sum(const float* M, int ld, int C, int n, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < C; c += NW) {
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += M[(size_t)i * ld + c];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = s;
+  }
+}
+
+// shared front end: stage edges, both CSRs (target-keyed for GraphConv, source-keyed for A S),
+// gcn_norm degrees, x into LDS, aggregation agg = A_hat x (edge order, loop last)
+template <int H>
+__device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* ib, int n0, int n, int e0, int ne,
+                          const Grp& ALL) {
+  float *xs = fb + Y.R1, *agg = fb + Y.R1 + (size_t)A.max_n * FP, *dinv = fb + Y.dinv, *dout = fb + Y.dout;
+  int *ek = ib + Y.ek, *eo = ib + Y.eo;
+  int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
+  int *cursor = ib + Y.cursor, *tmp = ib + Y.tmp, *wsum = ib + Y.wsum;
+  bool bad = false;
+  for (int e = threadIdx.x; e < ne; e += SRT) {
+    int k = (int)(A.dst[e0 + e] - n0);
+    const int o = (int)(A.src[e0 + e] - n0);
+    if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; }
+    if (k == o) k = -1;  // an existing self loop is replaced by the unit loop gcn_norm appends
+    ek[e] = k;
+    eo[e] = o;
+  }
+  if (bad && A.flag) atomicOr(A.flag, 2);
+  for (int idx = threadIdx.x; idx < n * FP; idx += SRT) {
+    const int i = idx / FP, k = idx - i * FP;
+    xs[idx] = k < A.F ? A.x[(size_t)(n0 + i) * A.F + k] : 0.f;
+  }
+  __syncthreads();
+  build_csr_lds(ek, eo, ne, n, rowptr_d, col_d, cursor, tmp, wsum, ALL);   // rows = targets, cols = sources
+  // the source-keyed CSR: swap the roles (dropped edges keep key -1)
+  for (int e = threadIdx.x; e < ne; e += SRT) {
+    const int k = ek[e], o = eo[e];
+    if (k >= 0) { ek[e] = o; eo[e] = k; }
+  }
+  __syncthreads();
+  build_csr_lds(ek, eo, ne, n, rowptr_s, col_s, cursor, tmp, wsum, ALL);   // rows = sources, cols = targets
+  for (int i = threadIdx.x; i < n; i += SRT) {
+    const float deg = (float)(rowptr_d[i + 1] - rowptr_d[i]) + 1.0f;        // scatter_add of unit weights + loop
+    dinv[i] = 1.0f / sqrtf(deg);
+    dout[i] = (float)(rowptr_s[i + 1] - rowptr_s[i]) + 1.0f;               // row sum of binary A + I
+  }
+  __syncthreads();
+  // agg_i = sum_{j->i} (dinv_j * 1 * dinv_i) x_j  (edge order)  +  (dinv_i * 1 * dinv_i) x_i  (loop last)
+  {
+    constexpr int LPR = FP / 4;
+    const int rl = threadIdx.x / LPR, f = (threadIdx.x % LPR) * 4;
+    for (int i = rl; i < n; i += SRT / LPR) {
+      const float di = dinv[i];
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p = rowptr_d[i]; p < rowptr_d[i + 1]; ++p) {
+        const int j = col_d[p];
+        const float w = mul_rn(mul_rn(dinv[j], 1.0f), di);
+        const float4 v = *reinterpret_cast<const float4*>(xs + j * FP + f);
+        a.x = add_rn(a.x, mul_rn(w, v.x)); a.y = add_rn(a.y, mul_rn(w, v.y));
+        a.z = add_rn(a.z, mul_rn(w, v.z)); a.w = add_rn(a.w, mul_rn(w, v.w));
+      }
+      const float wl = mul_rn(mul_rn(di, 1.0f), di);
+      const float4 v = *reinterpret_cast<const float4*>(xs + i * FP + f);
+      a.x = add_rn(a.x, mul_rn(wl, v.x)); a.y = add_rn(a.y, mul_rn(wl, v.y));
+      a.z = add_rn(a.z, mul_rn(wl, v.z)); a.w = add_rn(a.w, mul_rn(wl, v.w));
+      *reinterpret_cast<float4*>(agg + i * FP + f) = a;
+    }
+  }
+  __syncthreads();
+}
+
+// stage W^T: W [O][I] (global) -> Wt[k][o] with row stride O, rows k >= I zero up to IP
+__device__ __forceinline__ void stage_t(const float* __restrict__ W, int O, int I, int IP, float* Wt) {
+  for (int idx = threadIdx.x; idx < O * I; idx += SRT) {
+    const int o = idx / I, k = idx - o * I;
+    Wt[k * O + o] = W[idx];
+  }
+  for (int idx = threadIdx.x + I * O; idx < IP * O; idx += SRT) Wt[idx] = 0.f;
+}
+
+template <int H>
+__global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NW = SRT / 64;
+  const int g = blockIdx.x, K = A.K;
+  const int n0 = A.nptr[g], n = A.nptr[g + 1] - n0;
+  const int e0 = A.eptr[g], ne = A.eptr[g + 1] - e0;
+  if (n > A.max_n || ne > A.max_e || n < 0 || ne < 0) {
+    if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    return;
+  }
+  const ScnLayout Y = scn_layout(H, K, A.max_n, A.max_e, 0);
+  float* fb = reinterpret_cast<float*>(smem);
+  int* ib = reinterpret_cast<int*>(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Grp ALL{(int)threadIdx.x, SRT, wave, NW};
+  float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = fb + Y.R1, *yl = fb + Y.R2;
+  float *dout = fb + Y.dout, *red = fb + Y.red;
+  float* WrT = fb + Y.wt;            // [FP][H]
+  float* WoT = WrT + FP * H;         // [FP][H]
+  float* brl = WoT + FP * H;         // [H]
+  float* WmT = brl + H;              // [H][K]
+  float* bml = WmT + (size_t)H * K;  // [K]
+  int *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
+
+  stage_t(A.W_rel, H, A.F, FP, WrT);
+  stage_t(A.W_root, H, A.F, FP, WoT);
+  for (int i = threadIdx.x; i < H; i += SRT) brl[i] = A.b_rel[i];
+  stage_t(A.W_mlp, K, H, H, WmT);
+  for (int i = threadIdx.x; i < K; i += SRT) bml[i] = A.b_mlp[i];
+  scn_front<H>(A, Y, fb, ib, n0, n, e0, ne, ALL);
+
+  // y = act(W_rel agg + b_rel + W_root x): thread (row, o); both weight columns in registers
+  {
+    const int o = threadIdx.x % H, r0 = threadIdx.x / H;
+    float wr[FP], wo[FP];
+#pragma unroll
+    for (int k = 0; k < FP; ++k) { wr[k] = WrT[k * H + o]; wo[k] = WoT[k * H + o]; }
+    const float b = brl[o];
+    for (int i = r0; i < n; i += SRT / H) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < FP / 4; ++k4) {
+        const float4 av = *reinterpret_cast<const float4*>(agg + i * FP + 4 * k4);
+        const float4 xv = *reinterpret_cast<const float4*>(xs + i * FP + 4 * k4);
+        a1 = fmaf(av.x, wr[4 * k4 + 0], a1); a1 = fmaf(av.y, wr[4 * k4 + 1], a1);
+        a1 = fmaf(av.z, wr[4 * k4 + 2], a1); a1 = fmaf(av.w, wr[4 * k4 + 3], a1);
+        a2 = fmaf(xv.x, wo[4 * k4 + 0], a2); a2 = fmaf(xv.y, wo[4 * k4 + 1], a2);
+        a2 = fmaf(xv.z, wo[4 * k4 + 2], a2); a2 = fmaf(xv.w, wo[4 * k4 + 3], a2);
+      }
+      const float v = apply_act((a1 + b) + a2, A.act);
+      yl[i * H + o] = v;
+      A.y[(size_t)(n0 + i) * H + o] = v;
+    }
+  }
+  __syncthreads();
+  // logits + softmax: KP lanes per row (KP = pow2 >= K), x / agg are dead: S overlays them
+  {
+    int KP = 1;
+    while (KP < K) KP <<= 1;
+    const int k = threadIdx.x % KP, r0 = threadIdx.x / KP;
+    for (int i = r0; i < n; i += SRT / KP) {
+      float s = -INFINITY;
+      if (k < K) {
+        float a = 0.f;
+        for (int h = 0; h < H; ++h) a = fmaf(yl[i * H + h], WmT[h * K + k], a);
+        s = a + bml[k];
+      }
+      float m = s;
+      for (int off = KP >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      const float ex = k < K ? expf(s - m) : 0.f;
+      float sum = ex;
+      for (int off = KP >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      // all rows of this pass were read (y) before S overwrites x/agg: y lives in R2, S in R1 -- no overlap
+      if (k < K) {
+        const float v = ex / sum;
+        Sl[i * K + k] = v;
+        A.S[(size_t)(n0 + i) * K + k] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // MinCUT statistics on the binary A + I
+  //   num = sum_i S_i . (sum_{p in row_s(i)} S[col] + S_i),  den = sum_i dout_i |S_i|^2,  ss = S^T S
+  {
+    float num = 0.f, den = 0.f;
+    for (int idx = threadIdx.x; idx < n * K; idx += SRT) {
+      const int i = idx / K, k = idx - i * K;
+      const float sv = Sl[idx];
+      float as = 0.f;
+      for (int p = rowptr_s[i]; p < rowptr_s[i + 1]; ++p) as += Sl[col_s[p] * K + k];
+      as += sv;
+      num = fmaf(sv, as, num);
+      den = fmaf(dout[i], sv * sv, den);
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if (lane == 0) { red[wave] = num; red[16 + wave] = den; }
+  }
+  // ss = S^T S through the tile outer product into LDS, then to global
+  float* ssl = bml + K;  // [K][K] (the slot the backward uses for Gss)
+  const int KK = K * K;
+  if ((K & 3) == 0) {
+    outer_sum<NW>(Sl, K, K, Sl, K, K, n, ssl, K, K);
+  } else {
+    for (int idx = threadIdx.x; idx < KK; idx += SRT) {
+      const int a = idx / K, b = idx - a * K;
+      float s = 0.f;
+      for (int i = 0; i < n; ++i) s = fmaf(Sl[i * K + a], Sl[i * K + b], s);
+      ssl[idx] = s;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < KK; idx += SRT) A.ss[(size_t)g * KK + idx] = ssl[idx];
+  if (threadIdx.x < 64) {
+    float num = 0.f, den = 0.f;
+    for (int w = 0; w < NW; ++w) { num += red[w]; den += red[16 + w]; }
+    float n2 = 0.f;
+    for (int idx = lane; idx < KK; idx += 64) n2 += ssl[idx] * ssl[idx];
+    n2 = wave_sum(n2);
+    const float nrm = sqrtf(n2);
+    const float isk = 1.0f / sqrtf((float)K);
+    float o2 = 0.f;
+    for (int idx = lane; idx < KK; idx += 64) {
+      const int a = idx / K, b = idx - a * K;
+      const float q = ssl[idx] / nrm - (a == b ? isk : 0.f);
+      o2 += q * q;
+    }
+    o2 = wave_sum(o2);
+    if (lane == 0) {
+      A.stats[g * 4 + 0] = num;
+      A.stats[g * 4 + 1] = den;
+      A.stats[g * 4 + 2] = nrm;
+      A.stats[g * 4 + 3] = sqrtf(o2);
+    }
+  }
+}
+
+template <int H>
+__global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NW = SRT / 64;
+  const int g = blockIdx.x, K = A.K, KK = A.K * A.K;
+  const int n0 = A.nptr[g], n = A.nptr[g + 1] - n0;
+  const int e0 = A.eptr[g], ne = A.eptr[g + 1] - e0;
+  float* part = A.partials + (size_t)g * A.P;
+  if (n > A.max_n || ne > A.max_e || n < 0 || ne < 0) {
+    if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    for (int i = threadIdx.x; i < A.P; i += SRT) part[i] = 0.f;
+    return;
+  }
+  const ScnLayout Y = scn_layout(H, K, A.max_n, A.max_e, 1);
+  float* fb = reinterpret_cast<float*>(smem);
+  int* ib = reinterpret_cast<int*>(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Grp ALL{(int)threadIdx.x, SRT, wave, NW};
+  float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = agg + (size_t)A.max_n * FP;
+  float *yl = fb + Y.R2, *DL = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;
+  float* WmT = fb + Y.wt + 2 * FP * H + H;   // [H][K] (same offsets as the forward's weight block)
+  float* Gss = WmT + (size_t)H * K + K;      // [K][K]
+  int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
+
+  stage_t(A.W_mlp, K, H, H, WmT);
+  scn_front<H>(A, Y, fb, ib, n0, n, e0, ne, ALL);
+  // S, y from the forward; Gss from ss/stats
+  for (int idx = threadIdx.x; idx < n * K; idx += SRT) Sl[idx] = A.S[(size_t)n0 * K + idx];
+  for (int idx = threadIdx.x; idx < n * H; idx += SRT) yl[idx] = A.y[(size_t)n0 * H + idx];
+  const float num = A.stats[g * 4 + 0], den = A.stats[g * 4 + 1], nrm = A.stats[g * 4 + 2], o = A.stats[g * 4 + 3];
+  const float gmc = A.g_losses[0] / (float)A.B, go = A.g_losses[1] / (float)A.B;
+  const float isk = 1.0f / sqrtf((float)K);
+  const float* ssg = A.ss + (size_t)g * KK;
+  if (threadIdx.x < 64) {
+    float v = 0.f;
+    if (o > 0.f)
+      for (int i = lane; i < KK; i += 64) {
+        const int a = i / K, b = i - a * K;
+        v += ((ssg[i] / nrm - (a == b ? isk : 0.f)) / o) * ssg[i];
+      }
+    v = wave_sum(v);
+    if (lane == 0) red[0] = v;
+  }
+  __syncthreads();
+  const float inner = red[0];
+  for (int i = threadIdx.x; i < KK; i += SRT) {
+    const int a = i / K, b = i - a * K;
+    const float gq = o > 0.f ? (ssg[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
+    Gss[i] = (gq - inner / (nrm * nrm) * ssg[i]) / nrm;
+  }
+  __syncthreads();
+  // dS -> DL, then dlogits = S * (dS - <dS, S>) in place (KP lanes per row)
+  const float c_num = -gmc / den, c_den = gmc * num / (den * den);
+  {
+    int KP = 1;
+    while (KP < K) KP <<= 1;
+    const int k = threadIdx.x % KP, r0 = threadIdx.x / KP;
+    for (int i = r0; i < n; i += SRT / KP) {
+      float dS = 0.f, sv = 0.f;
+      if (k < K) {
+        sv = Sl[i * K + k];
+        float as = 0.f;
+        for (int p = rowptr_s[i]; p < rowptr_s[i + 1]; ++p) as += Sl[col_s[p] * K + k];   // (A S)_i
+        for (int p = rowptr_d[i]; p < rowptr_d[i + 1]; ++p) as += Sl[col_d[p] * K + k];   // (A^T S)_i
+        as += 2.f * sv;                                                                   // the two identity terms
+        float orth = 0.f;
+        for (int a = 0; a < K; ++a) orth = fmaf(Sl[i * K + a], Gss[a * K + k], orth);
+        dS = c_num * as + c_den * 2.f * dout[i] * sv + go * 2.f * orth;
+      }
+      float dot = dS * sv;
+      for (int off = KP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+      if (k < K) DL[i * K + k] = sv * (dS - dot);
+    }
+  }
+  __syncthreads();
+  // parameter-gradient partials.  layout: W_rel [H*F], b_rel [H], W_root [H*F], W_mlp [K*H], b_mlp [K]
+  const int oWrel = 0, obrel = H * A.F, oWroot = obrel + H, oWmlp = oWroot + H * A.F, obmlp = oWmlp + K * H;
+  if ((K & 3) == 0) {
+    outer_sum<NW>(DL, K, K, yl, H, H, n, part + oWmlp, H, H);          // dW_mlp[k][h] = sum_i DL[i][k] y[i][h]
+  } else {
+    for (int idx = threadIdx.x; idx < K * H; idx += SRT) {
+      const int k = idx / H, h = idx - k * H;
+      float s = 0.f;
+      for (int i = 0; i < n; ++i) s = fmaf(DL[i * K + k], yl[i * H + h], s);
+      part[oWmlp + idx] = s;
+    }
+  }
+  col_sum<NW>(DL, K, K, n, part + obmlp);
+  __syncthreads();
+  // dz = (DL W_mlp) * act'(y)  in place over y: thread (row, h)
+  {
+    const int h = threadIdx.x % H, r0 = threadIdx.x / H;
+    for (int i = r0; i < n; i += SRT / H) {
+      float a = 0.f;
+      for (int k = 0; k < K; ++k) a = fmaf(DL[i * K + k], WmT[h * K + k], a);
+      yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
+    }
+  }
+  __syncthreads();
+  outer_sum<NW>(yl, H, H, agg, FP, FP, n, part + oWrel, A.F, A.F);     // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
+  outer_sum<NW>(yl, H, H, xs, FP, FP, n, part + oWroot, A.F, A.F);     // dW_root[o][k] = sum_i dz[i][o] x[i][k]
+  col_sum<NW>(yl, H, H, n, part + obrel);
+}
+
+__global__ void k_scn_losses(const float* __restrict__ stats, float* __restrict__ losses, int G) {
+  float mc = 0.f, o = 0.f;
+  for (int g = threadIdx.x; g < G; g += 64) {
+    mc += -(stats[g * 4 + 0] / stats[g * 4 + 1]);
+    o += stats[g * 4 + 3];
+  }
+  mc = wave_sum(mc);
+  o = wave_sum(o);
+  if (threadIdx.x == 0) {
+    losses[0] = mc / (float)G;
+    losses[1] = o / (float)G;
+  }
+}
+
+inline int64_t scn_param_count(int F, int H, int K) { return (int64_t)2 * H * F + H + (int64_t)K * H + K; }
+
+template <int H>
+int launch_scn(ScnArgs& A, int bwd, hipStream_t st) {
+  const size_t lds = scn_layout(H, A.K, A.max_n, A.max_e, bwd).total * 4;
+  if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  if (bwd) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_scn_bwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_scn_bwd<H><<<(unsigned)A.B, SRT, lds, st>>>(A);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_scn_fwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_scn_fwd<H><<<(unsigned)A.B, SRT, lds, st>>>(A);
+  }
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hscn_scn_resident_supported(int F, int H, int K, int max_n, int max_e) {
+  if (!(H == 16 || H == 32) || F < 1 || F > FP || K < 1 || K > 64 || max_n < 0 || max_e < 0) return 0;
+  if (SRT % H != 0) return 0;
+  if (scn_layout(H, K, max_n, max_e, 0).total * 4 > 160 * 1024) return 0;
+  if (scn_layout(H, K, max_n, max_e, 1).total * 4 > 160 * 1024) return 0;
+  return 1;
+}
+
+int64_t hscn_scn_resident_param_count(int F, int H, int K) { return scn_param_count(F, H, K); }
+
+int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                          const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                          const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
+                          const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
+                          float* losses, int32_t* flag, void* stream_) {
+  if (B < 1 || N < 0 || E < 0) return HSCN_E_BADARG;
+  if (!hscn_scn_resident_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
+  if (!x || !nptr || !eptr || !W_rel || !b_rel || !W_root || !W_mlp || !b_mlp || !S || !y || !stats || !ss ||
+      !losses || (E > 0 && !edge_index))
+    return HSCN_E_BADARG;
+  ScnArgs A{};
+  A.x = x; A.src = edge_index; A.dst = edge_index ? edge_index + E : nullptr; A.nptr = nptr; A.eptr = eptr;
+  A.W_rel = W_rel; A.b_rel = b_rel; A.W_root = W_root; A.W_mlp = W_mlp; A.b_mlp = b_mlp;
+  A.S = S; A.y = y; A.stats = stats; A.ss = ss; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
+  A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
+  hipStream_t st = hscn_stream(stream_);
+  int rc = H == 16 ? launch_scn<16>(A, 0, st) : launch_scn<32>(A, 0, st);
+  if (rc) return rc;
+  k_scn_losses<<<1, 64, 0, st>>>(stats, losses, (int)B);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                          const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                          const float* W_mlp, const float* S, const float* y, const float* stats, const float* ss,
+                          const float* g_losses, int max_n, int max_e, float* partials, float* grads,
+                          int32_t* flag, void* stream_) {
+  if (B < 1 || N < 0 || E < 0) return HSCN_E_BADARG;
+  if (!hscn_scn_resident_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
+  if (!x || !nptr || !eptr || !W_mlp || !S || !y || !stats || !ss || !g_losses || !partials || !grads ||
+      (E > 0 && !edge_index))
+    return HSCN_E_BADARG;
+  ScnArgs A{};
+  A.x = x; A.src = edge_index; A.dst = edge_index ? edge_index + E : nullptr; A.nptr = nptr; A.eptr = eptr;
+  A.W_mlp = W_mlp; A.S = const_cast<float*>(S); A.y = const_cast<float*>(y);
+  A.stats = const_cast<float*>(stats); A.ss = const_cast<float*>(ss); A.g_losses = g_losses;
+  A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
+  A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
+  hipStream_t st = hscn_stream(stream_);
+  int rc = H == 16 ? launch_scn<16>(A, 1, st) : launch_scn<32>(A, 1, st);
+  if (rc) return rc;
+  k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+}  // extern "C"

@@ -110,6 +110,14 @@ class Batch(Data):
         out.batch = torch.repeat_interleave(torch.arange(len(ns)), torch.as_tensor(ns))
         out.ptr = ptr
         out.num_graphs = len(graphs)
+        # per-graph node / edge ranges + maxima for the graph-resident kernels
+        es = [int(g.edge_index.size(1)) for g in graphs]
+        eptr = torch.zeros(len(es) + 1, dtype=torch.int32)
+        eptr[1:] = torch.cumsum(torch.as_tensor(es, dtype=torch.int64), 0).to(torch.int32)
+        out.ptr32 = ptr.to(torch.int32)
+        out.eptr32 = eptr
+        out.max_nodes = int(max(ns)) if ns else 0
+        out.max_edges = int(max(es)) if es else 0
         return out
 
     @property

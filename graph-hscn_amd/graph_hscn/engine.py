@@ -148,3 +148,91 @@ class HSCNResidentFn(Function):
         out[base + 2] = grads[off: off + C * H].view(C, H); off += C * H
         out[base + 3] = grads[off: off + C]
         return tuple(out)
+
+
+# --------------------------------------------------------------------------- #
+# stage A: gcn_norm + SCN.forward + MinCUT losses, graph-resident
+# --------------------------------------------------------------------------- #
+@dataclass
+class ScnMeta:
+    nptr: Tensor
+    eptr: Tensor
+    num_graphs: int
+    max_n: int
+    max_e: int
+    flag: Tensor
+
+    def check(self) -> None:
+        f = int(self.flag.item())
+        if f & 2:
+            raise IndexError("an edge connects nodes of different graphs (or leaves the graph)")
+        if f & 4:
+            raise ValueError("a graph exceeds the sizes the resident launch was configured for")
+
+
+def scn_meta(data, device) -> ScnMeta:
+    """Segmentation of a ``graph_hscn.data.Batch`` (block-diagonal) or a single ``Data`` graph."""
+    cached = getattr(data, "_scn_meta", None)
+    if cached is not None and cached.nptr.device == device:
+        return cached
+    if "ptr32" in data and "eptr32" in data:
+        meta = ScnMeta(data.ptr32.to(device), data.eptr32.to(device), int(data.num_graphs), int(data.max_nodes),
+                       int(data.max_edges), torch.zeros(1, dtype=torch.int32, device=device))
+    else:
+        n, e = int(data.num_nodes), int(data.edge_index.size(1))
+        meta = ScnMeta(torch.tensor([0, n], dtype=torch.int32, device=device),
+                       torch.tensor([0, e], dtype=torch.int32, device=device), 1, n, e,
+                       torch.zeros(1, dtype=torch.int32, device=device))
+    try:
+        data._scn_meta = meta
+    except AttributeError:
+        pass
+    return meta
+
+
+class SCNResidentFn(Function):
+    """(x, raw edge_index, meta, act, W_rel, b_rel, W_root, W_mlp, b_mlp) -> (S, losses[2])."""
+
+    @staticmethod
+    def forward(ctx, x, edge_index, meta: ScnMeta, act: int, W_rel, b_rel, W_root, W_mlp, b_mlp):
+        x = x.contiguous()
+        edge_index = edge_index.contiguous()
+        W_rel, b_rel, W_root, W_mlp, b_mlp = (t.contiguous() for t in (W_rel, b_rel, W_root, W_mlp, b_mlp))
+        N, F = x.shape
+        H, K = W_rel.shape[0], W_mlp.shape[0]
+        B = meta.num_graphs
+        dev = x.device
+        S = torch.empty(N, K, dtype=torch.float32, device=dev)
+        y = torch.empty(N, H, dtype=torch.float32, device=dev)
+        stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        ss = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        E = edge_index.size(1)
+        call("hscn_scn_resident_fwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
+             F, H, K, act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), meta.max_n, meta.max_e,
+             ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(losses), ptr(meta.flag), stream())
+        ctx.meta, ctx.act, ctx.dims = meta, act, (N, F, H, K, B, E)
+        ctx.save_for_backward(x, edge_index, W_mlp, S, y, stats, ss)
+        ctx.mark_non_differentiable(S)
+        return S, losses
+
+    @staticmethod
+    def backward(ctx, gS, g_losses):
+        x, edge_index, W_mlp, S, y, stats, ss = ctx.saved_tensors
+        meta: ScnMeta = ctx.meta
+        N, F, H, K, B, E = ctx.dims
+        dev = x.device
+        P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
+        partials = torch.empty(B, P, dtype=torch.float32, device=dev)
+        grads = torch.empty(P, dtype=torch.float32, device=dev)
+        gl = g_losses.contiguous() if g_losses is not None else torch.zeros(2, dtype=torch.float32, device=dev)
+        call("hscn_scn_resident_bwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
+             F, H, K, ctx.act, ptr(W_mlp), ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(gl), meta.max_n, meta.max_e,
+             ptr(partials), ptr(grads), ptr(meta.flag), stream())
+        o = 0
+        gW_rel = grads[o:o + H * F].view(H, F); o += H * F
+        gb_rel = grads[o:o + H]; o += H
+        gW_root = grads[o:o + H * F].view(H, F); o += H * F
+        gW_mlp = grads[o:o + K * H].view(K, H); o += K * H
+        gb_mlp = grads[o:o + K]
+        return None, None, None, None, gW_rel, gb_rel, gW_root, gW_mlp, gb_mlp

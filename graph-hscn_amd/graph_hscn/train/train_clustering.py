@@ -31,6 +31,11 @@ def _assign(S: torch.Tensor) -> torch.Tensor:
 
 
 def _forward(model: SCN, graphs: Sequence, device) -> tuple:
+    # fused graph-resident path (gcn_norm folded into the kernel) whenever the model/graphs qualify
+    data = graphs[0] if len(graphs) == 1 else Batch.from_data_list(list(graphs))
+    if getattr(data, "edge_weight", None) is None and model.resident_ok(data):
+        S, mc, o = model.forward_graphs(data)
+        return (S, mc, o, None), (None if len(graphs) == 1 else data.ptr)
     if len(graphs) == 1:
         g = graphs[0]
         ei, ew = gcn_norm(g.edge_index.to(device), getattr(g, "edge_weight", None), g.num_nodes,

@@ -285,6 +285,33 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
                       const float* pooled, const float* z, const float* g_pred, int max_n, int max_ell,
                       float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * a2/a4/a6  stage A, graph-resident engine: the body of the reference's clustering loop
+ * (train/train_clustering.py:37-47) for a batch of RAW graphs in one launch --
+ * gcn_norm(add_self_loops=True) folded into the CSR walk, SCN.forward for
+ * mp_units=[H], mlp_units=[] (GraphConv + act, Linear -> K logits, softmax), MinCUT and
+ * orthogonality losses on the binary A + I (model/hscn.py:56-64), one workgroup per graph.
+ *   edge_index: int64 [2,E] raw COO (self loops, if any, are replaced by the unit loop);
+ *   graph g owns nodes [nptr[g],nptr[g+1]) and edges [eptr[g],eptr[g+1]);
+ *   outputs S [N,K] (= softmax, the reference's first return), y [N,H] (post-activation
+ *   GraphConv output, kept for the backward), stats [B,4] {num, den, |S^T S|_F, ortho},
+ *   ss [B,K,K], losses [2] = {mean mincut, mean ortho}.
+ * hscn_scn_resident_bwd: grads packed as {W_rel [H,F], b_rel [H], W_root [H,F], W_mlp [K,H],
+ * b_mlp [K]} given g_losses = {dL/dmincut, dL/dortho} on the device.
+ * ------------------------------------------------------------------------- */
+int hscn_scn_resident_supported(int F, int H, int K, int max_n, int max_e);
+int64_t hscn_scn_resident_param_count(int F, int H, int K);
+int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                          const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                          const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
+                          const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
+                          float* losses, int32_t* flag, void* stream);
+int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                          const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                          const float* W_mlp, const float* S, const float* y, const float* stats, const float* ss,
+                          const float* g_losses, int max_n, int max_e, float* partials /*[B,P]*/, float* grads /*[P]*/,
+                          int32_t* flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""Fused graph-resident stage A (csrc/resident_scn.hip): gcn_norm + SCN.forward + MinCUT losses
+and its backward vs the CPU oracle's per-graph loop body (train_clustering.py:37-50)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as OM
+from tests.helpers import ATOL, DEV, close
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(K, H=16, act="elu", F=9, seed=0):
+    from graph_hscn.model.hscn import SCN
+    torch.manual_seed(seed)
+    om = OM.SCN([H], act, F, K)
+    pm = SCN([H], act, F, K).to(DEV)
+    pm.load_state_dict(om.state_dict())
+    return om, pm
+
+
+@pytest.mark.parametrize("K,H,act,name", [(16, 16, "elu", "peptides_func"), (4, 16, "tanh", "peptides_func"),
+                                          (32, 16, "relu", "pcqm_contact"), (6, 32, "elu", "pcqm_contact"),
+                                          (16, 16, "identity", "pascalvoc_sp")])
+def test_single_graph_step_matches_oracle(K, H, act, name):
+    from graph_hscn.loader.synthetic import SHAPES, make_dataset
+    F = SHAPES[name].num_features
+    om, pm = _models(K, H, act, F, seed=K)
+    for g in make_dataset(name, 3, seed=K + 1):
+        om.zero_grad(); pm.zero_grad()
+        S_o, mc_o, o_o, *_ = OM.scn_step_single_graph(om, g.x, g.edge_index)
+        (mc_o + 0.5 * o_o).backward()
+        fits = name != "pascalvoc_sp"      # n ~ 480, e ~ 2700 exceeds the fused backward's LDS: layered operators
+        assert pm.resident_ok(g) == fits
+        S_d, mc_d, o_d = pm.forward_graphs(g)
+        assert pm.last_engine == ("resident" if fits else "layered")
+        (mc_d + 0.5 * o_d).backward()
+        if fits:
+            g._scn_meta.check()
+        assert close(S_d, S_o)
+        assert abs(mc_d.item() - mc_o.item()) < ATOL and abs(o_d.item() - o_o.item()) < ATOL
+        assert np.array_equal(S_d.max(1)[1].cpu().numpy(), OM.assign_clusters(S_o)) or \
+            float((S_o.topk(2, 1).values[:, 0] - S_o.topk(2, 1).values[:, 1]).min()) < 1e-6
+        for (n_, po), (_, pp) in zip(om.named_parameters(), pm.named_parameters()):
+            assert close(pp.grad, po.grad, atol=1e-4, rtol=2e-3), n_
+
+
+def test_batched_equals_mean_of_singles_and_layered():
+    from graph_hscn.data import Batch
+    from graph_hscn.loader.synthetic import make_dataset
+    _, pm = _models(16)
+    graphs = make_dataset("peptides_func", 9, seed=3)
+    with torch.no_grad():
+        singles = [pm.forward_graphs(g) for g in graphs]
+    big = Batch.from_data_list(graphs)
+    pm.zero_grad()
+    S, mc, o = pm.forward_graphs(big)
+    assert pm.last_engine == "resident"
+    (mc + o).backward()
+    gr = {n: p.grad.clone() for n, p in pm.named_parameters()}
+    assert close(S, torch.cat([s[0] for s in singles]), atol=1e-6)
+    assert abs(mc.item() - torch.stack([s[1] for s in singles]).mean().item()) < 1e-6
+    assert abs(o.item() - torch.stack([s[2] for s in singles]).mean().item()) < 1e-6
+    # the layered operators on the same batch
+    from graph_hscn.nn import gcn_norm
+    pm.zero_grad()
+    ei, ew = gcn_norm(big.edge_index.to(DEV), None, big.num_nodes, add_self_loops=True)
+    S2, mc2, o2, _ = pm(big.x.to(DEV).float(), ei, ew, node_ptr=big.ptr.to(DEV).to(torch.int32))
+    (mc2 + o2).backward()
+    assert close(S, S2, atol=1e-6) and abs(mc.item() - mc2.item()) < 1e-6 and abs(o.item() - o2.item()) < 1e-6
+    for n, p in pm.named_parameters():
+        assert close(gr[n], p.grad, atol=1e-5, rtol=1e-3), n
+
+
+def test_existing_self_loops_become_the_unit_loop():
+    from graph_hscn.data import Data
+    om, pm = _models(4)
+    g = torch.Generator().manual_seed(0)
+    ei = torch.tensor([[0, 1, 1, 2, 2, 3, 1, 0], [1, 0, 2, 1, 2, 3, 1, 0]])       # self loops at 2, 3, 1, 0
+    x = torch.randint(0, 9, (4, 9), generator=g)
+    S_o, mc_o, o_o, *_ = OM.scn_step_single_graph(om, x, ei)
+    S_d, mc_d, o_d = pm.forward_graphs(Data(x=x, edge_index=ei, num_nodes=4))
+    assert close(S_d, S_o) and abs(mc_d.item() - mc_o.item()) < ATOL and abs(o_d.item() - o_o.item()) < ATOL
+
+
+def test_reproducible_and_flags_bad_edges():
+    from graph_hscn.data import Batch
+    from graph_hscn.loader.synthetic import make_dataset
+    _, pm = _models(16)
+    big = Batch.from_data_list(make_dataset("peptides_func", 6, seed=1))
+    outs = []
+    for _ in range(2):
+        pm.zero_grad()
+        S, mc, o = pm.forward_graphs(big)
+        (mc + o).backward()
+        outs.append((S.clone(), mc.clone(), [p.grad.clone() for p in pm.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
+    big.edge_index[0, 0] = big.num_nodes - 1
+    del big._d["_scn_meta"]
+    pm.forward_graphs(big)
+    with pytest.raises(IndexError):
+        big._scn_meta.check()
