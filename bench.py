@@ -55,6 +55,7 @@ def parse():
                     help="per-step: COO->CSR build is inside every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming-spmm", action="store_true")
+    ap.add_argument("--no-stage-a", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -348,6 +349,44 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
 
+    # ---- stage A (MinCUT coarsening: gcn_norm + SCN fwd + (mc+o) bwd) on the same graphs, fused engine,
+    # one hipGraph replay per 128-graph step; reported beside the stage C headline
+    stage_a = None
+    if rank == 0 and not args.no_stage_a:
+        from graph_hscn.data import Batch
+        from graph_hscn.model.hscn import SCN
+        torch.manual_seed(1)
+        scn = SCN([16], "elu", F, K).to(dev)
+        bigd = Batch.from_data_list(graphs).to(dev)
+        bigd.x = bigd.x.float()
+        if scn.resident_ok(bigd):
+            def a_step():
+                for p in scn.parameters():
+                    p.grad = None
+                _, mc, o = scn.forward_graphs(bigd)
+                (mc + o).backward()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    a_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                a_step()
+            for _ in range(20):
+                ga.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ga.replay()
+            torch.cuda.synchronize()
+            ta = (time.perf_counter() - t0) / args.steps
+            stage_a = {"what": "gcn_norm + SCN fwd + (mincut+ortho) bwd, batched, graph-resident kernels",
+                       "ms_per_step": ta * 1e3, "graphs_per_s": B / ta,
+                       "combined_A_plus_C_graphs_per_s": B / (ta + dt / args.steps)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(hb_host, args, C, loss_fn, args.cpu_seconds)
@@ -366,7 +405,7 @@ def main():
                        "virtual_nodes_per_gpu": int(hb["virtual"].num_nodes),
                        "mode": args.mode, "engine": model.last_engine, "structure_build": args.structure,
                        "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "streaming_spmm_scaled": streaming,
+            "roofline": roofline, "cpu_baseline": cpu, "streaming_spmm_scaled": streaming, "stage_a": stage_a,
         }
         if cpu:
             out["vs_cpu_baseline"] = value / cpu["value"]
