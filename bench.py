@@ -205,6 +205,7 @@ def main():
     model.engine = args.engine
     reducer = FlatGradReducer(model) if world > 1 else None
     x_dict, ei_dict = hb.x_dict, hb.edge_index_dict
+    root_grad = torch.ones((), dtype=torch.float32, device=dev)   # = loss.backward()'s implicit ones_like(loss)
 
     def fwd_bwd():
         if args.structure == "per-step":
@@ -213,7 +214,7 @@ def main():
             p.grad = None
         pred = model(x_dict, ei_dict, hb)
         loss, _ = criterion(loss_fn, pred, y)
-        loss.backward()
+        loss.backward(root_grad)
         return loss
 
     def step_eager():

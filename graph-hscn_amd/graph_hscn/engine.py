@@ -116,6 +116,7 @@ class HSCNResidentFn(Function):
         ctx.meta, ctx.head_act, ctx.dims = meta, head_act, (N, F, H, L, C, B)
         ctx.save_for_backward(x_local, ei_ll, acts, pooled, z, W1, W2, *[params[9 * l] for l in range(L)])
         ctx.mark_non_differentiable(*([xv_out] if xv_out is not None else []))
+        ctx.set_materialize_grads(False)
         if xv_out is None:
             return pred
         return pred, xv_out
@@ -123,6 +124,8 @@ class HSCNResidentFn(Function):
     @staticmethod
     def backward(ctx, g_pred, *_):
         x_local, ei_ll, acts, pooled, z, W1, W2, *W_ll = ctx.saved_tensors
+        if g_pred is None:
+            return (None,) * (7 + 9 * ((len(W_ll))) + 4)
         meta: ResidentMeta = ctx.meta
         N, F, H, L, C, B = ctx.dims
         dev = x_local.device
@@ -214,6 +217,7 @@ class SCNResidentFn(Function):
         ctx.meta, ctx.act, ctx.dims = meta, act, (N, F, H, K, B, E)
         ctx.save_for_backward(x, edge_index, W_mlp, S, y, stats, ss)
         ctx.mark_non_differentiable(S)
+        ctx.set_materialize_grads(False)
         return S, losses
 
     @staticmethod

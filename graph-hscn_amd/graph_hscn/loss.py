@@ -23,11 +23,14 @@ class _CriterionFn(Function):
              stream())
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(score)
+        ctx.set_materialize_grads(False)  # no zero tensor (a fill launch) for the score output
         return loss.view(()), score
 
     @staticmethod
     def backward(ctx, g_loss, _g_score):
         (grad,) = ctx.saved_tensors
+        if g_loss is None:
+            return None, None, None
         out = torch.empty_like(grad)
         call("hscn_scale", ptr(g_loss.reshape(1).contiguous()), ptr(grad), ptr(out), grad.numel(), stream())
         return out, None, None

@@ -302,6 +302,7 @@ class MinCutSparseFn(Function):
              stream())
         ctx.rel, ctx.G = rel, num_graphs
         ctx.save_for_backward(S, stats, ss, node_ptr)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(S, padj)
         if px is not None:
             ctx.mark_non_differentiable(px)
@@ -345,6 +346,7 @@ class MinCutDenseFn(Function):
         call("hscn_mincut_dense_fwd", ptr(x), ptr(adj), ptr(logits), B, n, K, Fx, ptr(S), ptr(AS), ptr(deg),
              ptr(stats), ptr(ss), ptr(px), ptr(padj), ptr(losses), stream())
         ctx.save_for_backward(adj, S, AS, deg, stats, ss)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(S, padj)
         if px is not None:
             ctx.mark_non_differentiable(px)
