@@ -36,6 +36,7 @@
 // multiply/add in the gather-reduce (same as the layered kernels).
 #include "hscn_common.h"
 #include "resident_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -54,10 +55,13 @@ struct FwdArgs {
   LayerP layer[MAXL];
   const float *W1, *b1, *W2, *b2;
   float *acts, *pooled, *z, *pred, *xv_out;
+  int32_t *csr_rowptr_t, *csr_col_t;  // exported source-keyed ll CSR (graph g: rowptr at n0+g, col at e0)
+  float* dinv_out;                     // exported in-degree^-1/2 of the ll relation
   int32_t* flag;
   int64_t N, V;
   int F, L, C, head_act, max_n, max_v, max_ell, max_evv, compute_virtual;
   int spec;  // 1: ll path and virtual branch run concurrently on two wave groups (needs a 3rd n x H buffer)
+  int exp;   // 1: this launch also builds + exports the source-keyed ll CSR (needs LDS for it)
   float slope;
 };
 
@@ -68,6 +72,8 @@ struct BwdArgs {
   const float* W_ll[MAXL];
   const float *W1, *W2;
   const float *acts, *pooled, *z, *g_pred;
+  const int32_t *csr_rowptr_t, *csr_col_t;  // from the forward launch
+  const float* dinv_in;
   float* partials;  // [B][P]
   int32_t* flag;
   int64_t N;
@@ -81,32 +87,45 @@ struct BwdArgs {
 template <int H, int RT>
 struct WStage {
   static constexpr int TOTAL = 4 * H * H + 5 * H;
-  static constexpr int WPT = (TOTAL + RT - 1) / RT;
-  float v[WPT];
+  static constexpr int MPT = (H * H + RT - 1) / RT;  // words of each matrix per thread
+  float m[4][MPT];
+  float v[5];
+  // One uniform base pointer per matrix / vector (no per-lane pointer table lookups), clamped
+  // addresses + select instead of branches: every request of the prefetch is issued back to back.
   __device__ __forceinline__ void fetch(const LayerP& P, bool cv, int fin) {
+    const float* mats[4] = {P.W_ll, cv ? P.W_src : P.W_ll, cv ? P.W_dst : P.W_ll, cv ? P.W_vv : P.W_ll};
+    const float* vecs[5] = {P.b_ll, cv ? P.b_vv : P.b_ll, cv ? P.b_gat : P.b_ll, cv ? P.att_src : P.b_ll,
+                            cv ? P.att_dst : P.b_ll};
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int idx = threadIdx.x + i * RT;
-      float val = 0.f;
-      if (idx < 4 * H * H) {
-        const int m = idx / (H * H), d = idx - m * H * H;
+    for (int mm = 0; mm < 4; ++mm) {
+#pragma unroll
+      for (int i = 0; i < MPT; ++i) {
+        const int d = threadIdx.x + i * RT;       // destination slot k*H + o (transposed)
         const int k = d / H, o = d - k * H;
-        const float* src = m == 0 ? P.W_ll : (m == 1 ? P.W_src : (m == 2 ? P.W_dst : P.W_vv));
-        if (k < fin && (m == 0 || cv)) val = src[o * fin + k];
-      } else if (idx < TOTAL) {
-        const int j = idx - 4 * H * H;
-        const int q = j / H;
-        const float* src = q == 0 ? P.b_ll : (q == 1 ? P.b_vv : (q == 2 ? P.b_gat : (q == 3 ? P.att_src : P.att_dst)));
-        if (q == 0 || cv) val = src[j - q * H];
+        const bool ok = d < H * H && k < fin && (mm == 0 || cv);
+        const float t = mats[mm][ok ? o * fin + k : 0];
+        m[mm][i] = ok ? t : 0.f;
       }
-      v[i] = val;
+    }
+    const int t_ = threadIdx.x < H ? threadIdx.x : 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float t = vecs[q][t_];
+      v[q] = (threadIdx.x < H && (q == 0 || cv)) ? t : 0.f;
     }
   }
   __device__ __forceinline__ void store(float* dst) const {
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int idx = threadIdx.x + i * RT;
-      if (idx < TOTAL) dst[idx] = v[i];
+    for (int mm = 0; mm < 4; ++mm) {
+#pragma unroll
+      for (int i = 0; i < MPT; ++i) {
+        const int d = threadIdx.x + i * RT;
+        if (d < H * H) dst[mm * H * H + d] = m[mm][i];
+      }
+    }
+    if (threadIdx.x < H) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) dst[4 * H * H + q * H + threadIdx.x] = v[q];
     }
   }
 };
@@ -201,10 +220,11 @@ __device__ void agg_gcn_lds(const int* rowptr, const int* col, const float* dr, 
 struct FwdLayout {
   size_t xa, bh, bs, xva, xvb, hv, a_s, a_d, sc, dinv, dinv_v, wt, headw, part, vec;
   size_t rowptr, col, rowptr_lv, col_lv, rowptr_vv, col_vv, cursorA, tmpA, cursorB, tmpB, wsum;
+  size_t rowptr_t, col_t, cursorT, tmpT, cursorV, tmpV;
   size_t ek_ll, eo_ll, ek_lv, eo_lv, ek_vv, eo_vv, total;
 };
 __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max_v, int max_ell, int max_evv,
-                                                int spec) {
+                                                int spec, int exp) {
   FwdLayout Y;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };  // keep 16-B alignment
@@ -249,6 +269,12 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   Y.cursorB = take(cb);
   Y.tmpB = take(max_n > max_evv ? max_n : max_evv);
   Y.wsum = take(32);
+  Y.rowptr_t = take(exp ? max_n + 1 : 0);
+  Y.col_t = take(exp ? max_ell : 0);
+  Y.cursorT = take(exp ? max_n + 1 : 0);
+  Y.tmpT = take(exp ? max_ell : 0);
+  Y.cursorV = take(max_v + 1);
+  Y.tmpV = take(max_evv);
   Y.total = o;
   return Y;
 }
@@ -265,11 +291,11 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
   const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
   const int el0 = A.eptr_lv[g], nel = A.eptr_lv[g + 1] - el0;
-  if (n > A.max_n || nv > A.max_v || ne > A.max_ell || nev > A.max_evv || nel > A.max_n || n < 0 || nv < 0) {
+  if ((n > A.max_n) | (nv > A.max_v) | (ne > A.max_ell) | (nev > A.max_evv) | (nel > A.max_n) | (n < 0) | (nv < 0)) {
     if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
     return;
   }
-  const FwdLayout Y = fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec);
+  const FwdLayout Y = fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec, A.exp);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   float *xa = fb + Y.xa, *bh = fb + Y.bh, *bs = fb + Y.bs, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *hv = fb + Y.hv;
@@ -293,44 +319,63 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   STAMP(0);
   WStage<H, RT> ws;
   ws.fetch(A.layer[0], cv, F);
-  constexpr int EPT = 4;   // edges per thread held in registers (covers RT*EPT edges per relation)
+  constexpr int EPT = 2;   // edges per thread held in registers (covers RT*EPT edges per relation)
   constexpr int XPT = 8;   // feature words per thread held in registers
-  int kll[EPT], oll[EPT], klv[EPT], olv[EPT], kvv[EPT], ovv[EPT];
+  // raw 64-bit ids first (clamped addresses, no arithmetic on the results yet): all requests of the
+  // prologue are in flight together
+  const int64_t* dummy = reinterpret_cast<const int64_t*>(A.lptr);
+  const int64_t *pld = A.ll_dst ? A.ll_dst : dummy, *pls = A.ll_src ? A.ll_src : dummy;
+  const int64_t *pvd = (cv && A.lv_dst) ? A.lv_dst : dummy, *pvs = (cv && A.lv_src) ? A.lv_src : dummy;
+  const int64_t *pwd = (cv && A.vv_dst) ? A.vv_dst : dummy, *pws = (cv && A.vv_src) ? A.vv_src : dummy;
+  long long rld[EPT], rls[EPT], rvd[EPT], rvs[EPT], rwd[EPT], rws[EPT];
   float xr[XPT], xvr[2], hw0 = 0.f, hw1 = 0.f;
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     const int e = threadIdx.x + i * RT;
-    kll[i] = oll[i] = klv[i] = olv[i] = kvv[i] = ovv[i] = -1;
-    if (e < ne) { kll[i] = (int)(A.ll_dst[e0 + e] - n0); oll[i] = (int)(A.ll_src[e0 + e] - n0); }
-    if (cv && e < nel) { klv[i] = (int)(A.lv_dst[el0 + e] - v0); olv[i] = (int)(A.lv_src[el0 + e] - n0); }
-    if (cv && e < nev) { kvv[i] = (int)(A.vv_dst[ev0 + e] - v0); ovv[i] = (int)(A.vv_src[ev0 + e] - v0); }
+    const bool o1 = e < ne && A.ll_dst, o2 = cv && e < nel && A.lv_dst, o3 = cv && e < nev && A.vv_dst;
+    rld[i] = pld[o1 ? e0 + e : 0]; rls[i] = pls[o1 ? e0 + e : 0];
+    rvd[i] = pvd[o2 ? el0 + e : 0]; rvs[i] = pvs[o2 ? el0 + e : 0];
+    rwd[i] = pwd[o3 ? ev0 + e : 0]; rws[i] = pws[o3 ? ev0 + e : 0];
   }
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int idx = threadIdx.x + i * RT;
     const int r = idx / H, k = idx - r * H;
-    xr[i] = (idx < n * H && k < F) ? A.x_local[(size_t)(n0 + r) * F + k] : 0.f;
+    const bool ok = idx < n * H && k < F;
+    const float t = A.x_local[ok ? (size_t)(n0 + r) * F + k : 0];
+    xr[i] = ok ? t : 0.f;
   }
+  const float* pxv = (cv && A.x_virtual) ? A.x_virtual : A.x_local;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = threadIdx.x + i * RT;
     const int r = idx / H, k = idx - r * H;
-    xvr[i] = (cv && idx < nv * H && k < F) ? A.x_virtual[(size_t)(v0 + r) * F + k] : 0.f;
+    const bool ok = cv && idx < nv * H && k < F;
+    const float t = pxv[ok ? (size_t)(v0 + r) * F + k : 0];
+    xvr[i] = ok ? t : 0.f;
   }
-  {  // head weights: W1 [H][H] | b1 [H] | W2 [C][H] | b2 [C]   (natural layout), two words per thread
-    const int HT = H * H + H + A.C * H + A.C;
-    auto hsrc = [&](int idx) -> float {
-      if (idx < H * H) return A.W1[idx];
-      idx -= H * H;
-      if (idx < H) return A.b1[idx];
-      idx -= H;
-      if (idx < A.C * H) return A.W2[idx];
-      return A.b2[idx - A.C * H];
-    };
-    if ((int)threadIdx.x < HT) hw0 = hsrc(threadIdx.x);
-    if ((int)threadIdx.x + RT < HT) hw1 = hsrc(threadIdx.x + RT);
-    // anything beyond 2*RT words (H = 64 or very wide heads) is copied directly
-    for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = hsrc(idx);
+  // head weights: W1 [H][H] | b1 [H] | W2 [C][H] | b2 [C]   (natural layout)
+  constexpr int HPT = (H * H + RT - 1) / RT;
+  float hw1r[HPT], hw2r[2], hb1, hb2;
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    hw1r[i] = A.W1[idx < H * H ? idx : 0];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    hw2r[i] = A.W2[idx < A.C * H ? idx : 0];
+  }
+  hb1 = A.b1[threadIdx.x < H ? threadIdx.x : 0];
+  hb2 = A.b2[(int)threadIdx.x < A.C ? threadIdx.x : 0];
+  (void)hw0; (void)hw1;
+  int kll[EPT], oll[EPT], klv[EPT], olv[EPT], kvv[EPT], ovv[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    kll[i] = (int)(rld[i] - n0); oll[i] = (int)(rls[i] - n0);
+    klv[i] = (int)(rvd[i] - v0); olv[i] = (int)(rvs[i] - n0);
+    kvv[i] = (int)(rwd[i] - v0); ovv[i] = (int)(rws[i] - v0);
   }
   // ---- consume: validate + park in LDS ---------------------------------------------------------
   {
@@ -342,8 +387,9 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
       const int e = threadIdx.x + i * RT;
       if (e < ne) {
         int k = kll[i];
-        if (k < 0 || k >= n || oll[i] < 0 || oll[i] >= n) { bad = true; k = -1; }
-        ek_ll[e] = k; eo_ll[e] = oll[i];
+        int o_ = oll[i];
+        if (k < 0 || k >= n || o_ < 0 || o_ >= n) { bad = true; k = -1; o_ = -1; }
+        ek_ll[e] = k; eo_ll[e] = o_;
       }
       if (cv && e < nel) {
         int k = klv[i];
@@ -358,8 +404,8 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
     }
     // slices longer than RT*EPT edges (not the LRGB case): straight copy
     for (int e = threadIdx.x + EPT * RT; e < ne; e += RT) {
-      int k = (int)(A.ll_dst[e0 + e] - n0); const int o = (int)(A.ll_src[e0 + e] - n0);
-      if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; }
+      int k = (int)(A.ll_dst[e0 + e] - n0); int o = (int)(A.ll_src[e0 + e] - n0);
+      if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; o = -1; }
       ek_ll[e] = k; eo_ll[e] = o;
     }
     if (cv) {
@@ -396,33 +442,59 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
       xva[idx] = k < F ? A.x_virtual[(size_t)(v0 + r) * F + k] : 0.f;
     }
   }
-  {
-    const int HT = H * H + H + A.C * H + A.C;
-    if ((int)threadIdx.x < HT) headw[threadIdx.x] = hw0;
-    if ((int)threadIdx.x + RT < HT) headw[threadIdx.x + RT] = hw1;
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx < H * H) headw[idx] = hw1r[i];
   }
+  if (threadIdx.x < H) headw[H * H + threadIdx.x] = hb1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx < A.C * H) headw[H * H + H + idx] = hw2r[i];
+  }
+  for (int idx = threadIdx.x + 2 * RT; idx < A.C * H; idx += RT) headw[H * H + H + idx] = A.W2[idx];
+  for (int idx = threadIdx.x; idx < A.C; idx += RT) headw[H * H + H + A.C * H + idx] = idx == (int)threadIdx.x ? hb2 : A.b2[idx];
   ws.store(wt);
   __syncthreads();
   STAMP(1);
-  // ---- structure: group A builds ll while group B builds vv; then everyone builds lv ----------
-  if (cv) {
-    if (!inB) {
-      build_csr_lds(ib + Y.ek_ll, ib + Y.eo_ll, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, wsum, GA);
-      dinv_from_rowptr(rowptr, n, dinv, GA);
+  // ---- structure: the CSRs are independent, so wave groups build them side by side between the
+  // same six barriers: ll keyed by target (forward), ll keyed by source (exported for the backward
+  // launch), vv, and lv (multisplit: five barriers + one idle)
+  {
+    int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
+    const int w_t = !A.exp ? 0 : (cv ? (NW * 3) / 8 : NW - NW / 2);          // 6 of 16 waves (1 of 4)
+    const int w_ll = cv ? (A.exp ? (NW * 3) / 8 : NW / 2) : NW - w_t;
+    const int w_vv = cv ? (NW - w_ll - w_t) / 2 : 0;
+    const int w_lv = cv ? NW - w_ll - w_t - w_vv : 0;
+    const int wa = wave < w_ll ? 0 : (wave < w_ll + w_t ? 1 : (wave < w_ll + w_t + w_vv ? 2 : 3));
+    const int wbase = wa == 0 ? 0 : (wa == 1 ? w_ll : (wa == 2 ? w_ll + w_t : w_ll + w_t + w_vv));
+    const int wcnt = wa == 0 ? w_ll : (wa == 1 ? w_t : (wa == 2 ? w_vv : w_lv));
+    const Grp GS{(int)threadIdx.x - wbase * 64, wcnt * 64, wave - wbase, wcnt};
+    if (wa == 0) {
+      build_csr_lds(ib + Y.ek_ll, ib + Y.eo_ll, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, wsum, GS);
+      dinv_from_rowptr(rowptr, n, dinv, GS);
+    } else if (wa == 1) {
+      build_csr_lds(ib + Y.eo_ll, ib + Y.ek_ll, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, wsum + 8, GS);
+    } else if (wa == 2) {
+      build_csr_lds(ib + Y.ek_vv, ib + Y.eo_vv, nev, nv, rowptr_vv, col_vv, ib + Y.cursorV, ib + Y.tmpV, wsum + 16,
+                    GS);
+      dinv_from_rowptr(rowptr_vv, nv, dinv_v, GS);
     } else {
-      build_csr_lds(ib + Y.ek_vv, ib + Y.eo_vv, nev, nv, rowptr_vv, col_vv, ib + Y.cursorB, ib + Y.tmpB, wsum + 16,
-                    GB);
-      dinv_from_rowptr(rowptr_vv, nv, dinv_v, GB);
+      build_csr_multisplit_lds(ib + Y.ek_lv, ib + Y.eo_lv, nel, nv, rowptr_lv, col_lv, ib + Y.cursorB, ib + Y.tmpB,
+                               wsum + 24, GS);
+      __syncthreads();  // the multisplit has one barrier less than the rank build
     }
     STAMP(2);
-    build_csr_multisplit_lds(ib + Y.ek_lv, ib + Y.eo_lv, nel, nv, rowptr_lv, col_lv, ib + Y.cursorB, ib + Y.tmpB,
-                             wsum, ALL);
-  } else {
-    build_csr_lds(ib + Y.ek_ll, ib + Y.eo_ll, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, wsum, ALL);
-    dinv_from_rowptr(rowptr, n, dinv, ALL);
-    STAMP(2);
+    __syncthreads();
+    // export the source-keyed CSR and the degree norm for the backward launch
+    if (A.exp) {
+      for (int i = threadIdx.x; i <= n; i += RT) A.csr_rowptr_t[(size_t)n0 + g + i] = rowptr_t[i];
+      const int cnt_t = rowptr_t[n];
+      for (int p = threadIdx.x; p < cnt_t; p += RT) A.csr_col_t[(size_t)e0 + p] = col_t[p];
+      for (int i = threadIdx.x; i < n; i += RT) A.dinv_out[(size_t)n0 + i] = dinv[i];
+    }
   }
-  __syncthreads();
   STAMP(3);
 
   for (int l = 0; l < A.L; ++l) {
@@ -623,19 +695,14 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
 
 // =============================== backward =====================================================
 struct BwdLayout {
-  size_t G, GH, X, dinv, vec, red, wl, headw, rowptr_t, col_t, cursor, tmp, wsum, ek, eo, total;
+  size_t G, GH, X, dinv, vec, red, wl, headw, rowptr_t, col_t, total;
 };
 __host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max_ell) {
   BwdLayout Y;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
   Y.G = take((size_t)max_n * H);
-  // GH is first written in layer L-1; before that its space holds the staged COO slice
-  const size_t st = (size_t)2 * (((size_t)max_ell + 3) / 4 * 4);
-  const size_t gh = (size_t)max_n * H;
-  Y.GH = take(gh > st ? gh : st);
-  Y.ek = Y.GH;
-  Y.eo = Y.GH + ((size_t)max_ell + 3) / 4 * 4;
+  Y.GH = take((size_t)max_n * H);
   Y.X = take((size_t)max_n * H);
   Y.dinv = take(max_n);
   Y.vec = take(256 + 64);
@@ -644,9 +711,6 @@ __host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max
   Y.headw = take((size_t)H * H + (size_t)C * H + C);  // W1 | W2 | g_pred row
   Y.rowptr_t = take(max_n + 1);
   Y.col_t = take(max_ell);
-  Y.cursor = take(max_n + 1);
-  Y.tmp = take(max_ell);
-  Y.wsum = take(32);
   Y.total = o;
   return Y;
 }
@@ -670,11 +734,11 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
   int* ib = reinterpret_cast<int*>(smem);
   float *G = fb + Y.G, *GH = fb + Y.GH, *X = fb + Y.X, *dinv = fb + Y.dinv, *vec = fb + Y.vec;
   float *red = fb + Y.red, *wl = fb + Y.wl, *headw = fb + Y.headw;
-  int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t, *cursor = ib + Y.cursor, *tmp = ib + Y.tmp;
-  int *wsum = ib + Y.wsum, *ek = ib + Y.ek, *eo = ib + Y.eo;
+  int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
   const int L = A.L;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const Grp ALL{(int)threadIdx.x, RT, wave, NW};
+  (void)ib;
 
   // ---- prologue: request all global inputs of the first phases at once ------------------------
   STAMP(0);
@@ -685,53 +749,59 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
   float* gz = vec + 128;     // dL/d(lin_1 output, pre-activation)
   float* gpool = vec + 192;
   float* pol = vec + 256;    // pooled
-  constexpr int EPT = 4, XPT = 8;
-  int ks[EPT], os[EPT];
-  float yr[XPT], hw0 = 0.f, hw1 = 0.f, zv = 0.f, pv = 0.f;
+  constexpr int EPT = 2, XPT = 8, RPT = 2;
+  // everything the launch needs from HBM up front, clamped addresses, no use before the parking
+  // stores below: source-keyed CSR + degree norm (exported by the forward launch), the last layer's
+  // output, head weights, upstream gradient
+  int cr[EPT], rr[RPT];
+  float yr[XPT], dr[RPT], hw0, hw1, zv, pv;
   const int HT = H * H + A.C * H + A.C;
-  auto hsrc = [&](int idx) -> float {
-    if (idx < H * H) return A.W1[idx];
+  auto haddr = [&](int idx) -> const float* {
+    if (idx < H * H) return A.W1 + idx;
     idx -= H * H;
-    if (idx < A.C * H) return A.W2[idx];
-    return A.g_pred[(size_t)g * A.C + (idx - A.C * H)];
+    if (idx < A.C * H) return A.W2 + idx;
+    idx -= A.C * H;
+    return A.g_pred + (size_t)g * A.C + (idx < A.C ? idx : 0);
   };
+  const int32_t* rpt = A.csr_rowptr_t + (size_t)n0 + g;
+  const int32_t* cpt = A.csr_col_t + (size_t)e0;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    rr[i] = rpt[idx <= n ? idx : 0];
+    dr[i] = A.dinv_in[(size_t)n0 + (idx < n ? idx : 0)];
+  }
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     const int e = threadIdx.x + i * RT;
-    ks[i] = os[i] = -1;
-    if (e < ne) { ks[i] = (int)(A.ll_src[e0 + e] - n0); os[i] = (int)(A.ll_dst[e0 + e] - n0); }  // key = SOURCE
+    cr[i] = cpt[(e < ne && A.csr_col_t) ? e : 0];
   }
   const float* yL = A.acts + ((size_t)(L - 1) * A.N + n0) * H;
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int idx = threadIdx.x + i * RT;
-    yr[i] = idx < n * H ? yL[idx] : 0.f;
+    yr[i] = yL[idx < n * H ? idx : 0];
   }
-  if ((int)threadIdx.x < HT) hw0 = hsrc(threadIdx.x);
-  if ((int)threadIdx.x + RT < HT) hw1 = hsrc(threadIdx.x + RT);
-  for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = hsrc(idx);
-  if (threadIdx.x < H) {
-    zv = A.z[(size_t)g * H + threadIdx.x];
-    pv = A.pooled[(size_t)g * H + threadIdx.x];
-  }
-  {
-    bool bad = false;
+  hw0 = *haddr((int)threadIdx.x < HT ? (int)threadIdx.x : 0);
+  hw1 = *haddr((int)threadIdx.x + RT < HT ? (int)threadIdx.x + RT : 0);
+  for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = *haddr(idx);
+  zv = A.z[(size_t)g * H + (threadIdx.x < H ? threadIdx.x : 0)];
+  pv = A.pooled[(size_t)g * H + (threadIdx.x < H ? threadIdx.x : 0)];
+  // ---- park in LDS ----------------------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int e = threadIdx.x + i * RT;
-      if (e < ne) {
-        int k = ks[i];
-        if (k < 0 || k >= n || os[i] < 0 || os[i] >= n) { bad = true; k = -1; }
-        ek[e] = k; eo[e] = os[i];
-      }
-    }
-    for (int e = threadIdx.x + EPT * RT; e < ne; e += RT) {
-      int k = (int)(A.ll_src[e0 + e] - n0); const int o = (int)(A.ll_dst[e0 + e] - n0);
-      if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; }
-      ek[e] = k; eo[e] = o;
-    }
-    if (bad && A.flag) atomicOr(A.flag, 2);
+  for (int i = 0; i < RPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx <= n) rowptr_t[idx] = rr[i];
+    if (idx < n) dinv[idx] = dr[i];
   }
+  for (int idx = threadIdx.x + RPT * RT; idx <= n; idx += RT) rowptr_t[idx] = rpt[idx];
+  for (int idx = threadIdx.x + RPT * RT; idx < n; idx += RT) dinv[idx] = A.dinv_in[(size_t)n0 + idx];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = threadIdx.x + i * RT;
+    if (e < ne) col_t[e] = cr[i];
+  }
+  for (int e = threadIdx.x + EPT * RT; e < ne; e += RT) col_t[e] = cpt[e];
   // last layer's output (ReLU mask source) -> X; it is also the next layer's input further down
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
@@ -745,19 +815,8 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
     zz[threadIdx.x] = zv;
     pol[threadIdx.x] = pv;
   }
-  for (int i = threadIdx.x; i <= n; i += RT) cursor[i] = 0;
   __syncthreads();
   STAMP(1);
-  // in-degree (by target) -> dinv
-  for (int e = threadIdx.x; e < ne; e += RT)
-    if (ek[e] >= 0) atomicAdd(&cursor[eo[e]], 1);
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += RT) {
-    const int d = cursor[i];
-    dinv[i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
-  }
-  __syncthreads();
-  build_csr_lds(ek, eo, ne, n, rowptr_t, col_t, cursor, tmp, wsum, ALL);
   STAMP(2);
 
   // ---- head backward ---------------------------------------------------------------------------
@@ -937,8 +996,8 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
   STAMP(63);
 }
 
-inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int spec) {
-  return fwd_layout(H, C, max_n, max_v, max_ell, max_evv, spec).total * 4;
+inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int spec, int exp) {
+  return fwd_layout(H, C, max_n, max_v, max_ell, max_evv, spec, exp).total * 4;
 }
 inline size_t bwd_lds_bytes(int H, int C, int max_n, int max_ell) {
   return bwd_layout(H, C, max_n, max_ell).total * 4;
@@ -955,14 +1014,74 @@ int launch_fwd_rt(const FwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
+// Source-keyed ll CSR + degree norm for the backward launch when the forward launch had no LDS
+// left to build them on the side (large graphs): a light kernel of its own, one workgroup per graph.
+__global__ void __launch_bounds__(256) k_ll_csr_t(const FwdArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  int* ib = reinterpret_cast<int*>(smem);
+  const int g = blockIdx.x;
+  const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
+  const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
+  if (n > A.max_n || ne > A.max_ell || n < 0 || ne < 0) return;
+  int* ek = ib;                       // [max_ell]  key = source
+  int* eo = ek + A.max_ell;           // [max_ell]
+  int* rowptr_t = eo + A.max_ell;     // [max_n+1]
+  int* col_t = rowptr_t + A.max_n + 1;
+  int* cursor = col_t + A.max_ell;    // [max_n+1]  (in-degree counts first)
+  int* tmp = cursor + A.max_n + 1;
+  int* wsum = tmp + A.max_ell;
+  const Grp ALL{(int)threadIdx.x, 256, (int)threadIdx.x >> 6, 4};
+  for (int i = threadIdx.x; i <= n; i += 256) cursor[i] = 0;
+  for (int e = threadIdx.x; e < ne; e += 256) {
+    int k = (int)(A.ll_src[e0 + e] - n0), o = (int)(A.ll_dst[e0 + e] - n0);
+    if (k < 0 || k >= n || o < 0 || o >= n) { k = -1; o = -1; }
+    ek[e] = k; eo[e] = o;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ne; e += 256)
+    if (ek[e] >= 0) atomicAdd(&cursor[eo[e]], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int d = cursor[i];
+    A.dinv_out[(size_t)n0 + i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
+  }
+  __syncthreads();
+  build_csr_lds(ek, eo, ne, n, rowptr_t, col_t, cursor, tmp, wsum, ALL);
+  for (int i = threadIdx.x; i <= n; i += 256) A.csr_rowptr_t[(size_t)n0 + g + i] = rowptr_t[i];
+  const int cnt_t = rowptr_t[n];
+  for (int p = threadIdx.x; p < cnt_t; p += 256) A.csr_col_t[(size_t)e0 + p] = col_t[p];
+}
+
 template <int H>
 int launch_fwd(FwdArgs& A, int64_t B, hipStream_t st) {
-  // concurrent wave groups need a third n x H buffer: use them when it fits (and leaves the CU usable)
-  A.spec = A.compute_virtual &&
-           fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, 1) <= 160 * 1024 ? 1 : 0;
-  const size_t lds = fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec);
-  if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
-  return A.max_n <= 64 ? launch_fwd_rt<H, 256>(A, B, lds, st) : launch_fwd_rt<H, 1024>(A, B, lds, st);
+  // preference order: concurrent wave groups + CSR export, then dropping the third n x H buffer,
+  // then dropping the in-launch export (a separate light kernel builds it)
+  const bool want_exp = A.csr_rowptr_t != nullptr;
+  const int tries[3][2] = {{1, 1}, {0, 1}, {0, 0}};
+  size_t lds = 0;
+  bool ok = false;
+  for (int t = 0; t < 3 && !ok; ++t) {
+    A.spec = (A.compute_virtual && tries[t][0]) ? 1 : 0;
+    A.exp = (want_exp && tries[t][1]) ? 1 : 0;
+    lds = fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec, A.exp);
+    ok = lds <= 160 * 1024;
+  }
+  if (!ok) return HSCN_E_UNSUPPORTED;
+  static const int rt_env = getenv("HSCN_RT") ? atoi(getenv("HSCN_RT")) : 0;
+  int rc;
+  if (A.max_n <= 64 || rt_env == 256) rc = launch_fwd_rt<H, 256>(A, B, lds, st);
+  else if (rt_env == 512) rc = launch_fwd_rt<H, 512>(A, B, lds, st);
+  else rc = launch_fwd_rt<H, 1024>(A, B, lds, st);
+  if (rc) return rc;
+  if (want_exp && !A.exp) {
+    const size_t l2 = ((size_t)4 * A.max_ell + 2 * ((size_t)A.max_n + 1) + 16) * 4;
+    if (l2 > 160 * 1024) return HSCN_E_UNSUPPORTED;
+    if (l2 > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_ll_csr_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    k_ll_csr_t<<<(unsigned)B, 256, l2, st>>>(A);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
+  return 0;
 }
 template <int H, int RT>
 int launch_bwd_rt(const BwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
@@ -977,7 +1096,10 @@ template <int H>
 int launch_bwd(const BwdArgs& A, int64_t B, hipStream_t st) {
   const size_t lds = bwd_lds_bytes(H, A.C, A.max_n, A.max_ell);
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
-  return A.max_n <= 64 ? launch_bwd_rt<H, 256>(A, B, lds, st) : launch_bwd_rt<H, 1024>(A, B, lds, st);
+  static const int rt_env = getenv("HSCN_RT") ? atoi(getenv("HSCN_RT")) : 0;
+  if (A.max_n <= 64 || rt_env == 256) return launch_bwd_rt<H, 256>(A, B, lds, st);
+  if (rt_env == 512) return launch_bwd_rt<H, 512>(A, B, lds, st);
+  return launch_bwd_rt<H, 1024>(A, B, lds, st);
 }
 
 }  // namespace
@@ -993,7 +1115,7 @@ int hscn_diag_set_stamp_buffer(long long* buf) {
 int hscn_resident_supported(int F, int H, int L, int C, int max_n, int max_v, int max_ell, int max_evv) {
   if (!(H == 16 || H == 32 || H == 64) || F < 1 || F > H || L < 1 || L > MAXL || C < 1 || C > 4096) return 0;
   if (max_n < 0 || max_v < 0 || max_ell < 0 || max_evv < 0) return 0;
-  if (fwd_lds_bytes(H, C, max_n, max_v, max_ell, max_evv, 0) > 160 * 1024) return 0;
+  if (fwd_lds_bytes(H, C, max_n, max_v, max_ell, max_evv, 0, 0) > 160 * 1024) return 0;
   if (bwd_lds_bytes(H, C, max_n, max_ell) > 160 * 1024) return 0;
   return 1;
 }
@@ -1011,7 +1133,8 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
                       int head_act, float slope, const void* const* layer_params_host /* L x 9 */,
                       const float* W1, const float* b1, const float* W2, const float* b2, int max_n, int max_v,
                       int max_ell, int max_evv, int compute_virtual, float* acts, float* pooled, float* z,
-                      float* pred, float* xv_out, int32_t* flag, void* stream_) {
+                      float* pred, float* xv_out, int32_t* csr_rowptr_t, int32_t* csr_col_t, float* dinv_out,
+                      int32_t* flag, void* stream_) {
   if (B < 0 || N < 0 || V < 0) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, max_v, max_ell, max_evv)) return HSCN_E_UNSUPPORTED;
@@ -1036,9 +1159,12 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
   }
   A.W1 = W1; A.b1 = b1; A.W2 = W2; A.b2 = b2;
   A.acts = acts; A.pooled = pooled; A.z = z; A.pred = pred; A.xv_out = xv_out; A.flag = flag;
+  if ((csr_rowptr_t == nullptr) != (csr_col_t == nullptr) || (csr_rowptr_t == nullptr) != (dinv_out == nullptr))
+    return HSCN_E_BADARG;
+  A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_out = dinv_out;
   A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_v = max_v; A.max_ell = max_ell; A.max_evv = max_evv;
-  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0;
+  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0;
   hipStream_t st = hscn_stream(stream_);
   switch (H) {
     case 16: return launch_fwd<16>(A, B, st);
@@ -1051,13 +1177,14 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
 int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                       const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
                       const void* const* W_ll_host /* L */, const float* W1, const float* W2, const float* acts,
-                      const float* pooled, const float* z, const float* g_pred, int max_n, int max_ell,
+                      const float* pooled, const float* z, const float* g_pred, const int32_t* csr_rowptr_t,
+                      const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
                       float* partials /*[B][P]*/, float* grads /*[P]*/, int32_t* flag, void* stream_) {
   if (B < 0 || N < 0) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, 0, max_ell, 0)) return HSCN_E_UNSUPPORTED;
   if (!x_local || !lptr || !eptr_ll || !W_ll_host || !W1 || !W2 || !acts || !pooled || !z || !g_pred ||
-      !partials || !grads || (E_ll > 0 && !ei_ll))
+      !partials || !grads || !csr_rowptr_t || !dinv || (E_ll > 0 && !csr_col_t))
     return HSCN_E_BADARG;
   BwdArgs A;
   A.x_local = x_local; A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
@@ -1067,6 +1194,7 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
     A.W_ll[l] = (const float*)W_ll_host[l];
   }
   A.W1 = W1; A.W2 = W2; A.acts = acts; A.pooled = pooled; A.z = z; A.g_pred = g_pred;
+  A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_in = dinv;
   A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_ell = max_ell; A.P = (int)hscn_resident_param_count(F, H, L, C);
   hipStream_t st = hscn_stream(stream_);

@@ -62,9 +62,9 @@ _SIGNATURES = {
     "hscn_resident_param_count": (c_int64, [c_int] * 4),
     "hscn_resident_fwd": (c_int, [P, P, P, c_int64, P, c_int64, P, c_int64, P, P, P, P, P, c_int64, c_int64,
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P, P, P, c_int,
-                                  c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+                                  c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_bwd": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
-                                  P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
+                                  P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
 }
 
 

@@ -106,14 +106,21 @@ class HSCNResidentFn(Function):
         z = torch.empty(B, H, dtype=torch.float32, device=dev)
         pred = torch.empty(B, C, dtype=torch.float32, device=dev)
         xv_out = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev) if (compute_virtual and keep_virtual) else None
+        # source-keyed CSR + degree norm: built in LDS by the forward launch, reused by the backward launch
+        need_bwd = any(p.requires_grad for p in params)
+        E_ll = ei_ll.size(1)
+        csr_rp = torch.empty(N + B, dtype=torch.int32, device=dev) if need_bwd else None
+        csr_col = torch.empty(max(E_ll, 1), dtype=torch.int32, device=dev) if need_bwd else None
+        dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev) if need_bwd else None
         table = _ptr_table(params[: 9 * L])
         call("hscn_resident_fwd", ptr(x_local), ptr(x_virtual), ptr(ei_ll), ei_ll.size(1), ptr(ei_vv),
              ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll),
              ptr(meta.eptr_vv), ptr(meta.eptr_lv), N, V, B, F, H, L, C, head_act, float(slope), table,
              ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_v, meta.max_ell, meta.max_evv,
-             int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(meta.flag),
-             stream())
+             int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(csr_rp),
+             ptr(csr_col), ptr(dinv), ptr(meta.flag), stream())
         ctx.meta, ctx.head_act, ctx.dims = meta, head_act, (N, F, H, L, C, B)
+        ctx.csr = (csr_rp, csr_col, dinv)
         ctx.save_for_backward(x_local, ei_ll, acts, pooled, z, W1, W2, *[params[9 * l] for l in range(L)])
         ctx.mark_non_differentiable(*([xv_out] if xv_out is not None else []))
         ctx.set_materialize_grads(False)
@@ -136,7 +143,8 @@ class HSCNResidentFn(Function):
         table = _ptr_table(list(W_ll))
         call("hscn_resident_bwd", ptr(x_local), ptr(ei_ll), ei_ll.size(1), ptr(meta.lptr), ptr(meta.eptr_ll), N, B,
              F, H, L, C, ctx.head_act, table, ptr(W1), ptr(W2), ptr(acts), ptr(pooled), ptr(z), ptr(g_pred),
-             meta.max_n, meta.max_ell, ptr(partials), ptr(grads), ptr(meta.flag), stream())
+             ptr(ctx.csr[0]), ptr(ctx.csr[1]), ptr(ctx.csr[2]), meta.max_n, meta.max_ell, ptr(partials), ptr(grads),
+             ptr(meta.flag), stream())
         out: List[Optional[Tensor]] = [None] * (7 + 9 * L + 4)
         off = 0
         for l in range(L):

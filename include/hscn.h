@@ -263,6 +263,9 @@ int hscn_scale(const float* g /*[1]*/, const float* x, float* y, int64_t count, 
  *   xv_out [V,H] or NULL: final virtual features (never used by the prediction
  *     in the reference architecture; exposed so the virtual branch is testable)
  *   compute_virtual 0 skips the virtual branch (it cannot change pred)
+ *   csr_rowptr_t / csr_col_t / dinv: the local->local CSR keyed by SOURCE (graph g: rowptr at
+ *     lptr[g]+g, columns at eptr_ll[g]) and in-degree^-1/2, built in LDS by the forward launch and
+ *     handed to the backward launch, which does not rebuild them (all three NULL = do not export)
  *   flag: bit 2 = an edge left its graph's node range, bit 4 = a graph exceeds
  *     max_n / max_v / max_ell / max_evv (the LDS budget the launch was sized for)
  * hscn_resident_bwd returns dL/d{W_ll, b_ll per layer, W1, b1, W2, b2} packed in
@@ -278,11 +281,13 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
                       int head_act, float slope, const void* const* layer_params_host,
                       const float* W1, const float* b1, const float* W2, const float* b2, int max_n, int max_v,
                       int max_ell, int max_evv, int compute_virtual, float* acts, float* pooled, float* z,
-                      float* pred, float* xv_out, int32_t* flag, void* stream);
+                      float* pred, float* xv_out, int32_t* csr_rowptr_t /*[N+B]*/, int32_t* csr_col_t /*[E_ll]*/,
+                      float* dinv /*[N]*/, int32_t* flag, void* stream);
 int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                       const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
                       const void* const* W_ll_host, const float* W1, const float* W2, const float* acts,
-                      const float* pooled, const float* z, const float* g_pred, int max_n, int max_ell,
+                      const float* pooled, const float* z, const float* g_pred, const int32_t* csr_rowptr_t,
+                      const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
                       float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
 
 /* ------------------------------------------------------------------------- *

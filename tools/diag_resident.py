@@ -42,7 +42,7 @@ def main():
     sizes = np.diff(hb_host["local"].ptr.numpy())
     total = st[:, 63] - st[:, 0]
     order = np.argsort(total)
-    names = {0: "start", 1: "prologue loads", 2: "ll | vv csr", 3: "lv csr"}
+    names = {0: "start", 1: "prologue loads", 2: "4 CSRs side by side", 3: "barrier + export"}
     for l in range(3):
         names.update({4 + 4 * l: f"L{l} begin", 5 + 4 * l: f"L{l} transforms (A: ll | B: lv,vv)",
                       6 + 4 * l: f"L{l} reduce (A: ll | B: gat+vv)"})
