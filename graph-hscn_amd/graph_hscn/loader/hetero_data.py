@@ -9,7 +9,7 @@ remapped cluster (v+1) mod U (:52-59), vv edges are {(i -> j): i + j <= U-1}
 The reference's per-node Python loop with ``.tolist()`` round trips is replaced
 by one vectorised pass per graph (host integer bookkeeping, as in the
 reference, which also runs this stage on the host); results are bit-identical
-(tests/test_hetero_transform.py).
+(tests/test_host_logic.py); `hetero_batch_on_device` does the transform and the collate on the GPU (tests/test_gpu_hetero_device.py).
 """
 from __future__ import annotations
 
@@ -85,3 +85,72 @@ def hetero_loaders(data_cfg, hetero_dataset: List[HeteroData], split_idx: Dict[s
         DataLoader(parts[1], data_cfg.batch_size, shuffle=False, num_workers=data_cfg.num_workers),
         DataLoader(parts[2], data_cfg.batch_size, shuffle=False, num_workers=data_cfg.num_workers),
     ]
+
+
+def hetero_batch_on_device(batch, clusters: torch.Tensor, num_clusters: int):
+    """Transform + collate in one step ON THE DEVICE: a block-diagonal ``Batch`` of raw graphs (on
+    'cuda') and the raw cluster id of every node (int64 ``[N]``, e.g. the argmax of stage A, still on
+    the device) -> the ``HeteroBatch`` the reference would obtain by running
+    ``generate_hetero_data`` per graph (hetero_data.py:42-87) and collating.  Bit-identical to the host
+    path (``hetero_from_clusters`` + ``HeteroBatch.from_data_list``); one host read of the two
+    totals (V, E_vv) sizes the outputs."""
+    from .. import _hip
+    from ..data import HeteroBatch
+    dev = batch.x.device
+    if dev.type != "cuda":
+        raise RuntimeError("hetero_batch_on_device works on device-resident batches")
+    K = int(num_clusters)
+    N, F = batch.x.shape
+    B = int(batch.num_graphs)
+    x = batch.x.contiguous()
+    if x.dtype not in (torch.int64, torch.float32):
+        x = x.float()
+    nptr = batch.ptr32 if ("ptr32" in batch and batch.ptr32.device == dev) else batch.ptr.to(dev).to(torch.int32)
+    clusters = clusters.to(torch.int64).contiguous()
+    U = torch.empty(B, dtype=torch.int32, device=dev)
+    lvl = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    means = torch.empty(B, K, F, dtype=torch.float32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _hip.call("hscn_build_hetero_count", _hip.ptr(x), int(x.dtype == torch.int64), _hip.ptr(clusters), _hip.ptr(nptr),
+              B, F, K, _hip.ptr(U), _hip.ptr(lvl), _hip.ptr(means), _hip.ptr(flag), _hip.stream())
+    U64 = U.to(torch.int64)
+    vptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    evptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    vptr[1:] = torch.cumsum(U64, 0)
+    evptr[1:] = torch.cumsum(U64 * (U64 + 1) // 2, 0)
+    tot = torch.stack([vptr[-1], evptr[-1], flag[0].to(torch.int64), U64.max()]).cpu()      # the one host read
+    V, Evv, bad, maxU = (int(t) for t in tot)
+    if bad:
+        raise IndexError("cluster ids must lie in [0, num_clusters)")
+    vx = torch.empty(V, F, dtype=torch.float32, device=dev)
+    ei_lv = torch.empty(2, N, dtype=torch.int64, device=dev)
+    ei_vv = torch.empty(2, Evv, dtype=torch.int64, device=dev)
+    _hip.call("hscn_build_hetero_emit", _hip.ptr(U), _hip.ptr(vptr), _hip.ptr(evptr), _hip.ptr(nptr), _hip.ptr(lvl),
+              _hip.ptr(means), B, F, K, N, Evv, _hip.ptr(vx), _hip.ptr(ei_lv), _hip.ptr(ei_vv), _hip.stream())
+    hb = HeteroBatch()
+    hb.num_graphs = B
+    loc, vir = hb["local"], hb["virtual"]
+    loc.x = batch.x.float()
+    if "y" in batch and batch.y is not None:
+        loc.y = batch.y
+    loc.batch = batch.batch if batch.batch.device == dev else batch.batch.to(dev)
+    loc.ptr = batch.ptr if batch.ptr.device == dev else batch.ptr.to(dev)
+    loc.ptr32 = nptr
+    loc.max_nodes = int(batch.max_nodes) if "max_nodes" in batch else int((loc.ptr[1:] - loc.ptr[:-1]).max())
+    loc.num_nodes = N
+    vir.x = vx
+    vir.ptr = vptr
+    vir.ptr32 = vptr.to(torch.int32)
+    vir.batch = torch.repeat_interleave(torch.arange(B, device=dev), U64)
+    vir.max_nodes = maxU
+    vir.num_nodes = V
+    hb[LL].edge_index = batch.edge_index
+    hb[LL].ptr32 = batch.eptr32 if batch.eptr32.device == dev else batch.eptr32.to(dev)
+    hb[LL].max_edges = int(batch.max_edges)
+    hb[VV].edge_index = ei_vv
+    hb[VV].ptr32 = evptr.to(torch.int32)
+    hb[VV].max_edges = maxU * (maxU + 1) // 2
+    hb[LV].edge_index = ei_lv
+    hb[LV].ptr32 = nptr
+    hb[LV].max_edges = loc.max_nodes
+    return hb
