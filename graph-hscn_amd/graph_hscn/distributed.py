@@ -61,6 +61,7 @@ class FlatGradReducer:
         self.group = process_group
         self._flat: Optional[torch.Tensor] = None
         self._mask: Optional[List[bool]] = None
+        self.last_path: Optional[str] = None
 
     @property
     def world_size(self) -> int:
@@ -82,32 +83,65 @@ class FlatGradReducer:
             raise RuntimeError("set of parameters with gradients changed between steps")
         return mask
 
+    def _aliased_flat(self, grads: List[torch.Tensor]) -> Optional[torch.Tensor]:
+        """If every gradient is a contiguous slice of ONE buffer that they tile without gaps (what the
+        graph-resident backward produces: all parameter gradients come out of a single ``grads[P]``
+        tensor), return that buffer as a flat view: the all-reduce then needs no packing at all."""
+        g0 = grads[0]
+        base = g0.untyped_storage().data_ptr()
+        spans = []
+        for g in grads:
+            if g.untyped_storage().data_ptr() != base or not g.is_contiguous() or g.dtype != torch.float32:
+                return None
+            spans.append((g.storage_offset(), g.numel()))
+        spans.sort()
+        end = spans[0][0]
+        for off, n in spans:
+            if off != end:
+                return None
+            end = off + n
+        flat = torch.empty(0, dtype=torch.float32, device=g0.device)
+        flat.set_(g0.untyped_storage(), spans[0][0], (end - spans[0][0],))
+        return flat
+
     def reduce(self, local_weight: float = 1.0, total_weight: Optional[float] = None) -> None:
         mask = self._layout()
         grads = [p.grad for p, m in zip(self.params, mask) if m]
         if not grads:
             return
+        ws = self.world_size
+        if ws <= 1:
+            return
+        if total_weight is not None:
+            scale = float(local_weight) / float(total_weight)      # known up front: no host sync
+        else:
+            w = torch.tensor([float(local_weight)], dtype=torch.float64, device=grads[0].device)
+            dist.all_reduce(w, group=self.group)
+            scale = float(local_weight) / float(w.item())
+        flat = self._aliased_flat(grads)
+        self.last_path = "aliased" if flat is not None else "packed"
+        if flat is not None:
+            # one collective on the gradients where they already live
+            if abs(scale * ws - 1.0) < 1e-12 and dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # equal shards: RCCL averages
+            else:
+                flat.mul_(scale)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
             self._flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
         flat = self._flat
-        ws = self.world_size
-        if ws > 1 and total_weight is not None:
-            scale = float(local_weight) / float(total_weight)      # known up front: no host sync
-        elif ws > 1:
-            w = torch.tensor([float(local_weight)], dtype=torch.float64, device=flat.device)
-            dist.all_reduce(w, group=self.group)
-            scale = float(local_weight) / float(w.item())
-        else:
-            scale = 1.0
-        off = 0
-        for g in grads:
-            flat[off: off + g.numel()].copy_(g.reshape(-1))
-            off += g.numel()
-        if ws > 1:
-            flat.mul_(scale)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
-        for g in grads:
-            g.copy_(flat[off: off + g.numel()].view_as(g))
-            off += g.numel()
+        torch.cat([g.reshape(-1) for g in grads], out=flat)           # one packing launch
+        flat.mul_(scale)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        torch._foreach_copy_(grads, [flat[o: o + g.numel()].view_as(g) for g, o in
+                                     zip(grads, _offsets(grads))])     # one unpacking launch
+
+
+def _offsets(grads: List[torch.Tensor]) -> List[int]:
+    out, o = [], 0
+    for g in grads:
+        out.append(o)
+        o += g.numel()
+    return out

@@ -59,7 +59,18 @@ def _worker(rank, world, port, q):
     _grads(model, mine)
     red.reduce(len(mine), len(hs))            # total weight given: no host sync
     g2 = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
-    q.put((rank, g1.numpy(), g2.numpy(), [p.grad is None for p in model.parameters()]))
+    # gradients that already tile one flat buffer (what the graph-resident backward returns) are reduced in place
+    _grads(model, mine)
+    with_grad = [p for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([p.grad.reshape(-1) for p in with_grad]).clone()
+    o = 0
+    for p in with_grad:
+        p.grad = flat[o:o + p.numel()].view_as(p)
+        o += p.numel()
+    red.reduce(len(mine), len(hs))
+    assert red.last_path == "aliased"
+    g3 = torch.cat([p.grad.reshape(-1) for p in with_grad])
+    q.put((rank, g1.numpy(), g2.numpy(), [p.grad is None for p in model.parameters()], g3.numpy()))
     dist.destroy_process_group()
 
 
@@ -83,10 +94,11 @@ def test_two_rank_gradients_equal_single_process_gradients():
     _grads(model, hs)
     want = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]).numpy()
     none_mask = [p.grad is None for p in model.parameters()]
-    for rank, g1, g2, mask in res:
+    for rank, g1, g2, mask, g3 in res:
         assert mask == none_mask                      # virtual-branch params stay grad-less on every rank
         np.testing.assert_allclose(g1, want, rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(g2, want, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(g3, want, rtol=1e-5, atol=1e-7)
     np.testing.assert_array_equal(res[0][1], res[1][1])  # ranks hold identical reduced gradients
 
 

@@ -139,3 +139,20 @@ def test_auto_engine_falls_back_to_layered_for_foreign_batches():
     out = pm({k: v.to(DEV) for k, v in ob["x_dict"].items()},
              {k: v.to(DEV) for k, v in ob["edge_index_dict"].items()}, fb)
     assert pm.last_engine == "layered" and out.shape == (3, 10)
+
+
+def test_resident_gradients_tile_one_flat_buffer_for_the_allreduce():
+    """The data-parallel reducer all-reduces the backward's single grads[P] buffer in place."""
+    from graph_hscn.distributed import FlatGradReducer
+    _, pb = _batches("peptides_func", 4, 8, seed=2)
+    _, pm = _models(9, 16, 10, 3)
+    pm.engine = "resident"
+    pbd = pb.to(DEV)
+    pm(pbd.x_dict, pbd.edge_index_dict, pbd).sum().backward()
+    red = FlatGradReducer(pm)
+    grads = [p.grad for p in pm.parameters() if p.grad is not None]
+    flat = red._aliased_flat(grads)
+    assert flat is not None and flat.numel() == sum(g.numel() for g in grads) == 1146
+    before = [g.clone() for g in grads]
+    flat.mul_(2.0)
+    assert all(torch.equal(g, 2 * b) for g, b in zip(grads, before))
