@@ -182,7 +182,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("HSCN_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -203,7 +207,9 @@ def main():
     torch.manual_seed(0)  # identical replicas
     model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], F, args.hidden, C, args.layers).to(dev)
     model.engine = args.engine
-    reducer = FlatGradReducer(model) if world > 1 else None
+    reducer = FlatGradReducer(model) if (world > 1 or force_dist) else None
+    if reducer is not None and force_dist:
+        reducer.__class__ = type("ForcedReducer", (FlatGradReducer,), {"world_size": property(lambda self: 2)})
     x_dict, ei_dict = hb.x_dict, hb.edge_index_dict
     root_grad = torch.ones((), dtype=torch.float32, device=dev)   # = loss.backward()'s implicit ones_like(loss)
 
@@ -245,7 +251,7 @@ def main():
         step = step_eager
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -431,7 +437,7 @@ def main():
         if cpu:
             out["vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
