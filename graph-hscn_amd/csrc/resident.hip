@@ -280,15 +280,15 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
 }
 
 template <int H, int RT>
-__global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
+__device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int OPT = Blk<H>::OPT;
   constexpr int NW = RT / 64;
   constexpr int WSZ = 4 * H * H + 5 * H;
-  const int g = blockIdx.x;
   const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
-  const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
+  const bool vonly = A.compute_virtual == 2;  // virtual branch only: the local activations come from `acts`
+  const int e0 = A.eptr_ll[g], ne = vonly ? 0 : A.eptr_ll[g + 1] - e0;
   const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
   const int el0 = A.eptr_lv[g], nel = A.eptr_lv[g + 1] - el0;
   if ((n > A.max_n) | (nv > A.max_v) | (ne > A.max_ell) | (nev > A.max_evv) | (nel > A.max_n) | (n < 0) | (nv < 0)) {
@@ -309,7 +309,9 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
 
   // wave groups: with the virtual branch on, the upper half of the waves works on it
   const int wave = threadIdx.x >> 6;
-  const int NA = cv ? NW / 2 : NW;  // structure build always splits when the virtual branch is on
+  // structure build always splits when the virtual branch is on; a virtual-only launch keeps a
+  // quarter of the waves for streaming the next layer's local activations in
+  const int NA = cv ? (vonly ? (NW >= 4 ? NW / 4 : 1) : NW / 2) : NW;
   const bool inB = wave >= NA;
   const Grp ALL{(int)threadIdx.x, RT, wave, NW};
   const Grp GA{(int)threadIdx.x, NA * 64, wave, NA};
@@ -360,15 +362,15 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
 #pragma unroll
   for (int i = 0; i < HPT; ++i) {
     const int idx = threadIdx.x + i * RT;
-    hw1r[i] = A.W1[idx < H * H ? idx : 0];
+    hw1r[i] = vonly ? 0.f : A.W1[idx < H * H ? idx : 0];
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = threadIdx.x + i * RT;
-    hw2r[i] = A.W2[idx < A.C * H ? idx : 0];
+    hw2r[i] = vonly ? 0.f : A.W2[idx < A.C * H ? idx : 0];
   }
-  hb1 = A.b1[threadIdx.x < H ? threadIdx.x : 0];
-  hb2 = A.b2[(int)threadIdx.x < A.C ? threadIdx.x : 0];
+  hb1 = vonly ? 0.f : A.b1[threadIdx.x < H ? threadIdx.x : 0];
+  hb2 = vonly ? 0.f : A.b2[(int)threadIdx.x < A.C ? threadIdx.x : 0];
   (void)hw0; (void)hw1;
   int kll[EPT], oll[EPT], klv[EPT], olv[EPT], kvv[EPT], ovv[EPT];
 #pragma unroll
@@ -453,8 +455,11 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
     const int idx = threadIdx.x + i * RT;
     if (idx < A.C * H) headw[H * H + H + idx] = hw2r[i];
   }
-  for (int idx = threadIdx.x + 2 * RT; idx < A.C * H; idx += RT) headw[H * H + H + idx] = A.W2[idx];
-  for (int idx = threadIdx.x; idx < A.C; idx += RT) headw[H * H + H + A.C * H + idx] = idx == (int)threadIdx.x ? hb2 : A.b2[idx];
+  if (!vonly) {
+    for (int idx = threadIdx.x + 2 * RT; idx < A.C * H; idx += RT) headw[H * H + H + idx] = A.W2[idx];
+    for (int idx = threadIdx.x; idx < A.C; idx += RT)
+      headw[H * H + H + A.C * H + idx] = idx == (int)threadIdx.x ? hb2 : A.b2[idx];
+  }
   ws.store(wt);
   __syncthreads();
   STAMP(1);
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   {
     int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
     const int w_t = !A.exp ? 0 : (cv ? (NW * 3) / 8 : NW - NW / 2);          // 6 of 16 waves (1 of 4)
-    const int w_ll = cv ? (A.exp ? (NW * 3) / 8 : NW / 2) : NW - w_t;
+    const int w_ll = vonly ? 0 : (cv ? (A.exp ? (NW * 3) / 8 : NW / 2) : NW - w_t);
     const int w_vv = cv ? (NW - w_ll - w_t) / 2 : 0;
     const int w_lv = cv ? NW - w_ll - w_t - w_vv : 0;
     const int wa = wave < w_ll ? 0 : (wave < w_ll + w_t ? 1 : (wave < w_ll + w_t + w_vv ? 2 : 3));
@@ -511,6 +516,13 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
     if (more && DB) ws.fetch(A.layer[l + 1], cv, H);
     STAMP(4 + 4 * l);
     auto transforms_ll = [&](const Grp& G_) { lin_blk<H, OPT>(xa, W, bh, n, nullptr, nullptr, G_); };
+    // virtual-only launch: layer l+1 reads the local activations the local launch stored
+    auto load_next_local = [&](const Grp& G_) {
+      if (!more) return;
+      const float4* src = reinterpret_cast<const float4*>(A.acts + ((size_t)l * A.N + n0) * H);
+      float4* dst = reinterpret_cast<float4*>(xa);
+      for (int i = G_.t; i < n * (H / 4); i += G_.nt) dst[i] = src[i];
+    };
     auto transforms_virtual = [&](const Grp& G_) {
       lin_blk<H, OPT>(xa, W + H * H, bs, n, att_s, a_s, G_);               // lv source side (+ a_src)
       lin_blk<H, OPT>(xva, W + 2 * H * H, nullptr, nv, att_d, a_d, G_);    // lv target side only through a_dst
@@ -587,11 +599,11 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
     };
     if (cv && A.spec) {
       // two barriers per layer: the ll path (group A) and the virtual branch (group B) side by side
-      if (!inB) transforms_ll(GA); else transforms_virtual(GB);
+      if (inB) transforms_virtual(GB); else if (!vonly) transforms_ll(GA);
       if (more && DB) ws.store(Wn);
       __syncthreads();
       STAMP(5 + 4 * l);
-      if (!inB) reduce_ll(GA); else reduce_virtual(GB);
+      if (inB) reduce_virtual(GB); else if (vonly) load_next_local(GA); else reduce_ll(GA);
       __syncthreads();
     } else {
       // one n x H transform buffer: the virtual branch first, then the ll path
@@ -601,11 +613,11 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
         reduce_virtual(ALL);
         __syncthreads();
       }
-      transforms_ll(ALL);
+      if (!vonly) transforms_ll(ALL);
       if (more && DB) ws.store(Wn);
       __syncthreads();
       STAMP(5 + 4 * l);
-      reduce_ll(ALL);
+      if (vonly) load_next_local(ALL); else reduce_ll(ALL);
       __syncthreads();
     }
     if (more && !DB) {  // single weight buffer: everybody is done with it now
@@ -622,6 +634,7 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   if (cv && A.xv_out)
     for (int idx = threadIdx.x; idx < nv * H; idx += RT) A.xv_out[(size_t)v0 * H + idx] = xva[idx];
 
+  if (vonly) return;  // the prediction belongs to the local launch
   // ---- global_mean_pool: every wave sums a strided row set, wave 0 folds in wave order -----------
   {
     constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
@@ -693,6 +706,11 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   STAMP(63);
 }
 
+template <int H, int RT>
+__global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
+  hscn_fwd_body<H, RT>(A, blockIdx.x);
+}
+
 // =============================== backward =====================================================
 struct BwdLayout {
   size_t G, GH, X, dinv, vec, red, wl, headw, rowptr_t, col_t, total;
@@ -716,12 +734,11 @@ __host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max
 }
 
 template <int H, int RT>
-__global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
+__device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int OPT = Blk<H>::OPT;
   constexpr int NW = RT / 64;
-  const int g = blockIdx.x;
-  const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
+    const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
   float* part = A.partials + (size_t)g * A.P;
   if (n > A.max_n || ne > A.max_ell || n < 0) {
@@ -996,6 +1013,20 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
   STAMP(63);
 }
 
+template <int H, int RT>
+__global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
+  hscn_bwd_body<H, RT>(A, blockIdx.x);
+}
+// One launch, two kinds of workgroup: even blocks run the backward of graph g, odd blocks the
+// virtual branch of the same step's forward (a mode-2 job: it depends on the local launch only and
+// nothing depends on it), so the virtual branch fills the CUs a 128-graph batch leaves idle.
+template <int H, int RT>
+__global__ void __launch_bounds__(RT) k_hscn_bwd_virtual(const BwdArgs Ab, const FwdArgs Af) {
+  const int g = blockIdx.x >> 1;
+  if (blockIdx.x & 1) hscn_fwd_body<H, RT>(Af, g);
+  else hscn_bwd_body<H, RT>(Ab, g);
+}
+
 inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int spec, int exp) {
   return fwd_layout(H, C, max_n, max_v, max_ell, max_evv, spec, exp).total * 4;
 }
@@ -1102,6 +1133,94 @@ int launch_bwd(const BwdArgs& A, int64_t B, hipStream_t st) {
   return launch_bwd_rt<H, 1024>(A, B, lds, st);
 }
 
+template <int H, int RT>
+int launch_bwd_virtual_rt(const BwdArgs& Ab, const FwdArgs& Af, int64_t B, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_hscn_bwd_virtual<H, RT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k_hscn_bwd_virtual<H, RT><<<(unsigned)(2 * B), RT, lds, st>>>(Ab, Af);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+template <int H>
+int launch_bwd_virtual(const BwdArgs& Ab, FwdArgs& Af, int64_t B, hipStream_t st) {
+  const size_t lb = bwd_lds_bytes(H, Ab.C, Ab.max_n, Ab.max_ell);
+  size_t lf = 0;
+  bool ok = false;
+  for (int spec = 1; spec >= 0 && !ok; --spec) {
+    Af.spec = spec;
+    Af.exp = 0;
+    lf = fwd_lds_bytes(H, Af.C, Af.max_n, Af.max_v, Af.max_ell, Af.max_evv, spec, 0);
+    ok = lf <= 160 * 1024;
+  }
+  if (!ok || lb > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  const size_t lds = lb > lf ? lb : lf;
+  if (Ab.max_n <= 64) return launch_bwd_virtual_rt<H, 256>(Ab, Af, B, lds, st);
+  return launch_bwd_virtual_rt<H, 1024>(Ab, Af, B, lds, st);
+}
+
+int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, const int64_t* ei_ll, int64_t E_ll,
+                  const int64_t* ei_vv, int64_t E_vv, const int64_t* ei_lv, int64_t E_lv, const int32_t* lptr,
+                  const int32_t* vptr, const int32_t* eptr_ll, const int32_t* eptr_vv, const int32_t* eptr_lv,
+                  int64_t N, int64_t V, int F, int H, int L, int C, int head_act, float slope,
+                  const void* const* layer_params_host, const float* W1, const float* b1, const float* W2,
+                  const float* b2, int max_n, int max_v, int max_ell, int max_evv, int compute_virtual,
+                  float* acts, float* pooled, float* z, float* pred, float* xv_out, int32_t* csr_rowptr_t,
+                  int32_t* csr_col_t, float* dinv_out, int32_t* flag) {
+  if (compute_virtual < 0 || compute_virtual > 2) return HSCN_E_BADARG;
+  const bool vonly = compute_virtual == 2;
+  if (!x_local || !lptr || !vptr || !eptr_ll || !eptr_vv || !eptr_lv || !layer_params_host || !acts)
+    return HSCN_E_BADARG;
+  if (!vonly && (!W1 || !b1 || !W2 || !b2 || !pooled || !z || !pred)) return HSCN_E_BADARG;
+  if (vonly && (!xv_out || csr_rowptr_t || csr_col_t || dinv_out)) return HSCN_E_BADARG;
+  if ((E_ll > 0 && !ei_ll && !vonly) || (compute_virtual && ((E_vv > 0 && !ei_vv) || (E_lv > 0 && !ei_lv) || !x_virtual)))
+    return HSCN_E_BADARG;
+  A.x_local = x_local; A.x_virtual = x_virtual;
+  A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
+  A.vv_src = ei_vv; A.vv_dst = ei_vv ? ei_vv + E_vv : nullptr;
+  A.lv_src = ei_lv; A.lv_dst = ei_lv ? ei_lv + E_lv : nullptr;
+  A.lptr = lptr; A.vptr = vptr; A.eptr_ll = eptr_ll; A.eptr_vv = eptr_vv; A.eptr_lv = eptr_lv;
+  for (int l = 0; l < L; ++l) {
+    const void* const* q = layer_params_host + (size_t)l * 9;
+    for (int k = 0; k < 9; ++k)
+      if (!q[k] && (compute_virtual || k < 2)) return HSCN_E_BADARG;
+    A.layer[l] = LayerP{(const float*)q[0], (const float*)q[1], (const float*)q[2], (const float*)q[3],
+                        (const float*)q[4], (const float*)q[5], (const float*)q[6], (const float*)q[7],
+                        (const float*)q[8]};
+  }
+  A.W1 = W1; A.b1 = b1; A.W2 = W2; A.b2 = b2;
+  A.acts = acts; A.pooled = pooled; A.z = z; A.pred = pred; A.xv_out = xv_out; A.flag = flag;
+  if ((csr_rowptr_t == nullptr) != (csr_col_t == nullptr) || (csr_rowptr_t == nullptr) != (dinv_out == nullptr))
+    return HSCN_E_BADARG;
+  A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_out = dinv_out;
+  A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
+  A.max_n = max_n; A.max_v = max_v; A.max_ell = vonly ? 0 : max_ell; A.max_evv = max_evv;
+  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0;
+  return 0;
+}
+
+int fill_bwd_args(BwdArgs& A, const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                  const int32_t* eptr_ll, int64_t N, int F, int H, int L, int C, int head_act,
+                  const void* const* W_ll_host, const float* W1, const float* W2, const float* acts,
+                  const float* pooled, const float* z, const float* g_pred, const int32_t* csr_rowptr_t,
+                  const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell, float* partials,
+                  float* grads, int32_t* flag) {
+  if (!x_local || !lptr || !eptr_ll || !W_ll_host || !W1 || !W2 || !acts || !pooled || !z || !g_pred ||
+      !partials || !grads || !csr_rowptr_t || !dinv || (E_ll > 0 && !csr_col_t))
+    return HSCN_E_BADARG;
+  A.x_local = x_local; A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
+  A.lptr = lptr; A.eptr_ll = eptr_ll;
+  for (int l = 0; l < L; ++l) {
+    if (!W_ll_host[l]) return HSCN_E_BADARG;
+    A.W_ll[l] = (const float*)W_ll_host[l];
+  }
+  A.W1 = W1; A.W2 = W2; A.acts = acts; A.pooled = pooled; A.z = z; A.g_pred = g_pred;
+  A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_in = dinv;
+  A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
+  A.max_n = max_n; A.max_ell = max_ell; A.P = (int)hscn_resident_param_count(F, H, L, C);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1138,33 +1257,12 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
   if (B < 0 || N < 0 || V < 0) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, max_v, max_ell, max_evv)) return HSCN_E_UNSUPPORTED;
-  if (!x_local || !lptr || !vptr || !eptr_ll || !eptr_vv || !eptr_lv || !layer_params_host || !W1 || !b1 ||
-      !W2 || !b2 || !acts || !pooled || !z || !pred)
-    return HSCN_E_BADARG;
-  if ((E_ll > 0 && !ei_ll) || (compute_virtual && ((E_vv > 0 && !ei_vv) || (E_lv > 0 && !ei_lv) || !x_virtual)))
-    return HSCN_E_BADARG;
   FwdArgs A;
-  A.x_local = x_local; A.x_virtual = x_virtual;
-  A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
-  A.vv_src = ei_vv; A.vv_dst = ei_vv ? ei_vv + E_vv : nullptr;
-  A.lv_src = ei_lv; A.lv_dst = ei_lv ? ei_lv + E_lv : nullptr;
-  A.lptr = lptr; A.vptr = vptr; A.eptr_ll = eptr_ll; A.eptr_vv = eptr_vv; A.eptr_lv = eptr_lv;
-  for (int l = 0; l < L; ++l) {
-    const void* const* q = layer_params_host + (size_t)l * 9;
-    for (int k = 0; k < 9; ++k)
-      if (!q[k] && (compute_virtual || k < 2)) return HSCN_E_BADARG;
-    A.layer[l] = LayerP{(const float*)q[0], (const float*)q[1], (const float*)q[2], (const float*)q[3],
-                        (const float*)q[4], (const float*)q[5], (const float*)q[6], (const float*)q[7],
-                        (const float*)q[8]};
-  }
-  A.W1 = W1; A.b1 = b1; A.W2 = W2; A.b2 = b2;
-  A.acts = acts; A.pooled = pooled; A.z = z; A.pred = pred; A.xv_out = xv_out; A.flag = flag;
-  if ((csr_rowptr_t == nullptr) != (csr_col_t == nullptr) || (csr_rowptr_t == nullptr) != (dinv_out == nullptr))
-    return HSCN_E_BADARG;
-  A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_out = dinv_out;
-  A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
-  A.max_n = max_n; A.max_v = max_v; A.max_ell = max_ell; A.max_evv = max_evv;
-  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0;
+  if (int rc = fill_fwd_args(A, x_local, x_virtual, ei_ll, E_ll, ei_vv, E_vv, ei_lv, E_lv, lptr, vptr, eptr_ll,
+                             eptr_vv, eptr_lv, N, V, F, H, L, C, head_act, slope, layer_params_host, W1, b1, W2,
+                             b2, max_n, max_v, max_ell, max_evv, compute_virtual, acts, pooled, z, pred, xv_out,
+                             csr_rowptr_t, csr_col_t, dinv_out, flag))
+    return rc;
   hipStream_t st = hscn_stream(stream_);
   switch (H) {
     case 16: return launch_fwd<16>(A, B, st);
@@ -1183,20 +1281,11 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
   if (B < 0 || N < 0) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, 0, max_ell, 0)) return HSCN_E_UNSUPPORTED;
-  if (!x_local || !lptr || !eptr_ll || !W_ll_host || !W1 || !W2 || !acts || !pooled || !z || !g_pred ||
-      !partials || !grads || !csr_rowptr_t || !dinv || (E_ll > 0 && !csr_col_t))
-    return HSCN_E_BADARG;
   BwdArgs A;
-  A.x_local = x_local; A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
-  A.lptr = lptr; A.eptr_ll = eptr_ll;
-  for (int l = 0; l < L; ++l) {
-    if (!W_ll_host[l]) return HSCN_E_BADARG;
-    A.W_ll[l] = (const float*)W_ll_host[l];
-  }
-  A.W1 = W1; A.W2 = W2; A.acts = acts; A.pooled = pooled; A.z = z; A.g_pred = g_pred;
-  A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_in = dinv;
-  A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
-  A.max_n = max_n; A.max_ell = max_ell; A.P = (int)hscn_resident_param_count(F, H, L, C);
+  if (int rc0 = fill_bwd_args(A, x_local, ei_ll, E_ll, lptr, eptr_ll, N, F, H, L, C, head_act, W_ll_host, W1, W2,
+                              acts, pooled, z, g_pred, csr_rowptr_t, csr_col_t, dinv, max_n, max_ell, partials,
+                              grads, flag))
+    return rc0;
   hipStream_t st = hscn_stream(stream_);
   int rc = HSCN_E_UNSUPPORTED;
   switch (H) {
@@ -1206,6 +1295,41 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
   }
   if (rc) return rc;
   k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                                   const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
+                                   int head_act, const void* const* W_ll_host, const float* W1, const float* W2,
+                                   const float* acts, const float* pooled, const float* z, const float* g_pred,
+                                   const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv,
+                                   int max_n, int max_ell, float* partials, float* grads, int32_t* flag,
+                                   const hscn_virtual_job* job, void* stream_) {
+  if (B < 0 || N < 0 || !job) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (!hscn_resident_supported(F, H, L, C, max_n, job->max_v, max_ell, job->max_evv)) return HSCN_E_UNSUPPORTED;
+  BwdArgs Ab;
+  if (int rc0 = fill_bwd_args(Ab, x_local, ei_ll, E_ll, lptr, eptr_ll, N, F, H, L, C, head_act, W_ll_host, W1,
+                              W2, acts, pooled, z, g_pred, csr_rowptr_t, csr_col_t, dinv, max_n, max_ell,
+                              partials, grads, flag))
+    return rc0;
+  FwdArgs Af;
+  if (int rc1 = fill_fwd_args(Af, x_local, job->x_virtual, nullptr, 0, job->ei_vv, job->E_vv, job->ei_lv,
+                              job->E_lv, lptr, job->vptr, eptr_ll, job->eptr_vv, job->eptr_lv, N, job->V, F, H, L,
+                              C, head_act, job->slope, job->layer_params_host, nullptr, nullptr, nullptr, nullptr,
+                              max_n, job->max_v, max_ell, job->max_evv, 2, const_cast<float*>(acts), nullptr,
+                              nullptr, nullptr, job->xv_out, nullptr, nullptr, nullptr, flag))
+    return rc1;
+  hipStream_t st = hscn_stream(stream_);
+  int rc = HSCN_E_UNSUPPORTED;
+  switch (H) {
+    case 16: rc = launch_bwd_virtual<16>(Ab, Af, B, st); break;
+    case 32: rc = launch_bwd_virtual<32>(Ab, Af, B, st); break;
+    case 64: rc = launch_bwd_virtual<64>(Ab, Af, B, st); break;
+  }
+  if (rc) return rc;
+  k_param_reduce<<<hscn_blocks(Ab.P, 32), 256, 0, st>>>(partials, grads, (int)B, Ab.P);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -83,14 +83,34 @@ def _ptr_table(ts: List[Optional[Tensor]]):
     return arr
 
 
+class _VirtualJob(ctypes.Structure):
+    """include/hscn.h: hscn_virtual_job."""
+    _fields_ = [("x_virtual", ctypes.c_void_p), ("ei_vv", ctypes.c_void_p), ("E_vv", ctypes.c_int64),
+                ("ei_lv", ctypes.c_void_p), ("E_lv", ctypes.c_int64), ("vptr", ctypes.c_void_p),
+                ("eptr_vv", ctypes.c_void_p), ("eptr_lv", ctypes.c_void_p),
+                ("layer_params_host", ctypes.c_void_p), ("xv_out", ctypes.c_void_p), ("V", ctypes.c_int64),
+                ("max_v", ctypes.c_int32), ("max_evv", ctypes.c_int32), ("slope", ctypes.c_float)]
+
+
+# final virtual features of the last step whose virtual branch rode on the backward launch (tests)
+last_deferred_virtual: Optional[Tensor] = None
+
+
 class HSCNResidentFn(Function):
     """inputs: x_local, x_virtual, ei_ll, ei_vv, ei_lv, meta, cfg, then parameters in
     the order  [W_ll, b_ll, W_vv, b_vv, W_src, W_dst, att_src, att_dst, b_gat] x L,
-    W1, b1, W2, b2.   cfg = (head_act code, slope, compute_virtual, keep_virtual)."""
+    W1, b1, W2, b2.   cfg = (head_act code, slope, compute_virtual, keep_virtual, overlap).
+
+    overlap: the virtual branch never feeds the prediction (reference model/hscn.py:111 pools
+    "local" only).  In a training step it therefore leaves the forward launch (local chain + head
+    only) and rides on the backward launch of the same step as extra workgroups
+    (hscn_resident_bwd_with_virtual), reading the local activations the forward stored.  Without a
+    backward to ride on (no_grad, or keep_virtual wanting the features right away) the one-launch
+    forward computes both branches.  Results are identical either way."""
 
     @staticmethod
     def forward(ctx, x_local, x_virtual, ei_ll, ei_vv, ei_lv, meta: ResidentMeta, cfg, *params):
-        head_act, slope, compute_virtual, keep_virtual = cfg
+        head_act, slope, compute_virtual, keep_virtual, overlap = cfg
         L = (len(params) - 4) // 9
         params = [p.contiguous() for p in params]
         W1, b1, W2, b2 = params[9 * L:]
@@ -101,32 +121,37 @@ class HSCNResidentFn(Function):
         V = x_virtual.shape[0]
         B = meta.num_graphs
         dev = x_local.device
+        need_bwd = any(ctx.needs_input_grad[7:])   # False under no_grad
+        defer = bool(compute_virtual and overlap and V > 0 and need_bwd and not keep_virtual)
         acts = torch.empty(L, N, H, dtype=torch.float32, device=dev)
         pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
         z = torch.empty(B, H, dtype=torch.float32, device=dev)
         pred = torch.empty(B, C, dtype=torch.float32, device=dev)
         xv_out = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev) if (compute_virtual and keep_virtual) else None
         # source-keyed CSR + degree norm: built in LDS by the forward launch, reused by the backward launch
-        need_bwd = any(p.requires_grad for p in params)
         E_ll = ei_ll.size(1)
         csr_rp = torch.empty(N + B, dtype=torch.int32, device=dev) if need_bwd else None
         csr_col = torch.empty(max(E_ll, 1), dtype=torch.int32, device=dev) if need_bwd else None
         dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev) if need_bwd else None
         table = _ptr_table(params[: 9 * L])
+        mode = 0 if (defer or not compute_virtual) else 1
         call("hscn_resident_fwd", ptr(x_local), ptr(x_virtual), ptr(ei_ll), ei_ll.size(1), ptr(ei_vv),
              ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll),
              ptr(meta.eptr_vv), ptr(meta.eptr_lv), N, V, B, F, H, L, C, head_act, float(slope), table,
              ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_v, meta.max_ell, meta.max_evv,
-             int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(csr_rp),
-             ptr(csr_col), ptr(dinv), ptr(meta.flag), stream())
+             mode, ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(csr_rp), ptr(csr_col), ptr(dinv),
+             ptr(meta.flag), stream())
+        # what the backward launch needs to run the virtual branch beside itself
+        ctx.virtual = (x_virtual, ei_vv, ei_lv, params[: 9 * L], table, float(slope)) if defer else None
         ctx.meta, ctx.head_act, ctx.dims = meta, head_act, (N, F, H, L, C, B)
         ctx.csr = (csr_rp, csr_col, dinv)
         ctx.save_for_backward(x_local, ei_ll, acts, pooled, z, W1, W2, *[params[9 * l] for l in range(L)])
-        ctx.mark_non_differentiable(*([xv_out] if xv_out is not None else []))
+        ret_xv = xv_out if keep_virtual else None
+        ctx.mark_non_differentiable(*([ret_xv] if ret_xv is not None else []))
         ctx.set_materialize_grads(False)
-        if xv_out is None:
+        if ret_xv is None:
             return pred
-        return pred, xv_out
+        return pred, ret_xv
 
     @staticmethod
     def backward(ctx, g_pred, *_):
@@ -141,10 +166,23 @@ class HSCNResidentFn(Function):
         grads = torch.empty(P, dtype=torch.float32, device=dev)
         g_pred = g_pred.contiguous()
         table = _ptr_table(list(W_ll))
-        call("hscn_resident_bwd", ptr(x_local), ptr(ei_ll), ei_ll.size(1), ptr(meta.lptr), ptr(meta.eptr_ll), N, B,
-             F, H, L, C, ctx.head_act, table, ptr(W1), ptr(W2), ptr(acts), ptr(pooled), ptr(z), ptr(g_pred),
-             ptr(ctx.csr[0]), ptr(ctx.csr[1]), ptr(ctx.csr[2]), meta.max_n, meta.max_ell, ptr(partials), ptr(grads),
-             ptr(meta.flag), stream())
+        args = (ptr(x_local), ptr(ei_ll), ei_ll.size(1), ptr(meta.lptr), ptr(meta.eptr_ll), N, B,
+                F, H, L, C, ctx.head_act, table, ptr(W1), ptr(W2), ptr(acts), ptr(pooled), ptr(z), ptr(g_pred),
+                ptr(ctx.csr[0]), ptr(ctx.csr[1]), ptr(ctx.csr[2]), meta.max_n, meta.max_ell, ptr(partials),
+                ptr(grads), ptr(meta.flag))
+        if ctx.virtual is not None:
+            global last_deferred_virtual
+            x_virtual, ei_vv, ei_lv, _keep, vtable, slope = ctx.virtual
+            V = x_virtual.shape[0]
+            xv = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev)
+            job = _VirtualJob(ptr(x_virtual), ptr(ei_vv), ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.vptr),
+                              ptr(meta.eptr_vv), ptr(meta.eptr_lv), ctypes.cast(vtable, ctypes.c_void_p), ptr(xv),
+                              V, meta.max_v, meta.max_evv, slope)
+            call("hscn_resident_bwd_with_virtual", *args, ctypes.byref(job), stream())
+            last_deferred_virtual = xv
+            ctx.virtual = None
+        else:
+            call("hscn_resident_bwd", *args, stream())
         out: List[Optional[Tensor]] = [None] * (7 + 9 * L + 4)
         off = 0
         for l in range(L):

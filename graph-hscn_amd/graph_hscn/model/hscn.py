@@ -15,6 +15,8 @@ Differences a caller can observe, all documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -159,6 +161,8 @@ class HSCN(nn.Module):
         self.engine = "auto"
         self.compute_virtual = True   # the reference evaluates the virtual branch although pred ignores it
         self.keep_virtual = False     # expose the final virtual features as self.last_virtual
+        # resident engine: run the virtual branch as its own launch beside loss + backward (engine.py)
+        self.overlap_virtual = os.environ.get("HSCN_OVERLAP_VIRTUAL", "1") != "0"
         self.last_virtual: Optional[Tensor] = None
         self.last_engine: Optional[str] = None
 
@@ -191,7 +195,7 @@ class HSCN(nn.Module):
                        lv.att_src, lv.att_dst, lv.bias]
         params += [self.lin_1.weight, self.lin_1.bias, self.lin_2.weight, self.lin_2.bias]
         slope = self.convs[0].convs["__".join(LV)].negative_slope
-        cfg = (_engine.ACT[act_name], slope, self.compute_virtual, self.keep_virtual)
+        cfg = (_engine.ACT[act_name], slope, self.compute_virtual, self.keep_virtual, self.overlap_virtual)
         out = _engine.HSCNResidentFn.apply(x_dict["local"], x_dict["virtual"], edge_index_dict[LL],
                                            edge_index_dict[VV], edge_index_dict[LV], meta, cfg, *params)
         if isinstance(out, tuple):

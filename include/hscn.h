@@ -280,7 +280,11 @@ int hscn_scale(const float* g /*[1]*/, const float* x, float* y, int64_t count, 
  *   pooled [B,H], z [B,H] (head hidden, post-activation), pred [B,C]
  *   xv_out [V,H] or NULL: final virtual features (never used by the prediction
  *     in the reference architecture; exposed so the virtual branch is testable)
- *   compute_virtual 0 skips the virtual branch (it cannot change pred)
+ *   compute_virtual: 1 = both branches in one launch; 0 = local chain + head only (the virtual
+ *     branch cannot change pred); 2 = virtual branch only: `acts` is an INPUT holding what a mode-0
+ *     launch of the same batch stored, xv_out is required, pooled / z / pred / head weights / CSR
+ *     export are not touched (may be NULL).  Modes 0 + 2 on two streams give the results of mode 1
+ *     with the virtual branch off the critical path of the step.
  *   csr_rowptr_t / csr_col_t / dinv: the local->local CSR keyed by SOURCE (graph g: rowptr at
  *     lptr[g]+g, columns at eptr_ll[g]) and in-degree^-1/2, built in LDS by the forward launch and
  *     handed to the backward launch, which does not rebuild them (all three NULL = do not export)
@@ -307,6 +311,34 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
                       const float* pooled, const float* z, const float* g_pred, const int32_t* csr_rowptr_t,
                       const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
                       float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+
+/* hscn_resident_bwd that also carries the virtual branch of the SAME step's forward: one launch
+ * of 2B workgroups, even ones run the backward of graph g, odd ones what a compute_virtual = 2
+ * hscn_resident_fwd launch would do for graph g (job->xv_out receives the final virtual features).
+ * The forward of the step is then a compute_virtual = 0 launch: the virtual branch (which the
+ * reference evaluates although nothing consumes it, model/hscn.py:106-111) leaves the step's
+ * critical path and runs on the CUs a 128-graph batch does not occupy.  Gradients are identical
+ * to hscn_resident_bwd, xv_out to the one-launch forward.  Fields as in hscn_resident_fwd. */
+typedef struct hscn_virtual_job {
+  const float* x_virtual;              /* [V,F] */
+  const int64_t* ei_vv; int64_t E_vv;  /* [2,E_vv] */
+  const int64_t* ei_lv; int64_t E_lv;  /* [2,E_lv] */
+  const int32_t* vptr;                 /* [B+1] */
+  const int32_t* eptr_vv;              /* [B+1] */
+  const int32_t* eptr_lv;              /* [B+1] */
+  const void* const* layer_params_host;/* L x 9 device pointers (host array) */
+  float* xv_out;                       /* [V,H] */
+  int64_t V;
+  int32_t max_v, max_evv;
+  float slope;                         /* GAT leaky-ReLU slope */
+} hscn_virtual_job;
+int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                                   const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
+                                   int head_act, const void* const* W_ll_host, const float* W1, const float* W2,
+                                   const float* acts, const float* pooled, const float* z, const float* g_pred,
+                                   const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv,
+                                   int max_n, int max_ell, float* partials /*[B,P]*/, float* grads /*[P]*/,
+                                   int32_t* flag, const hscn_virtual_job* job, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * a2/a4/a6  stage A, graph-resident engine: the body of the reference's clustering loop

@@ -156,3 +156,79 @@ def test_resident_gradients_tile_one_flat_buffer_for_the_allreduce():
     before = [g.clone() for g in grads]
     flat.mul_(2.0)
     assert all(torch.equal(g, 2 * b) for g, b in zip(grads, before))
+
+
+@pytest.mark.parametrize("name,B,K,H,L", [("peptides_func", 12, 16, 16, 3), ("pascalvoc_sp", 3, 64, 16, 2),
+                                          ("pcqm_contact", 9, 16, 64, 2), ("peptides_struct", 5, 8, 32, 3)])
+def test_virtual_branch_riding_on_the_backward_launch_equals_the_fused_forward(name, B, K, H, L):
+    """Forward mode 0 + hscn_resident_bwd_with_virtual (the virtual branch as extra workgroups of the
+    backward launch, reading the stored activations) == the one-launch forward + plain backward,
+    bit for bit: prediction, final virtual features, gradients."""
+    from graph_hscn import engine
+    ob, pb = _batches(name, B, K, seed=3)
+    F = ob["x_dict"]["local"].size(1)
+    _, pm = _models(F, H, 10, L, "relu", seed=4)
+    pm.engine = "resident"
+    pbd = pb.to(DEV)
+    g = torch.randn(B, 10, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    res = {}
+    for overlap in (False, True):
+        pm.overlap_virtual, pm.keep_virtual = overlap, not overlap
+        engine.last_deferred_virtual = None
+        pm.zero_grad(set_to_none=True)
+        out = pm(pbd.x_dict, pbd.edge_index_dict, pbd)
+        out.backward(g)
+        torch.cuda.synchronize()
+        pbd._resident_meta.check()
+        xv = engine.last_deferred_virtual if overlap else pm.last_virtual
+        assert xv is not None
+        res[overlap] = (out.detach().clone(), xv.clone(),
+                        {n: p.grad.clone() for n, p in pm.named_parameters() if p.grad is not None})
+    assert torch.equal(res[False][0], res[True][0])
+    assert torch.equal(res[False][1], res[True][1])
+    assert res[False][2].keys() == res[True][2].keys()
+    for n in res[False][2]:
+        assert torch.equal(res[False][2][n], res[True][2][n]), n
+
+
+def test_deferred_virtual_branch_inside_a_captured_step():
+    """A captured training step (forward mode 0, loss, backward carrying the virtual branch)
+    replays to the eager result."""
+    from graph_hscn.loss import criterion
+    B, K, H, L, C = 16, 16, 16, 3, 10
+    ob, pb = _batches("peptides_func", B, K, seed=5)
+    F = ob["x_dict"]["local"].size(1)
+    _, pm = _models(F, H, C, L, "relu", seed=6)
+    pm.engine, pm.keep_virtual, pm.overlap_virtual = "resident", False, True
+    pbd = pb.to(DEV)
+    y = (torch.rand(B, C, device=DEV) > 0.5).float()
+
+    def step():
+        pm.zero_grad(set_to_none=True)
+        out = pm(pbd.x_dict, pbd.edge_index_dict, pbd)
+        loss, _ = criterion("cross_entropy", out, y)
+        loss.backward()
+        return loss
+
+    eager_loss = step().detach().clone()
+    eager = {n: p.grad.clone() for n, p in pm.named_parameters() if p.grad is not None}
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    for n, p in pm.named_parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(loss, eager_loss)
+    for n, p in pm.named_parameters():
+        if n in eager:
+            assert torch.equal(p.grad, eager[n]), n
