@@ -286,7 +286,8 @@ def main():
         vv_b = 8 * V * H + 4 * Evv
         lin_b = 12 * N * H + 12 * V * H
         used_resident = model.last_engine == "resident"
-        names = ["hscn_resident_fwd", "hscn_resident_bwd"] if used_resident else ["hscn_spmm_csr_gcn"]
+        names = (["hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual",
+                  "hscn_resident_bwd_with_virtual"] if used_resident else ["hscn_spmm_csr_gcn"])
         timer = KernelTimer(names)
         orig_call = _hip.call
 
@@ -327,15 +328,23 @@ def main():
             return s_.elapsed_time(e_) * 1e-3 / REP, REP
 
         if used_resident:
-            t_f, n_f = avg_s(lambda nm, a: nm == "hscn_resident_fwd")
-            t_b, n_b = avg_s(lambda nm, a: nm == "hscn_resident_bwd")
+            split = any(nm == "hscn_resident_fwd_with_virtual" for (nm, a, s_, e_) in timer.events)
+            t_f, n_f = avg_s(lambda nm, a: nm in ("hscn_resident_fwd", "hscn_resident_fwd_with_virtual"))
+            t_b, n_b = avg_s(lambda nm, a: nm in ("hscn_resident_bwd", "hscn_resident_bwd_with_virtual"))
+            virt_layer = lv_b + vv_b + 4 * N * H + 12 * V * H      # one layer of the virtual branch
             alg_f = L * (ll_b + lv_b + vv_b + lin_b)
             alg_b = L * (ll_b + lin_b)     # the backward only walks the local->local relation (+ its transforms)
+            if split:                      # layers 1.. of the virtual branch ride on the backward launch
+                alg_f -= (L - 1) * virt_layer
+                alg_b += (L - 1) * virt_layer
             dom_fwd = t_f >= t_b
             t, alg = (t_f, alg_f) if dom_fwd else (t_b, alg_b)
+            k_f = ("k_hscn_fwd_pair (hscn_resident_fwd_with_virtual: local chain + head | virtual CSRs + layer 0, "
+                   "2 workgroups/graph)") if split else "k_hscn_fwd (hscn_resident_fwd: all layers, 1 workgroup/graph)"
+            k_b = ("k_hscn_bwd_virtual + k_param_reduce (hscn_resident_bwd_with_virtual: backward | virtual layers 1..)"
+                   if split else "k_hscn_bwd + k_param_reduce (hscn_resident_bwd)")
             roofline = {"bound": "hbm",
-                        "kernel": "k_hscn_fwd (hscn_resident_fwd: all layers, 1 workgroup/graph)" if dom_fwd
-                        else "k_hscn_bwd + k_param_reduce (hscn_resident_bwd)",
+                        "kernel": k_f if dom_fwd else k_b,
                         "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": t * 1e6,
@@ -367,7 +376,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
             default_shape = (args.workload == "peptides_func" and B == 128 and args.hidden == 16 and args.layers == 3)
             if roofline and default_shape:
-                key = "k_hscn_fwd" if "k_hscn_fwd" in roofline["kernel"] else ("k_hscn_bwd" if "k_hscn_bwd" in roofline["kernel"] else None)
+                key = roofline["kernel"].split(" ")[0]      # exact kernel name
                 if key and key in pmc:
                     roofline["traffic"] = pmc[key]["traffic_bytes"]
                     roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"

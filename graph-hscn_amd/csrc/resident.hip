@@ -60,6 +60,11 @@ struct FwdArgs {
   int32_t* flag;
   int64_t N, V;
   int F, L, C, head_act, max_n, max_v, max_ell, max_evv, compute_virtual;
+  // virtual-only launches may run a layer range [l_begin, l_end): a first part (0..l_end) exports the
+  // virtual relations' CSRs and the virtual features to vs_*, a resumed part (l_begin > 0) loads them
+  int l_begin, l_end;
+  int32_t *vs_rowptr_lv, *vs_col_lv, *vs_rowptr_vv, *vs_col_vv;
+  float *vs_dinv_v, *vs_xv;
   int spec;  // 1: ll path and virtual branch run concurrently on two wave groups (needs a 3rd n x H buffer)
   int exp;   // 1: this launch also builds + exports the source-keyed ll CSR (needs LDS for it)
   float slope;
@@ -221,6 +226,7 @@ struct FwdLayout {
   size_t xa, bh, bs, xva, xvb, hv, a_s, a_d, sc, dinv, dinv_v, wt, headw, part, vec;
   size_t rowptr, col, rowptr_lv, col_lv, rowptr_vv, col_vv, cursorA, tmpA, cursorB, tmpB, wsum;
   size_t rowptr_t, col_t, cursorT, tmpT, cursorV, tmpV;
+  size_t ck_tab, ck_first, ck_arrive, gpart;  // softmax chunks of the lv relation (64 members each)
   size_t ek_ll, eo_ll, ek_lv, eo_lv, ek_vv, eo_vv, total;
 };
 __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max_v, int max_ell, int max_evv,
@@ -262,7 +268,11 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   Y.rowptr_vv = take(max_v + 1);
   Y.col_vv = take(max_evv);
   Y.cursorA = take(max_n + 1);
-  Y.tmpA = take(max_ell);
+  // softmax chunk partials (layers only) share the words of the ll build's scratch (structure only)
+  const size_t maxck = (size_t)max_n / 64 + max_v + 1;   // sum over clusters of max(1, ceil(size / 64))
+  const size_t gwords = max_v ? maxck * H : 0;
+  Y.tmpA = take((size_t)max_ell > gwords ? (size_t)max_ell : gwords);
+  Y.gpart = Y.tmpA;
   const int nchunk = (max_n + 63) / 64;
   size_t cb = (size_t)max_v + 1;
   if ((size_t)max_v * nchunk > cb) cb = (size_t)max_v * nchunk;  // multisplit counters
@@ -275,6 +285,9 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   Y.tmpT = take(exp ? max_ell : 0);
   Y.cursorV = take(max_v + 1);
   Y.tmpV = take(max_evv);
+  Y.ck_tab = take(max_v ? maxck : 0);
+  Y.ck_first = take(max_v ? max_v + 1 : 0);
+  Y.ck_arrive = take(max_v);
   Y.total = o;
   return Y;
 }
@@ -304,6 +317,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   int *rowptr = ib + Y.rowptr, *col = ib + Y.col, *rowptr_lv = ib + Y.rowptr_lv, *col_lv = ib + Y.col_lv;
   int *rowptr_vv = ib + Y.rowptr_vv, *col_vv = ib + Y.col_vv;
   int* wsum = ib + Y.wsum;
+  int *ck_tab = ib + Y.ck_tab, *ck_first = ib + Y.ck_first, *ck_arrive = ib + Y.ck_arrive;
+  float* gpart = fb + Y.gpart;
   const bool cv = A.compute_virtual != 0;
   const int F = A.F;
 
@@ -317,9 +332,38 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   const Grp GA{(int)threadIdx.x, NA * 64, wave, NA};
   const Grp GB{(int)threadIdx.x - NA * 64, (NW - NA) * 64, wave - NA, NW - NA};
 
+  // softmax work list (layer independent), built by ONE wave: cluster v is cut into
+  // max(1, ceil(size/64)) chunks of 64 members; entry k = (v << 8) | index inside v,
+  // ck_first[v] = first chunk of v, ck_first[nv] = number of chunks
+  auto build_chunk_table = [&]() {
+    const int lane = threadIdx.x & 63;
+    int carry = 0;
+    for (int base = 0; base < nv; base += 64) {
+      const int v = base + lane;
+      const int sz = v < nv ? rowptr_lv[v + 1] - rowptr_lv[v] : 0;
+      const int cnt = v < nv ? (sz > 64 ? (sz + 63) >> 6 : 1) : 0;
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t_ = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t_;
+      }
+      const int first = carry + incl - cnt;
+      if (v < nv) {
+        ck_first[v] = first;
+        ck_arrive[v] = 0;
+        for (int c = 0; c < cnt; ++c) ck_tab[first + c] = (v << 8) | c;
+      }
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) ck_first[nv] = carry;
+  };
+
   // ---- prologue: request every global input of this graph, then consume -----------------------
   STAMP(0);
   WStage<H, RT> ws;
+  const bool resume = vonly && A.l_begin > 0;
+  if (!resume) {
   ws.fetch(A.layer[0], cv, F);
   constexpr int EPT = 2;   // edges per thread held in registers (covers RT*EPT edges per relation)
   constexpr int XPT = 8;   // feature words per thread held in registers
@@ -461,7 +505,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       headw[H * H + H + A.C * H + idx] = idx == (int)threadIdx.x ? hb2 : A.b2[idx];
   }
   ws.store(wt);
-  __syncthreads();
+  lds_barrier();
   STAMP(1);
   // ---- structure: the CSRs are independent, so wave groups build them side by side between the
   // same six barriers: ll keyed by target (forward), ll keyed by source (exported for the backward
@@ -488,10 +532,11 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     } else {
       build_csr_multisplit_lds(ib + Y.ek_lv, ib + Y.eo_lv, nel, nv, rowptr_lv, col_lv, ib + Y.cursorB, ib + Y.tmpB,
                                wsum + 24, GS);
-      __syncthreads();  // the multisplit has one barrier less than the rank build
+      if (GS.w == 0) build_chunk_table();
+      lds_barrier();  // the multisplit has one barrier less than the rank build
     }
     STAMP(2);
-    __syncthreads();
+    lds_barrier();
     // export the source-keyed CSR and the degree norm for the backward launch
     if (A.exp) {
       for (int i = threadIdx.x; i <= n; i += RT) A.csr_rowptr_t[(size_t)n0 + g + i] = rowptr_t[i];
@@ -500,9 +545,28 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       for (int i = threadIdx.x; i < n; i += RT) A.dinv_out[(size_t)n0 + i] = dinv[i];
     }
   }
+  } else {
+    // ---- resumed virtual branch: the structure and the virtual features come from the state the
+    // first part of this step exported, the local rows from the previous layer's activations
+    ws.fetch(A.layer[A.l_begin], true, H);
+    const float4* src = reinterpret_cast<const float4*>(A.acts + ((size_t)(A.l_begin - 1) * A.N + n0) * H);
+    for (int i = threadIdx.x; i < n * (H / 4); i += RT) reinterpret_cast<float4*>(xa)[i] = src[i];
+    for (int i = threadIdx.x; i < nv * H; i += RT) xva[i] = A.vs_xv[(size_t)v0 * H + i];
+    for (int i = threadIdx.x; i <= nv; i += RT) {
+      rowptr_lv[i] = A.vs_rowptr_lv[(size_t)v0 + g + i];
+      rowptr_vv[i] = A.vs_rowptr_vv[(size_t)v0 + g + i];
+    }
+    for (int i = threadIdx.x; i < nel; i += RT) col_lv[i] = A.vs_col_lv[(size_t)el0 + i];
+    for (int i = threadIdx.x; i < nev; i += RT) col_vv[i] = A.vs_col_vv[(size_t)ev0 + i];
+    for (int i = threadIdx.x; i < nv; i += RT) dinv_v[i] = A.vs_dinv_v[(size_t)v0 + i];
+    ws.store(wt + ((H <= 16) ? (A.l_begin & 1) * WSZ : 0));
+    lds_barrier();
+    if (wave == 0) build_chunk_table();
+    lds_barrier();
+  }
   STAMP(3);
 
-  for (int l = 0; l < A.L; ++l) {
+  for (int l = A.l_begin; l < A.l_end; ++l) {
     constexpr bool DB = H <= 16;               // two weight buffers: the next layer's land under this layer's math
     float* W = wt + (DB ? (l & 1) * WSZ : 0);
     float* Wn = wt + (DB ? ((l + 1) & 1) * WSZ : 0);
@@ -511,19 +575,33 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     const float* b_gat = b_ll + 2 * H;
     const float* att_s = b_ll + 3 * H;
     const float* att_d = b_ll + 4 * H;
-    const bool more = l + 1 < A.L;
+    const bool more = l + 1 < A.l_end;
     // fetch the next layer's weights now, park them in LDS under this layer's math
     if (more && DB) ws.fetch(A.layer[l + 1], cv, H);
     STAMP(4 + 4 * l);
     auto transforms_ll = [&](const Grp& G_) { lin_blk<H, OPT>(xa, W, bh, n, nullptr, nullptr, G_); };
     // virtual-only launch: layer l+1 reads the local activations the local launch stored
-    auto load_next_local = [&](const Grp& G_) {
+    auto load_next_local = [&](const Grp& G_, float* to) {
       if (!more) return;
       const float4* src = reinterpret_cast<const float4*>(A.acts + ((size_t)l * A.N + n0) * H);
-      float4* dst = reinterpret_cast<float4*>(xa);
+      float4* dst = reinterpret_cast<float4*>(to);
       for (int i = G_.t; i < n * (H / 4); i += G_.nt) dst[i] = src[i];
     };
     auto transforms_virtual = [&](const Grp& G_) {
+      // the two cluster-side transforms have a handful of rows: one wave each, beside the waves
+      // that transform the n local rows
+      constexpr int RPW = 64 / (H / OPT);   // rows one wave covers per pass
+      if (G_.nw >= 4 && nv <= 4 * RPW) {
+        const int ns = G_.nw - 2;
+        if (G_.w < ns) {
+          lin_blk<H, OPT>(xa, W + H * H, bs, n, att_s, a_s, Grp{G_.t, ns * 64, G_.w, ns});
+        } else if (G_.w == ns) {
+          lin_blk<H, OPT>(xva, W + 2 * H * H, nullptr, nv, att_d, a_d, Grp{G_.t - ns * 64, 64, 0, 1});
+        } else {
+          lin_blk<H, OPT>(xva, W + 3 * H * H, hv, nv, nullptr, nullptr, Grp{G_.t - (ns + 1) * 64, 64, 0, 1});
+        }
+        return;
+      }
       lin_blk<H, OPT>(xa, W + H * H, bs, n, att_s, a_s, G_);               // lv source side (+ a_src)
       lin_blk<H, OPT>(xva, W + 2 * H * H, nullptr, nv, att_d, a_d, G_);    // lv target side only through a_dst
       lin_blk<H, OPT>(xva, W + 3 * H * H, hv, nv, nullptr, nullptr, G_);   // vv
@@ -531,99 +609,201 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     auto reduce_ll = [&](const Grp& G_) {
       agg_gcn_lds<H>(rowptr, col, dinv, dinv, bh, b_ll, xa, n, 1, A.acts + ((size_t)l * A.N + n0) * H, G_);
     };
-    // one wave per cluster: vv gather-reduce for its row + segment softmax over its members
+    // lv segment softmax + weighted sum, one wave per 64-member chunk of a cluster (clusters are as
+    // unbalanced as the assignment makes them: one wave per cluster would serialise the big one).
+    // Every chunk wave recomputes the cluster's max / denominator (a few LDS reads), reduces its own
+    // members into a partial row, and the wave that arrives last at the cluster's counter adds the
+    // partials in chunk order, the vv GCN row and the biases.  LDS executes a wave's operations in
+    // order and the counter is acquire/release, so the partials are visible to the finisher.
     auto reduce_virtual = [&](const Grp& G_) {
       constexpr int LPR = H / 4 > 64 ? 64 : H / 4;
       constexpr int S = 64 / LPR;
       const int lane = threadIdx.x & 63, slot = lane / LPR, f = (lane % LPR) * 4;
-      for (int v = G_.w; v < nv; v += G_.nw) {
+      const int nck = ck_first[nv];
+      for (int ck = G_.w; ck < nck; ck += G_.nw) {
+        const int code = ck_tab[ck];
+        const int v = code >> 8, c = code & 255;
         const int s = rowptr_lv[v], t = rowptr_lv[v + 1];
         const float ad = a_d[v];
-        float m = -INFINITY;
-        for (int p = s + lane; p < t; p += 64) {
-          const float e = leaky(a_s[col_lv[p]] + ad, A.slope);
-          sc[p] = e;
-          m = fmaxf(m, e);
+        const int cs = s + c * 64, ce = (cs + 64 < t) ? cs + 64 : t;   // this wave's members
+        const int p_own = cs + lane;
+        const bool on = p_own < ce;
+        const float e_own = on ? leaky(a_s[col_lv[p_own]] + ad, A.slope) : -INFINITY;
+        float m, denom;
+        if (t - s <= 64) {
+          m = wave_max_dpp(e_own);
+          denom = wave_sum_dpp(on ? expf(e_own - m) : 0.f) + 1e-16f;
+        } else {
+          m = -INFINITY;
+          for (int p = s + lane; p < t; p += 64) m = fmaxf(m, leaky(a_s[col_lv[p]] + ad, A.slope));
+          m = wave_max_dpp(m);
+          float sum = 0.f;
+          for (int p = s + lane; p < t; p += 64) sum += expf(leaky(a_s[col_lv[p]] + ad, A.slope) - m);
+          denom = wave_sum_dpp(sum) + 1e-16f;
         }
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int p = s + lane; p < t; p += 64) {
-          const float ex = expf(sc[p] - m);
-          sc[p] = ex;
-          sum += ex;
-        }
-        sum = wave_sum(sum);
-        const float denom = sum + 1e-16f;
-        for (int p = s + lane; p < t; p += 64) sc[p] = sc[p] / denom;
-        // LDS operations of one wave complete in order: the slot loop sees the alphas
+        if (on) sc[p_own] = expf(e_own - m) / denom;
+        // (in-order LDS: the slot loop below sees the alphas)  Four members per slot per trip: the
+        // index, alpha and row reads of a trip are independent.
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = s + slot; p < t; p += S) {
-          const int j = col_lv[p];
-          const float al = sc[p];
-          const float4 hvv = *reinterpret_cast<const float4*>(bs + j * H + f);
-          acc.x = fmaf(al, hvv.x, acc.x);
-          acc.y = fmaf(al, hvv.y, acc.y);
-          acc.z = fmaf(al, hvv.z, acc.z);
-          acc.w = fmaf(al, hvv.w, acc.w);
-        }
+        for (int p0 = cs + slot; p0 < ce; p0 += 4 * S) {
+          int jj[4];
+          float al[4];
+          float4 hh[4];
 #pragma unroll
-        for (int off = 32; off >= LPR; off >>= 1) {
+          for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * S;
+            const bool ok = p < ce;
+            jj[u] = ok ? col_lv[p] : 0;
+            al[u] = ok ? sc[p] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) hh[u] = *reinterpret_cast<const float4*>(bs + jj[u] * H + f);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (p0 + u * S < ce) {
+              acc.x = fmaf(al[u], hh[u].x, acc.x);
+              acc.y = fmaf(al[u], hh[u].y, acc.y);
+              acc.z = fmaf(al[u], hh[u].z, acc.z);
+              acc.w = fmaf(al[u], hh[u].w, acc.w);
+            }
+          }
+        }
+        // fold the slots: across DPP rows through bpermute, inside a row through DPP rotations
+#pragma unroll
+        for (int off = 32; off >= 16 && off >= LPR; off >>= 1) {
           acc.x += __shfl_xor(acc.x, off, 64);
           acc.y += __shfl_xor(acc.y, off, 64);
           acc.z += __shfl_xor(acc.z, off, 64);
           acc.w += __shfl_xor(acc.w, off, 64);
         }
+        if (LPR <= 8) {
+          acc.x = row_ror_add<8>(acc.x); acc.y = row_ror_add<8>(acc.y);
+          acc.z = row_ror_add<8>(acc.z); acc.w = row_ror_add<8>(acc.w);
+        }
+        if (LPR <= 4) {
+          acc.x = row_ror_add<4>(acc.x); acc.y = row_ror_add<4>(acc.y);
+          acc.z = row_ror_add<4>(acc.z); acc.w = row_ror_add<4>(acc.w);
+        }
+        const int first = ck_first[v], cntv = ck_first[v + 1] - first;
+        if (slot == 0) *reinterpret_cast<float4*>(gpart + (size_t)ck * H + f) = acc;
+        int arrived = 0;
+        if (lane == 0)
+          arrived = __hip_atomic_fetch_add(&ck_arrive[v], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived != cntv - 1) continue;
+        // ---- last chunk of cluster v: finish row v ----
+        if (lane == 0) ck_arrive[v] = 0;   // ready for the next layer
         if (slot == 0) {
-          // virtual -> virtual GCN row v (edge order, separately rounded), + b_vv
+          // virtual -> virtual GCN row v (edge order, separately rounded)
           const int s2 = rowptr_vv[v], t2 = rowptr_vv[v + 1];
           const float di = dinv_v[v];
           float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int p = s2; p < t2; ++p) {
-            const int j = col_vv[p];
-            const float w_ = mul_rn(dinv_v[j], di);
-            const float4 x = *reinterpret_cast<const float4*>(hv + j * H + f);
-            a.x = add_rn(a.x, mul_rn(w_, x.x));
-            a.y = add_rn(a.y, mul_rn(w_, x.y));
-            a.z = add_rn(a.z, mul_rn(w_, x.z));
-            a.w = add_rn(a.w, mul_rn(w_, x.w));
+          for (int p0 = s2; p0 < t2; p0 += 4) {
+            int jj[4];
+            float ww[4];
+            float4 xx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = (p0 + u < t2) ? col_vv[p0 + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              ww[u] = mul_rn(dinv_v[jj[u]], di);
+              xx[u] = *reinterpret_cast<const float4*>(hv + jj[u] * H + f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (p0 + u < t2) {
+                a.x = add_rn(a.x, mul_rn(ww[u], xx[u].x));
+                a.y = add_rn(a.y, mul_rn(ww[u], xx[u].y));
+                a.z = add_rn(a.z, mul_rn(ww[u], xx[u].z));
+                a.w = add_rn(a.w, mul_rn(ww[u], xx[u].w));
+              }
+            }
+          }
+          float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int c2 = 0; c2 < cntv; ++c2) {
+            const float4 q = *reinterpret_cast<const float4*>(gpart + (size_t)(first + c2) * H + f);
+            g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
           }
           const float4 bv = *reinterpret_cast<const float4*>(b_vv + f);
           const float4 bg = *reinterpret_cast<const float4*>(b_gat + f);
-          a.x = fmaxf((a.x + bv.x) + (acc.x + bg.x), 0.f);
-          a.y = fmaxf((a.y + bv.y) + (acc.y + bg.y), 0.f);
-          a.z = fmaxf((a.z + bv.z) + (acc.z + bg.z), 0.f);
-          a.w = fmaxf((a.w + bv.w) + (acc.w + bg.w), 0.f);
+          a.x = fmaxf((a.x + bv.x) + (g.x + bg.x), 0.f);
+          a.y = fmaxf((a.y + bv.y) + (g.y + bg.y), 0.f);
+          a.z = fmaxf((a.z + bv.z) + (g.z + bg.z), 0.f);
+          a.w = fmaxf((a.w + bv.w) + (g.w + bg.w), 0.f);
           *reinterpret_cast<float4*>(xvb + v * H + f) = a;
         }
       }
     };
     if (cv && A.spec) {
       // two barriers per layer: the ll path (group A) and the virtual branch (group B) side by side
-      if (inB) transforms_virtual(GB); else if (!vonly) transforms_ll(GA);
-      if (more && DB) ws.store(Wn);
-      __syncthreads();
-      STAMP(5 + 4 * l);
-      if (inB) reduce_virtual(GB); else if (vonly) load_next_local(GA); else reduce_ll(GA);
-      __syncthreads();
+      // (virtual-only launch: group A streams the next layer's local rows into the idle transform
+      // buffer while group B works, the two buffers swap roles at the end of the layer)
+      // Each wave group walks its own copy of the two-barrier sequence: what one group keeps in
+      // registers across the barrier (the streamed rows) is not live in the other group's code.
+      if (inB) {
+        transforms_virtual(GB);
+        STAMP_T(40 + 4 * l, NA * 64);        // group B done with its transforms
+        if (more && DB) ws.store(Wn);
+        lds_barrier();
+        reduce_virtual(GB);
+        STAMP_T(42 + 4 * l, NA * 64);        // group B (its first wave) done with its reduce
+        lds_barrier();
+      } else if (vonly) {
+        // request up to PF float4 words per thread before the barrier, store them to LDS after it:
+        // the rows travel under group B's transforms (inline, not a lambda: they stay in registers)
+        constexpr int PF = 8;
+        float pf[PF][4];
+        const float4* nsrc = reinterpret_cast<const float4*>(A.acts + ((size_t)l * A.N + n0) * H);
+        const int ncnt = more ? n * (H / 4) : 0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int i = GA.t + u * GA.nt;
+          const float4 q = nsrc[i < ncnt ? i : 0];
+          pf[u][0] = q.x; pf[u][1] = q.y; pf[u][2] = q.z; pf[u][3] = q.w;
+        }
+        STAMP_T(41 + 4 * l, 0);              // group A done with its phase-1 work
+        if (more && DB) ws.store(Wn);
+        lds_barrier();
+        STAMP(5 + 4 * l);
+        float4* ndst = reinterpret_cast<float4*>(bh);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int i = GA.t + u * GA.nt;
+          if (i < ncnt) ndst[i] = make_float4(pf[u][0], pf[u][1], pf[u][2], pf[u][3]);
+        }
+        for (int i = GA.t + PF * GA.nt; i < ncnt; i += GA.nt) ndst[i] = nsrc[i];
+        STAMP_T(43 + 4 * l, 0);              // group A done with its phase-2 work
+        lds_barrier();
+      } else {
+        transforms_ll(GA);
+        STAMP_T(41 + 4 * l, 0);
+        if (more && DB) ws.store(Wn);
+        lds_barrier();
+        STAMP(5 + 4 * l);
+        reduce_ll(GA);
+        STAMP_T(43 + 4 * l, 0);
+        lds_barrier();
+      }
+      if (vonly && more) { float* t_ = xa; xa = bh; bh = t_; }
     } else {
       // one n x H transform buffer: the virtual branch first, then the ll path
       if (cv) {
         transforms_virtual(ALL);
-        __syncthreads();
+        lds_barrier();
         reduce_virtual(ALL);
-        __syncthreads();
+        lds_barrier();
       }
       if (!vonly) transforms_ll(ALL);
       if (more && DB) ws.store(Wn);
-      __syncthreads();
+      lds_barrier();
       STAMP(5 + 4 * l);
-      if (vonly) load_next_local(ALL); else reduce_ll(ALL);
-      __syncthreads();
+      if (vonly) load_next_local(ALL, xa); else reduce_ll(ALL);
+      lds_barrier();
     }
     if (more && !DB) {  // single weight buffer: everybody is done with it now
       ws.fetch(A.layer[l + 1], cv, H);
       ws.store(Wn);
-      __syncthreads();
+      lds_barrier();
     }
     STAMP(6 + 4 * l);
     if (cv) {  // swap virtual buffers
@@ -631,9 +811,22 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     }
   }
 
-  if (cv && A.xv_out)
+  if (vonly && A.l_end < A.L) {
+    // first part of a split virtual branch: hand the state to the part that resumes at l_end
+    for (int idx = threadIdx.x; idx < nv * H; idx += RT) A.vs_xv[(size_t)v0 * H + idx] = xva[idx];
+    for (int i = threadIdx.x; i <= nv; i += RT) {
+      A.vs_rowptr_lv[(size_t)v0 + g + i] = rowptr_lv[i];
+      A.vs_rowptr_vv[(size_t)v0 + g + i] = rowptr_vv[i];
+    }
+    const int c_lv = rowptr_lv[nv], c_vv = rowptr_vv[nv];
+    for (int i = threadIdx.x; i < c_lv; i += RT) A.vs_col_lv[(size_t)el0 + i] = col_lv[i];
+    for (int i = threadIdx.x; i < c_vv; i += RT) A.vs_col_vv[(size_t)ev0 + i] = col_vv[i];
+    for (int i = threadIdx.x; i < nv; i += RT) A.vs_dinv_v[(size_t)v0 + i] = dinv_v[i];
+  } else if (cv && A.xv_out) {
     for (int idx = threadIdx.x; idx < nv * H; idx += RT) A.xv_out[(size_t)v0 * H + idx] = xva[idx];
+  }
 
+  STAMP(62);
   if (vonly) return;  // the prediction belongs to the local launch
   // ---- global_mean_pool: every wave sums a strided row set, wave 0 folds in wave order -----------
   {
@@ -654,7 +847,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     }
     if (slot == 0) *reinterpret_cast<float4*>(part + wave * H + f) = acc;
   }
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     float* pooled = vec;
@@ -709,6 +902,16 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
 template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
   hscn_fwd_body<H, RT>(A, blockIdx.x);
+}
+
+// One launch, two kinds of workgroup: even blocks run the local chain + head of graph g, odd blocks
+// the part of the virtual branch that does not need them (its CSRs and layer 0, which reads the
+// input features); see k_hscn_bwd_virtual for the rest.
+template <int H, int RT>
+__global__ void __launch_bounds__(RT) k_hscn_fwd_pair(const FwdArgs Al, const FwdArgs Av) {
+  const int g = blockIdx.x >> 1;
+  if (blockIdx.x & 1) hscn_fwd_body<H, RT>(Av, g);
+  else hscn_fwd_body<H, RT>(Al, g);
 }
 
 // =============================== backward =====================================================
@@ -832,7 +1035,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     zz[threadIdx.x] = zv;
     pol[threadIdx.x] = pv;
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(1);
   STAMP(2);
 
@@ -847,7 +1050,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     for (int c = 0; c < A.C; ++c) acc = fmaf(gpl[c], W2l[c * H + threadIdx.x], acc);
     gz[threadIdx.x] = acc * act_grad_from_output(zz[threadIdx.x], A.head_act);
   }
-  __syncthreads();
+  lds_barrier();
   for (int idx = threadIdx.x; idx < A.C * H; idx += RT) {
     const int c = idx / H, k = idx - c * H;
     part[oW2 + idx] = gpl[c] * zz[k];
@@ -864,7 +1067,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     for (int o = 0; o < H; ++o) acc = fmaf(gz[o], W1l[o * H + threadIdx.x], acc);
     gpool[threadIdx.x] = acc;
   }
-  __syncthreads();
+  lds_barrier();
   // dL/d x_L[i][f] = g_pool[f] / n, masked by ReLU of the saved output (in X)
   {
     const float cnt = (float)(n > 0 ? n : 1);
@@ -877,7 +1080,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     const int fin = l == 0 ? A.F : H;
     off -= H * fin + H;
     const int oW = off, ob = off + H * fin;
-    __syncthreads();  // G (masked) complete; X free to be overwritten
+    lds_barrier();  // G (masked) complete; X free to be overwritten
     // layer input -> X (zero padded) and this layer's W_ll -> LDS.  The loads are issued first and
     // parked in LDS after the gather-reduce: their HBM latency hides under it.
     float xr[XPT], wr_[(H * H + RT - 1) / RT];
@@ -916,7 +1119,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
       const int idx = threadIdx.x + i * RT;
       if (idx < H * H) wl[idx] = wr_[i];
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(4 + 4 * l);
     // weight gradient gW[o][k] = sum_j GH[j][o] * X[j][k]: 4x4 tiles of (o,k); a 16-lane DPP row
     // owns a tile, its lanes and NRG wave-groups split the rows; 16 register accumulators per
@@ -960,7 +1163,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
           }
         const int tpp = (NW / NRG) * TPW;  // tiles per pass
         if (live) red[(rg * tpp + (tile - tg0 * TPW)) * 16 + l16] = mine;
-        __syncthreads();
+        lds_barrier();
         for (int idx = threadIdx.x; idx < (NW / NRG) * TPW * 16; idx += RT) {
           const int t_ = tg0 * TPW + idx / 16, e_ = idx & 15;
           if (t_ < NT) {
@@ -970,7 +1173,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
             if (kk < fin) part[oW + oo * fin + kk] = s;
           }
         }
-        __syncthreads();
+        lds_barrier();
       }
     }
     STAMP(5 + 4 * l);
@@ -1068,15 +1271,15 @@ __global__ void __launch_bounds__(256) k_ll_csr_t(const FwdArgs A) {
     if (k < 0 || k >= n || o < 0 || o >= n) { k = -1; o = -1; }
     ek[e] = k; eo[e] = o;
   }
-  __syncthreads();
+  lds_barrier();
   for (int e = threadIdx.x; e < ne; e += 256)
     if (ek[e] >= 0) atomicAdd(&cursor[eo[e]], 1);
-  __syncthreads();
+  lds_barrier();
   for (int i = threadIdx.x; i < n; i += 256) {
     const int d = cursor[i];
     A.dinv_out[(size_t)n0 + i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   build_csr_lds(ek, eo, ne, n, rowptr_t, col_t, cursor, tmp, wsum, ALL);
   for (int i = threadIdx.x; i <= n; i += 256) A.csr_rowptr_t[(size_t)n0 + g + i] = rowptr_t[i];
   const int cnt_t = rowptr_t[n];
@@ -1196,6 +1399,63 @@ int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, cons
   A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_v = max_v; A.max_ell = vonly ? 0 : max_ell; A.max_evv = max_evv;
   A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0;
+  A.l_begin = 0; A.l_end = L;
+  A.vs_rowptr_lv = A.vs_col_lv = A.vs_rowptr_vv = A.vs_col_vv = nullptr;
+  A.vs_dinv_v = A.vs_xv = nullptr;
+  return 0;
+}
+
+inline bool job_has_state(const hscn_virtual_job* j) {
+  return j->st_rowptr_lv && j->st_col_lv && j->st_rowptr_vv && j->st_col_vv && j->st_dinv_v && j->st_xv;
+}
+inline void attach_state(FwdArgs& A, const hscn_virtual_job* j) {
+  A.vs_rowptr_lv = j->st_rowptr_lv; A.vs_col_lv = j->st_col_lv;
+  A.vs_rowptr_vv = j->st_rowptr_vv; A.vs_col_vv = j->st_col_vv;
+  A.vs_dinv_v = j->st_dinv_v; A.vs_xv = j->st_xv;
+}
+
+template <int H, int RT>
+int launch_fwd_pair_rt(const FwdArgs& Al, const FwdArgs& Av, int64_t B, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_hscn_fwd_pair<H, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  k_hscn_fwd_pair<H, RT><<<(unsigned)(2 * B), RT, lds, st>>>(Al, Av);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+template <int H>
+int launch_fwd_pair(FwdArgs& Al, FwdArgs& Av, int64_t B, hipStream_t st) {
+  // local part: no virtual branch, CSR export in the launch when LDS allows (else the side kernel)
+  const bool want_exp = Al.csr_rowptr_t != nullptr;
+  size_t ll = 0, lv = 0;
+  bool ok = false;
+  for (int e = 1; e >= 0 && !ok; --e) {
+    Al.spec = 0;
+    Al.exp = (want_exp && e) ? 1 : 0;
+    ll = fwd_lds_bytes(H, Al.C, Al.max_n, Al.max_v, Al.max_ell, Al.max_evv, 0, Al.exp);
+    ok = ll <= 160 * 1024;
+  }
+  if (!ok) return HSCN_E_UNSUPPORTED;
+  ok = false;
+  for (int spec = 1; spec >= 0 && !ok; --spec) {
+    Av.spec = spec;
+    Av.exp = 0;
+    lv = fwd_lds_bytes(H, Av.C, Av.max_n, Av.max_v, Av.max_ell, Av.max_evv, spec, 0);
+    ok = lv <= 160 * 1024;
+  }
+  if (!ok) return HSCN_E_UNSUPPORTED;
+  const size_t lds = ll > lv ? ll : lv;
+  int rc = Al.max_n <= 64 ? launch_fwd_pair_rt<H, 256>(Al, Av, B, lds, st)
+                          : launch_fwd_pair_rt<H, 1024>(Al, Av, B, lds, st);
+  if (rc) return rc;
+  if (want_exp && !Al.exp) {
+    const size_t l2 = ((size_t)4 * Al.max_ell + 2 * ((size_t)Al.max_n + 1) + 16) * 4;
+    if (l2 > 160 * 1024) return HSCN_E_UNSUPPORTED;
+    if (l2 > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_ll_csr_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    k_ll_csr_t<<<(unsigned)B, 256, l2, st>>>(Al);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
   return 0;
 }
 
@@ -1321,6 +1581,11 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                               max_n, job->max_v, max_ell, job->max_evv, 2, const_cast<float*>(acts), nullptr,
                               nullptr, nullptr, job->xv_out, nullptr, nullptr, nullptr, flag))
     return rc1;
+  if (job_has_state(job)) {   // the forward launch ran structure + layer 0 (hscn_resident_fwd_with_virtual)
+    if (L < 2) return HSCN_E_BADARG;
+    attach_state(Af, job);
+    Af.l_begin = 1;
+  }
   hipStream_t st = hscn_stream(stream_);
   int rc = HSCN_E_UNSUPPORTED;
   switch (H) {
@@ -1332,6 +1597,43 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
   k_param_reduce<<<hscn_blocks(Ab.P, 32), 256, 0, st>>>(partials, grads, (int)B, Ab.P);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+
+int hscn_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                                   const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
+                                   int head_act, const void* const* layer_params_host, const float* W1,
+                                   const float* b1, const float* W2, const float* b2, int max_n, int max_ell,
+                                   float* acts, float* pooled, float* z, float* pred, int32_t* csr_rowptr_t,
+                                   int32_t* csr_col_t, float* dinv_out, int32_t* flag, const hscn_virtual_job* job,
+                                   void* stream_) {
+  if (B < 0 || N < 0 || !job) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (L < 2 || !job_has_state(job)) return HSCN_E_BADARG;
+  if (!hscn_resident_supported(F, H, L, C, max_n, job->max_v, max_ell, job->max_evv)) return HSCN_E_UNSUPPORTED;
+  FwdArgs Al, Av;
+  if (int rc0 = fill_fwd_args(Al, x_local, job->x_virtual, ei_ll, E_ll, job->ei_vv, job->E_vv, job->ei_lv,
+                              job->E_lv, lptr, job->vptr, eptr_ll, job->eptr_vv, job->eptr_lv, N, job->V, F, H, L,
+                              C, head_act, job->slope, layer_params_host, W1, b1, W2, b2, max_n, job->max_v,
+                              max_ell, job->max_evv, 0, acts, pooled, z, pred, nullptr, csr_rowptr_t, csr_col_t,
+                              dinv_out, flag))
+    return rc0;
+  // virtual part 1: `acts` is not read by layer 0 (it takes the input features) but must be valid
+  if (int rc1 = fill_fwd_args(Av, x_local, job->x_virtual, nullptr, 0, job->ei_vv, job->E_vv, job->ei_lv,
+                              job->E_lv, lptr, job->vptr, eptr_ll, job->eptr_vv, job->eptr_lv, N, job->V, F, H, L,
+                              C, head_act, job->slope, job->layer_params_host, nullptr, nullptr, nullptr, nullptr,
+                              max_n, job->max_v, max_ell, job->max_evv, 2, acts, nullptr, nullptr, nullptr,
+                              job->xv_out ? job->xv_out : job->st_xv, nullptr, nullptr, nullptr, flag))
+    return rc1;
+  attach_state(Av, job);
+  Av.l_begin = 0;
+  Av.l_end = 1;
+  hipStream_t st = hscn_stream(stream_);
+  switch (H) {
+    case 16: return launch_fwd_pair<16>(Al, Av, B, st);
+    case 32: return launch_fwd_pair<32>(Al, Av, B, st);
+    case 64: return launch_fwd_pair<64>(Al, Av, B, st);
+  }
+  return HSCN_E_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -16,9 +16,21 @@ __device__ long long* g_stamp_buf = nullptr;  // [grid][64]
   do {                                                                                           \
     if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 64 + (k)] = clock64(); \
   } while (0)
+#define STAMP_T(k, tid)                                                                           \
+  do {                                                                                           \
+    if ((int)threadIdx.x == (tid) && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 64 + (k)] = clock64(); \
+  } while (0)
 #else
 #define STAMP(k) do {} while (0)
+#define STAMP_T(k, tid) do {} while (0)
 #endif
+
+// Workgroup barrier for phases that exchange data through LDS only.  __syncthreads() carries a
+// workgroup-scope fence, which on gfx9 drains the vector-memory counter as well: every barrier
+// would wait for the global stores (activations, CSR export, gradient partials) and prefetch loads
+// still in flight.  Nothing in these kernels is exchanged between the waves of a workgroup through
+// global memory, so waiting for the LDS / scalar counter is enough.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // A wave group: a contiguous range of waves of the workgroup that works on its own arrays
 // between the workgroup-wide barriers (every group executes the same barrier sequence).
@@ -38,6 +50,35 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
+// Whole-wave reductions for a fully active wave: DPP inside the four rows, then the four row
+// results through readlane (scalar), folded in row order.  ~10 VALU ops instead of six dependent
+// ds_bpermute round trips.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  const int r = __float_as_int(row16_sum(v));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(r, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(r, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(r, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(r, 48));
+  return ((r0 + r1) + r2) + r3;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  const int r = __float_as_int(row16_max(v));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(r, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(r, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(r, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(r, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// v + (the lane `off` away inside the 16-lane DPP row, rotation): with off = 8 then 4 every lane ends
+// with the sum over the four lanes congruent to it mod 4 (the same pairs as an xor butterfly)
+template <int OFF>
+__device__ __forceinline__ float row_ror_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + OFF, 0xF, 0xF, true));
+}
+
 // ---- group inclusive scan of a[0..n) in LDS, in place (two workgroup barriers) -----------------
 __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp& G) {
   const int per = (n + G.nt - 1) / G.nt;
@@ -53,7 +94,7 @@ __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp&
     if (lane >= o) incl += t;
   }
   if (lane == 63) wsum[G.w] = incl;
-  __syncthreads();
+  lds_barrier();
   int off = 0;
   for (int i = 0; i < G.w; ++i) off += wsum[i];
   int run = off + incl - s;
@@ -62,7 +103,7 @@ __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp&
       run += a[b + i];
       a[b + i] = run;
     }
-  __syncthreads();
+  lds_barrier();
 }
 
 // ---- stable CSR from staged edges (local ids; key -1 = dropped): low-degree rows --------------
@@ -75,12 +116,12 @@ __device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, i
     rowptr[i] = 0;
     cursor[i] = 0;
   }
-  __syncthreads();
+  lds_barrier();
   for (int e = G.t; e < ne; e += G.nt) {
     const int k = ek[e];
     if (k >= 0) atomicAdd(&rowptr[k + 1], 1);
   }
-  __syncthreads();
+  lds_barrier();
   scan_inclusive_lds(rowptr, nrows + 1, wsum, G);
   for (int e = G.t; e < ne; e += G.nt) {
     const int k = ek[e];
@@ -88,7 +129,7 @@ __device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, i
     const int p = atomicAdd(&cursor[k], 1);
     tmp[rowptr[k] + p] = e;
   }
-  __syncthreads();
+  lds_barrier();
   for (int e = G.t; e < ne; e += G.nt) {
     const int k = ek[e];
     if (k < 0) continue;
@@ -97,7 +138,7 @@ __device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, i
     for (int q = s; q < t; ++q) rank += (tmp[q] < e) ? 1 : 0;
     col[s + rank] = eo[e];
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // ---- stable CSR, few rows of high degree (local -> virtual: rows are clusters) ----------------
@@ -110,7 +151,7 @@ __device__ void build_csr_multisplit_lds(const int* ek, const int* eo, int ne, i
   const int nchunk = (ne + 63) >> 6;
   const int lane = threadIdx.x & 63;
   for (int i = G.t; i < nrows * nchunk; i += G.nt) cnt[i] = 0;
-  __syncthreads();
+  lds_barrier();
   for (int c = G.w; c < nchunk; c += G.nw) {
     const int e = c * 64 + lane;
     const int k = e < ne ? ek[e] : -1;
@@ -126,7 +167,7 @@ __device__ void build_csr_multisplit_lds(const int* ek, const int* eo, int ne, i
     }
     if (e < ne) tmp[e] = rank;
   }
-  __syncthreads();
+  lds_barrier();
   scan_inclusive_lds(cnt, nrows * nchunk, wsum, G);
   for (int r = G.t; r <= nrows; r += G.nt) rowptr[r] = (r * nchunk > 0) ? cnt[r * nchunk - 1] : 0;
   for (int e = G.t; e < ne; e += G.nt) {
@@ -136,7 +177,7 @@ __device__ void build_csr_multisplit_lds(const int* ek, const int* eo, int ne, i
     const int base = idx > 0 ? cnt[idx - 1] : 0;
     col[base + tmp[e]] = eo[e];
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float* dinv, const Grp& G) {
@@ -167,7 +208,7 @@ __global__ void __launch_bounds__(256) k_param_reduce(const float* __restrict__ 
     for (; g < g1; ++g) s += partials[(size_t)g * P + p];
   }
   red[sl][pl] = s;
-  __syncthreads();
+  lds_barrier();
   if (sl == 0 && p < P) {
     float t = 0.f;
 #pragma unroll

@@ -67,6 +67,8 @@ _SIGNATURES = {
                                   c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_bwd": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                   P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
+    "hscn_resident_fwd_with_virtual": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                                               c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_bwd_with_virtual": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                                c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
 }

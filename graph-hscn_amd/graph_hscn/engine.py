@@ -89,7 +89,10 @@ class _VirtualJob(ctypes.Structure):
                 ("ei_lv", ctypes.c_void_p), ("E_lv", ctypes.c_int64), ("vptr", ctypes.c_void_p),
                 ("eptr_vv", ctypes.c_void_p), ("eptr_lv", ctypes.c_void_p),
                 ("layer_params_host", ctypes.c_void_p), ("xv_out", ctypes.c_void_p), ("V", ctypes.c_int64),
-                ("max_v", ctypes.c_int32), ("max_evv", ctypes.c_int32), ("slope", ctypes.c_float)]
+                ("max_v", ctypes.c_int32), ("max_evv", ctypes.c_int32), ("slope", ctypes.c_float),
+                ("st_rowptr_lv", ctypes.c_void_p), ("st_col_lv", ctypes.c_void_p),
+                ("st_rowptr_vv", ctypes.c_void_p), ("st_col_vv", ctypes.c_void_p),
+                ("st_dinv_v", ctypes.c_void_p), ("st_xv", ctypes.c_void_p)]
 
 
 # final virtual features of the last step whose virtual branch rode on the backward launch (tests)
@@ -102,11 +105,13 @@ class HSCNResidentFn(Function):
     W1, b1, W2, b2.   cfg = (head_act code, slope, compute_virtual, keep_virtual, overlap).
 
     overlap: the virtual branch never feeds the prediction (reference model/hscn.py:111 pools
-    "local" only).  In a training step it therefore leaves the forward launch (local chain + head
-    only) and rides on the backward launch of the same step as extra workgroups
-    (hscn_resident_bwd_with_virtual), reading the local activations the forward stored.  Without a
-    backward to ride on (no_grad, or keep_virtual wanting the features right away) the one-launch
-    forward computes both branches.  Results are identical either way."""
+    "local" only), and a 128-graph batch occupies half of the CUs.  In a training step the branch
+    therefore leaves the critical path: its CSR builds and layer 0 (which reads input features only)
+    run as extra workgroups of the forward launch (hscn_resident_fwd_with_virtual), layers 1.. as
+    extra workgroups of the backward launch (hscn_resident_bwd_with_virtual), reading the local
+    activations the forward stored.  Without a backward to ride on (no_grad, or keep_virtual
+    wanting the features right away) the one-launch forward computes both branches.  Results are
+    identical either way."""
 
     @staticmethod
     def forward(ctx, x_local, x_virtual, ei_ll, ei_vv, ei_lv, meta: ResidentMeta, cfg, *params):
@@ -122,7 +127,7 @@ class HSCNResidentFn(Function):
         B = meta.num_graphs
         dev = x_local.device
         need_bwd = any(ctx.needs_input_grad[7:])   # False under no_grad
-        defer = bool(compute_virtual and overlap and V > 0 and need_bwd and not keep_virtual)
+        defer = bool(compute_virtual and overlap and V > 0 and need_bwd and not keep_virtual and L >= 2)
         acts = torch.empty(L, N, H, dtype=torch.float32, device=dev)
         pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
         z = torch.empty(B, H, dtype=torch.float32, device=dev)
@@ -134,15 +139,28 @@ class HSCNResidentFn(Function):
         csr_col = torch.empty(max(E_ll, 1), dtype=torch.int32, device=dev) if need_bwd else None
         dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev) if need_bwd else None
         table = _ptr_table(params[: 9 * L])
-        mode = 0 if (defer or not compute_virtual) else 1
-        call("hscn_resident_fwd", ptr(x_local), ptr(x_virtual), ptr(ei_ll), ei_ll.size(1), ptr(ei_vv),
-             ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll),
-             ptr(meta.eptr_vv), ptr(meta.eptr_lv), N, V, B, F, H, L, C, head_act, float(slope), table,
-             ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_v, meta.max_ell, meta.max_evv,
-             mode, ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(csr_rp), ptr(csr_col), ptr(dinv),
-             ptr(meta.flag), stream())
-        # what the backward launch needs to run the virtual branch beside itself
-        ctx.virtual = (x_virtual, ei_vv, ei_lv, params[: 9 * L], table, float(slope)) if defer else None
+        ctx.virtual = None
+        if defer:
+            E_lv, E_vv = ei_lv.size(1), ei_vv.size(1)
+            state = (torch.empty(V + B, dtype=torch.int32, device=dev), torch.empty(max(E_lv, 1), dtype=torch.int32, device=dev),
+                     torch.empty(V + B, dtype=torch.int32, device=dev), torch.empty(max(E_vv, 1), dtype=torch.int32, device=dev),
+                     torch.empty(V, dtype=torch.float32, device=dev), torch.empty(V, H, dtype=torch.float32, device=dev))
+            job = _VirtualJob(ptr(x_virtual), ptr(ei_vv), E_vv, ptr(ei_lv), E_lv, ptr(meta.vptr), ptr(meta.eptr_vv),
+                              ptr(meta.eptr_lv), ctypes.cast(table, ctypes.c_void_p), None, V, meta.max_v,
+                              meta.max_evv, float(slope), *[ptr(t) for t in state])
+            call("hscn_resident_fwd_with_virtual", ptr(x_local), ptr(ei_ll), E_ll, ptr(meta.lptr), ptr(meta.eptr_ll),
+                 N, B, F, H, L, C, head_act, table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_ell,
+                 ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(meta.flag),
+                 ctypes.byref(job), stream())
+            # what the backward launch needs to run the rest of the virtual branch beside itself
+            ctx.virtual = (x_virtual, ei_vv, ei_lv, params[: 9 * L], table, float(slope), state)
+        else:
+            call("hscn_resident_fwd", ptr(x_local), ptr(x_virtual), ptr(ei_ll), ei_ll.size(1), ptr(ei_vv),
+                 ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll),
+                 ptr(meta.eptr_vv), ptr(meta.eptr_lv), N, V, B, F, H, L, C, head_act, float(slope), table,
+                 ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_v, meta.max_ell, meta.max_evv,
+                 int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(csr_rp),
+                 ptr(csr_col), ptr(dinv), ptr(meta.flag), stream())
         ctx.meta, ctx.head_act, ctx.dims = meta, head_act, (N, F, H, L, C, B)
         ctx.csr = (csr_rp, csr_col, dinv)
         ctx.save_for_backward(x_local, ei_ll, acts, pooled, z, W1, W2, *[params[9 * l] for l in range(L)])
@@ -172,12 +190,12 @@ class HSCNResidentFn(Function):
                 ptr(grads), ptr(meta.flag))
         if ctx.virtual is not None:
             global last_deferred_virtual
-            x_virtual, ei_vv, ei_lv, _keep, vtable, slope = ctx.virtual
+            x_virtual, ei_vv, ei_lv, _keep, vtable, slope, state = ctx.virtual
             V = x_virtual.shape[0]
             xv = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev)
             job = _VirtualJob(ptr(x_virtual), ptr(ei_vv), ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.vptr),
                               ptr(meta.eptr_vv), ptr(meta.eptr_lv), ctypes.cast(vtable, ctypes.c_void_p), ptr(xv),
-                              V, meta.max_v, meta.max_evv, slope)
+                              V, meta.max_v, meta.max_evv, slope, *[ptr(t) for t in state])
             call("hscn_resident_bwd_with_virtual", *args, ctypes.byref(job), stream())
             last_deferred_virtual = xv
             ctx.virtual = None

@@ -331,7 +331,27 @@ typedef struct hscn_virtual_job {
   int64_t V;
   int32_t max_v, max_evv;
   float slope;                         /* GAT leaky-ReLU slope */
+  /* Optional split of the virtual branch over the two launches of a step (all six NULL = the
+   * backward launch runs the whole branch).  hscn_resident_fwd_with_virtual builds the virtual
+   * relations' CSRs and runs layer 0 (which reads only input features) beside the local chain and
+   * leaves this state; hscn_resident_bwd_with_virtual resumes at layer 1 from it. */
+  int32_t* st_rowptr_lv;               /* [V+B]  (graph g: at vptr[g]+g) */
+  int32_t* st_col_lv;                  /* [E_lv] local node ids, graph g at eptr_lv[g] */
+  int32_t* st_rowptr_vv;               /* [V+B] */
+  int32_t* st_col_vv;                  /* [E_vv] */
+  float* st_dinv_v;                    /* [V] in-degree^-1/2 of the vv relation */
+  float* st_xv;                        /* [V,H] virtual features after layer 0 */
 } hscn_virtual_job;
+/* hscn_resident_fwd with compute_virtual = 0 (local chain + head, CSR export) whose launch also
+ * carries, as odd workgroups, the first part of the virtual branch described by `job` (state
+ * pointers required, L >= 2).  Pair it with hscn_resident_bwd_with_virtual on the same job. */
+int hscn_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                                   const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
+                                   int head_act, const void* const* layer_params_host, const float* W1,
+                                   const float* b1, const float* W2, const float* b2, int max_n, int max_ell,
+                                   float* acts, float* pooled, float* z, float* pred, int32_t* csr_rowptr_t,
+                                   int32_t* csr_col_t, float* dinv, int32_t* flag, const hscn_virtual_job* job,
+                                   void* stream);
 int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                                    const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
                                    int head_act, const void* const* W_ll_host, const float* W1, const float* W2,
