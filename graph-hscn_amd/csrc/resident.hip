@@ -375,21 +375,29 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   const int64_t *pwd = (cv && A.vv_dst) ? A.vv_dst : dummy, *pws = (cv && A.vv_src) ? A.vv_src : dummy;
   long long rld[EPT], rls[EPT], rvd[EPT], rvs[EPT], rwd[EPT], rws[EPT];
   float xr[XPT], xvr[2], hw0 = 0.f, hw1 = 0.f;
+  // a wave whose whole 64-element slice lies past the end of an array skips the request (scalar
+  // branch on the wave's first index): the vector-memory pipe of the CU sees only useful requests
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     const int e = threadIdx.x + i * RT;
+    const int eb = wbase + i * RT;
     const bool o1 = e < ne && A.ll_dst, o2 = cv && e < nel && A.lv_dst, o3 = cv && e < nev && A.vv_dst;
-    rld[i] = pld[o1 ? e0 + e : 0]; rls[i] = pls[o1 ? e0 + e : 0];
-    rvd[i] = pvd[o2 ? el0 + e : 0]; rvs[i] = pvs[o2 ? el0 + e : 0];
-    rwd[i] = pwd[o3 ? ev0 + e : 0]; rws[i] = pws[o3 ? ev0 + e : 0];
+    rld[i] = 0; rls[i] = 0; rvd[i] = 0; rvs[i] = 0; rwd[i] = 0; rws[i] = 0;
+    if (eb < ne) { rld[i] = pld[o1 ? e0 + e : 0]; rls[i] = pls[o1 ? e0 + e : 0]; }
+    if (cv && eb < nel) { rvd[i] = pvd[o2 ? el0 + e : 0]; rvs[i] = pvs[o2 ? el0 + e : 0]; }
+    if (cv && eb < nev) { rwd[i] = pwd[o3 ? ev0 + e : 0]; rws[i] = pws[o3 ? ev0 + e : 0]; }
   }
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int idx = threadIdx.x + i * RT;
     const int r = idx / H, k = idx - r * H;
     const bool ok = idx < n * H && k < F;
-    const float t = A.x_local[ok ? (size_t)(n0 + r) * F + k : 0];
-    xr[i] = ok ? t : 0.f;
+    xr[i] = 0.f;
+    if (wbase + i * RT < n * H) {
+      const float t = A.x_local[ok ? (size_t)(n0 + r) * F + k : 0];
+      xr[i] = ok ? t : 0.f;
+    }
   }
   const float* pxv = (cv && A.x_virtual) ? A.x_virtual : A.x_local;
 #pragma unroll
@@ -397,8 +405,11 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     const int idx = threadIdx.x + i * RT;
     const int r = idx / H, k = idx - r * H;
     const bool ok = cv && idx < nv * H && k < F;
-    const float t = pxv[ok ? (size_t)(v0 + r) * F + k : 0];
-    xvr[i] = ok ? t : 0.f;
+    xvr[i] = 0.f;
+    if (cv && wbase + i * RT < nv * H) {
+      const float t = pxv[ok ? (size_t)(v0 + r) * F + k : 0];
+      xvr[i] = ok ? t : 0.f;
+    }
   }
   // head weights: W1 [H][H] | b1 [H] | W2 [C][H] | b2 [C]   (natural layout)
   constexpr int HPT = (H * H + RT - 1) / RT;
@@ -916,7 +927,7 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd_pair(const FwdArgs Al, const Fw
 
 // =============================== backward =====================================================
 struct BwdLayout {
-  size_t G, GH, X, dinv, vec, red, wl, headw, rowptr_t, col_t, total;
+  size_t G, GH, X, dinv, vec, red, bred, wl, headw, rowptr_t, col_t, total;
 };
 __host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max_ell) {
   BwdLayout Y;
@@ -927,7 +938,8 @@ __host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max
   Y.X = take((size_t)max_n * H);
   Y.dinv = take(max_n);
   Y.vec = take(256 + 64);
-  Y.red = take((size_t)RT_MAX);  // per pass: NW waves x 4 tiles x 16 entries
+  Y.red = take((size_t)(RT_MAX / 64) * 256);  // weight gradient: one 16 x 16 partial tile per wave
+  Y.bred = take((size_t)(RT_MAX / 64) * H);    // bias gradient: one H-vector per wave
   Y.wl = take((size_t)H * H);
   Y.headw = take((size_t)H * H + (size_t)C * H + C);  // W1 | W2 | g_pred row
   Y.rowptr_t = take(max_n + 1);
@@ -953,7 +965,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   float *G = fb + Y.G, *GH = fb + Y.GH, *X = fb + Y.X, *dinv = fb + Y.dinv, *vec = fb + Y.vec;
-  float *red = fb + Y.red, *wl = fb + Y.wl, *headw = fb + Y.headw;
+  float *red = fb + Y.red, *bred = fb + Y.bred, *wl = fb + Y.wl, *headw = fb + Y.headw;
   int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
   const int L = A.L;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1096,12 +1108,34 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
       const int idx = threadIdx.x + i * RT;
       wr_[i] = (l > 0 && idx < H * H) ? A.W_ll[l][idx] : 0.f;
     }
-    // bias gradient: wave per feature column, lanes split the rows, wave fold
-    for (int f = wave; f < H; f += NW) {
-      float s = 0.f;
-      for (int i = lane; i < n; i += 64) s += G[i * H + f];
-      s = wave_sum(s);
-      if (lane == 0) part[ob + f] = s;
+    // bias gradient = column sums of G: a lane adds float4 pieces of a strided row set (consecutive
+    // lanes read consecutive 16 B: no bank conflicts), the slots of a wave fold through DPP /
+    // bpermute, the waves through LDS after the phase barrier (in wave order)
+    {
+      constexpr int LQ = H / 4 > 64 ? 64 : H / 4;
+      constexpr int SQ = 64 / LQ;
+      const int slot = lane / LQ, f = (lane % LQ) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = wave * SQ + slot; i < n; i += NW * SQ) {
+        const float4 v = *reinterpret_cast<const float4*>(G + i * H + f);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+#pragma unroll
+      for (int o_ = 32; o_ >= 16 && o_ >= LQ; o_ >>= 1) {
+        acc.x += __shfl_xor(acc.x, o_, 64);
+        acc.y += __shfl_xor(acc.y, o_, 64);
+        acc.z += __shfl_xor(acc.z, o_, 64);
+        acc.w += __shfl_xor(acc.w, o_, 64);
+      }
+      if (LQ <= 8) {
+        acc.x = row_ror_add<8>(acc.x); acc.y = row_ror_add<8>(acc.y);
+        acc.z = row_ror_add<8>(acc.z); acc.w = row_ror_add<8>(acc.w);
+      }
+      if (LQ <= 4) {
+        acc.x = row_ror_add<4>(acc.x); acc.y = row_ror_add<4>(acc.y);
+        acc.z = row_ror_add<4>(acc.z); acc.w = row_ror_add<4>(acc.w);
+      }
+      if (slot == 0) *reinterpret_cast<float4*>(bred + wave * H + f) = acc;
     }
     // dL/d(transform output) = A_hat^T G  (transposed CSR, edge order)
     agg_gcn_lds<H>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, nullptr, ALL);
@@ -1121,59 +1155,53 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     }
     lds_barrier();
     STAMP(4 + 4 * l);
-    // weight gradient gW[o][k] = sum_j GH[j][o] * X[j][k]: 4x4 tiles of (o,k); a 16-lane DPP row
-    // owns a tile, its lanes and NRG wave-groups split the rows; 16 register accumulators per
-    // lane, DPP row fold, then the NRG partials are folded in order through LDS.
+    if (threadIdx.x < H) {   // bias gradient: fold the waves' column sums in wave order
+      float sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sb += bred[w * H + threadIdx.x];
+      part[ob + threadIdx.x] = sb;
+    }
+    // weight gradient gW[o][k] = sum_j GH[j][o] * X[j][k] = GH^T X on the matrix cores
+    // (v_mfma_f32_16x16x4_f32, fp32 in and out): a wave owns one 16 x 16 tile (o, k) and a strided
+    // set of 4-row chunks of j; A[o][j] and B[j][k] are single LDS words per lane, consecutive lanes
+    // on consecutive addresses.  The waves that share a tile fold their partial tiles through LDS
+    // in a fixed order.
     {
-      constexpr int TPD = H / 4;            // tiles per dimension
-      constexpr int NT = TPD * TPD;         // tiles
-      constexpr int TPW = 4;                // tiles per wave (one per DPP row)
-      const int row = lane >> 4, l16 = lane & 15;
-      const int ntg = (NT + TPW - 1) / TPW;                 // tile groups
-      const int NRG = NW / ntg > 0 ? (NW / ntg > 4 ? 4 : NW / ntg) : 1;  // row groups (waves per tile group)
-      for (int tg0 = 0; tg0 < ntg; tg0 += NW / NRG) {
-        const int tg = tg0 + wave / NRG, rg = wave % NRG;
-        const int tile = tg * TPW + row;
-        const bool live = tg < ntg && tile < NT && wave < (NW / NRG) * NRG;
-        float acc[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-        const int o4 = live ? (tile / TPD) * 4 : 0, k4 = live ? (tile % TPD) * 4 : 0;
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      constexpr int TD = H / 16;                       // tiles per dimension
+      constexpr int NT = TD * TD;
+      constexpr int TPP = NT < NW ? NT : NW;           // tiles per pass
+      constexpr int RG = NW / TPP;                     // waves (row groups) per tile
+      const int li = lane & 15, lj = lane >> 4;
+      for (int t0 = 0; t0 < NT; t0 += TPP) {
+        const int tl = wave % TPP, rg = wave / TPP;
+        const int tile = t0 + tl;
+        const bool live = tile < NT && rg < RG;
+        const int o0 = live ? (tile / TD) * 16 : 0, k0 = live ? (tile % TD) * 16 : 0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (live) {
-          for (int j = rg * 16 + l16; j < n; j += 16 * NRG) {
-            const float4 gv = *reinterpret_cast<const float4*>(GH + j * H + o4);
-            const float4 xv = *reinterpret_cast<const float4*>(X + j * H + k4);
-            const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
-            const float xb[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-              for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(ga[a], xb[b], acc[a][b]);
+          for (int j0 = rg * 4; j0 < n; j0 += 4 * RG) {
+            const int j = j0 + lj;
+            const bool ok = j < n;
+            const float av = ok ? GH[j * H + o0 + li] : 0.f;
+            const float bv = ok ? X[j * H + k0 + li] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(rg * TPP + tl) * 256 + (lj * 4 + r) * 16 + li] = acc[r];
         }
-        float mine = 0.f;  // after the row fold lane l16 keeps entry (a,b) = (l16>>2, l16&3)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const float v = row16_sum(acc[a][b]);
-            if (l16 == a * 4 + b) mine = v;
-          }
-        const int tpp = (NW / NRG) * TPW;  // tiles per pass
-        if (live) red[(rg * tpp + (tile - tg0 * TPW)) * 16 + l16] = mine;
         lds_barrier();
-        for (int idx = threadIdx.x; idx < (NW / NRG) * TPW * 16; idx += RT) {
-          const int t_ = tg0 * TPW + idx / 16, e_ = idx & 15;
+        for (int idx = threadIdx.x; idx < TPP * 256; idx += RT) {
+          const int t_ = t0 + idx / 256, e_ = idx & 255;
           if (t_ < NT) {
-            float s = 0.f;
-            for (int r = 0; r < NRG; ++r) s += red[(r * tpp + idx / 16) * 16 + e_];
-            const int oo = (t_ / TPD) * 4 + (e_ >> 2), kk = (t_ % TPD) * 4 + (e_ & 3);
-            if (kk < fin) part[oW + oo * fin + kk] = s;
+            float s_ = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) s_ += red[(r * TPP + idx / 256) * 256 + e_];
+            const int oo = (t_ / TD) * 16 + (e_ >> 4), kk = (t_ % TD) * 16 + (e_ & 15);
+            if (kk < fin) part[oW + oo * fin + kk] = s_;
           }
         }
-        lds_barrier();
+        if (t0 + TPP < NT) lds_barrier();   // the partial-tile buffer is reused by the next pass
       }
     }
     STAMP(5 + 4 * l);
