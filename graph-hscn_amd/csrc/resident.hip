@@ -97,26 +97,34 @@ struct WStage {
   float v[5];
   // One uniform base pointer per matrix / vector (no per-lane pointer table lookups), clamped
   // addresses + select instead of branches: every request of the prefetch is issued back to back.
-  __device__ __forceinline__ void fetch(const LayerP& P, bool cv, int fin) {
-    const float* mats[4] = {P.W_ll, cv ? P.W_src : P.W_ll, cv ? P.W_dst : P.W_ll, cv ? P.W_vv : P.W_ll};
-    const float* vecs[5] = {P.b_ll, cv ? P.b_vv : P.b_ll, cv ? P.b_gat : P.b_ll, cv ? P.att_src : P.b_ll,
-                            cv ? P.att_dst : P.b_ll};
+  // ll: the local->local matrix / bias are wanted; cv: the virtual branch's are.  What a launch does
+  // not use is not requested (uniform branches: no request reaches the memory pipe).
+  __device__ __forceinline__ void fetch(const LayerP& P, bool ll, bool cv, int fin) {
+    const float* mats[4] = {P.W_ll, P.W_src, P.W_dst, P.W_vv};
+    const float* vecs[5] = {P.b_ll, P.b_vv, P.b_gat, P.att_src, P.att_dst};
 #pragma unroll
     for (int mm = 0; mm < 4; ++mm) {
 #pragma unroll
-      for (int i = 0; i < MPT; ++i) {
-        const int d = threadIdx.x + i * RT;       // destination slot k*H + o (transposed)
-        const int k = d / H, o = d - k * H;
-        const bool ok = d < H * H && k < fin && (mm == 0 || cv);
-        const float t = mats[mm][ok ? o * fin + k : 0];
-        m[mm][i] = ok ? t : 0.f;
+      for (int i = 0; i < MPT; ++i) m[mm][i] = 0.f;
+      if (mm == 0 ? ll : cv) {
+#pragma unroll
+        for (int i = 0; i < MPT; ++i) {
+          const int d = threadIdx.x + i * RT;       // destination slot k*H + o (transposed)
+          const int k = d / H, o = d - k * H;
+          const bool ok = d < H * H && k < fin;
+          const float t = mats[mm][ok ? o * fin + k : 0];
+          m[mm][i] = ok ? t : 0.f;
+        }
       }
     }
     const int t_ = threadIdx.x < H ? threadIdx.x : 0;
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-      const float t = vecs[q][t_];
-      v[q] = (threadIdx.x < H && (q == 0 || cv)) ? t : 0.f;
+      v[q] = 0.f;
+      if (q == 0 ? ll : cv) {
+        const float t = vecs[q][t_];
+        v[q] = threadIdx.x < H ? t : 0.f;
+      }
     }
   }
   __device__ __forceinline__ void store(float* dst) const {
@@ -181,6 +189,48 @@ __device__ void lin_blk(const float* X, const float* Wt, float* Y, int n, const 
       for (int off = LPR >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
       if (og == 0) a_out[i] = d;
     }
+  }
+}
+
+// ---- the same product on the matrix cores: Y[n][H] = X[n][H] * Wt[H][H] (Wt[k][o], fp32) ---------
+// v_mfma_f32_16x16x4_f32: a wave owns 16-row tiles; A[row][k] is one LDS word per lane per k-step,
+// B[k][o] (the weights) stays in registers for all of the wave's tiles.  MASK: multiply the result
+// by relu'(M[row][o]) (the backward's input gradient).  k runs in ascending order as in lin_blk.
+template <int H, bool MASK>
+__device__ void lin_mfma(const float* X, const float* Wt, float* Y, int n, const float* M, const Grp& G) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int TD = H / 16, KS = H / 4;
+  const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int ntile = (n + 15) >> 4;
+  if (G.w >= ntile) return;
+  float b[TD][KS];
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[ct][s] = Wt[(4 * s + lj) * H + ct * 16 + li];
+  for (int rt = G.w; rt < ntile; rt += G.nw) {
+    const int r0 = rt * 16;
+    const bool ok = r0 + li < n;
+    const float* xr = X + (r0 + li) * H + lj;
+    f32x4 acc[TD];
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float a = ok ? xr[4 * s] : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < TD; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[ct][s], acc[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + lj * 4 + r;
+        if (row < n) {
+          const int idx = row * H + ct * 16 + li;
+          Y[idx] = MASK ? (M[idx] > 0.f ? acc[ct][r] : 0.f) : acc[ct][r];
+        }
+      }
   }
 }
 
@@ -342,19 +392,14 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       const int v = base + lane;
       const int sz = v < nv ? rowptr_lv[v + 1] - rowptr_lv[v] : 0;
       const int cnt = v < nv ? (sz > 64 ? (sz + 63) >> 6 : 1) : 0;
-      int incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t_ = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t_;
-      }
+      const int incl = wave_incl_scan(cnt);
       const int first = carry + incl - cnt;
       if (v < nv) {
         ck_first[v] = first;
         ck_arrive[v] = 0;
         for (int c = 0; c < cnt; ++c) ck_tab[first + c] = (v << 8) | c;
       }
-      carry += __shfl(incl, 63, 64);
+      carry += __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) ck_first[nv] = carry;
   };
@@ -364,7 +409,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   WStage<H, RT> ws;
   const bool resume = vonly && A.l_begin > 0;
   if (!resume) {
-  ws.fetch(A.layer[0], cv, F);
+  ws.fetch(A.layer[0], !vonly, cv, F);
   constexpr int EPT = 2;   // edges per thread held in registers (covers RT*EPT edges per relation)
   constexpr int XPT = 8;   // feature words per thread held in registers
   // raw 64-bit ids first (clamped addresses, no arithmetic on the results yet): all requests of the
@@ -559,7 +604,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   } else {
     // ---- resumed virtual branch: the structure and the virtual features come from the state the
     // first part of this step exported, the local rows from the previous layer's activations
-    ws.fetch(A.layer[A.l_begin], true, H);
+    ws.fetch(A.layer[A.l_begin], false, true, H);
     const float4* src = reinterpret_cast<const float4*>(A.acts + ((size_t)(A.l_begin - 1) * A.N + n0) * H);
     for (int i = threadIdx.x; i < n * (H / 4); i += RT) reinterpret_cast<float4*>(xa)[i] = src[i];
     for (int i = threadIdx.x; i < nv * H; i += RT) xva[i] = A.vs_xv[(size_t)v0 * H + i];
@@ -588,9 +633,12 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     const float* att_d = b_ll + 4 * H;
     const bool more = l + 1 < A.l_end;
     // fetch the next layer's weights now, park them in LDS under this layer's math
-    if (more && DB) ws.fetch(A.layer[l + 1], cv, H);
+    if (more && DB) ws.fetch(A.layer[l + 1], !vonly, cv, H);
     STAMP(4 + 4 * l);
-    auto transforms_ll = [&](const Grp& G_) { lin_blk<H, OPT>(xa, W, bh, n, nullptr, nullptr, G_); };
+    auto transforms_ll = [&](const Grp& G_) {
+      if (H <= 32) lin_mfma<H, false>(xa, W, bh, n, nullptr, G_);
+      else lin_blk<H, OPT>(xa, W, bh, n, nullptr, nullptr, G_);
+    };
     // virtual-only launch: layer l+1 reads the local activations the local launch stored
     auto load_next_local = [&](const Grp& G_, float* to) {
       if (!more) return;
@@ -805,14 +853,17 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         lds_barrier();
       }
       if (!vonly) transforms_ll(ALL);
+      STAMP_T(41 + 4 * l, 0);
       if (more && DB) ws.store(Wn);
+      STAMP_T(40 + 4 * l, 0);
       lds_barrier();
       STAMP(5 + 4 * l);
       if (vonly) load_next_local(ALL, xa); else reduce_ll(ALL);
+      STAMP_T(43 + 4 * l, 0);
       lds_barrier();
     }
     if (more && !DB) {  // single weight buffer: everybody is done with it now
-      ws.fetch(A.layer[l + 1], cv, H);
+      ws.fetch(A.layer[l + 1], !vonly, cv, H);
       ws.store(Wn);
       lds_barrier();
     }
@@ -1207,7 +1258,9 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     STAMP(5 + 4 * l);
     // input gradient: G[j][k] = relu'(x_l[j][k]) * sum_o GH[j][o] * W[o][k]   (W is [H][H] here;
     // x_l = this layer's input = previous layer's output, already in X)
-    if (l > 0) {
+    if (l > 0 && H <= 32) {
+      lin_mfma<H, true>(GH, wl, G, n, X, ALL);
+    } else if (l > 0) {
       constexpr int LPR = H / OPT;
       constexpr int RS = RT / LPR;
       const int kg = threadIdx.x % LPR, r0 = threadIdx.x / LPR;

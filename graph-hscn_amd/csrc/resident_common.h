@@ -79,6 +79,19 @@ __device__ __forceinline__ float row_ror_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + OFF, 0xF, 0xF, true));
 }
 
+// inclusive scan over the 64 lanes of a fully active wave: Hillis-Steele inside the four DPP rows
+// (row_shr, zeros shifted in), then the three row totals through readlane.  VALU only.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31);
+  const int t2 = __builtin_amdgcn_readlane(v, 47);
+  const int row = (threadIdx.x & 63) >> 4;
+  return v + (row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2)));
+}
+
 // ---- group inclusive scan of a[0..n) in LDS, in place (two workgroup barriers) -----------------
 __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp& G) {
   const int per = (n + G.nt - 1) / G.nt;
@@ -87,12 +100,7 @@ __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp&
   for (int i = 0; i < per; ++i)
     if (b + i < n) s += a[b + i];
   const int lane = threadIdx.x & 63;
-  int incl = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
+  const int incl = wave_incl_scan(s);
   if (lane == 63) wsum[G.w] = incl;
   lds_barrier();
   int off = 0;

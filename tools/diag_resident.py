@@ -71,6 +71,15 @@ def main():
     st = buf.cpu().numpy()
     show(st, 2 * rows, {**fn, 63: "pool+head"}, fkeys + [63], 63, "fwd local chain (even blocks of the forward launch)")
     show(st, 2 * rows + 1, fn, fkeys, 62, "virtual part 1: CSRs + layer 0 (odd blocks of the forward launch)")
+    lr = 2 * rows
+    tot = st[lr, 63] - st[lr, 0]
+    for tag, i in (("slowest", np.argsort(tot)[-1]), ("median", np.argsort(tot)[len(tot) // 2])):
+        r = lr[i]
+        print(f"--- local chain {tag} n={sizes[i]}: per layer, cycles since the layer's begin stamp")
+        for l in range(3):
+            b0 = st[r, 4 + 4 * l]
+            print(f"   L{l}: wave0 transforms done {st[r, 41 + 4 * l] - b0:6d} | weights parked {st[r, 40 + 4 * l] - b0:6d} | barrier {st[r, 5 + 4 * l] - b0:6d} | "
+                  f"wave0 reduce done {st[r, 43 + 4 * l] - b0:6d} | layer end {st[r, 6 + 4 * l] - b0:6d}")
     buf.zero_()
     out.sum().backward()
     torch.cuda.synchronize()
