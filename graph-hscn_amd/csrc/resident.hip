@@ -77,6 +77,7 @@ struct BwdArgs {
   const float* W_ll[MAXL];
   const float *W1, *W2;
   const float *acts, *pooled, *z, *g_pred;
+  const float* g_scale;  // optional device scalar: the upstream gradient is g_scale[0] * g_pred
   const int32_t *csr_rowptr_t, *csr_col_t;  // from the forward launch
   const float* dinv_in;
   float* partials;  // [B][P]
@@ -1065,9 +1066,13 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     const int idx = threadIdx.x + i * RT;
     yr[i] = yL[idx < n * H ? idx : 0];
   }
+  const float gs = A.g_scale ? A.g_scale[0] : 1.f;
+  const bool scaled = A.g_scale != nullptr;
+  // (the last C words are the upstream gradient row: the loss node's scalar factor is applied here)
+  auto hval = [&](int idx, float v) { return (scaled && idx >= HT - A.C) ? gs * v : v; };
   hw0 = *haddr((int)threadIdx.x < HT ? (int)threadIdx.x : 0);
   hw1 = *haddr((int)threadIdx.x + RT < HT ? (int)threadIdx.x + RT : 0);
-  for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = *haddr(idx);
+  for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = hval(idx, *haddr(idx));
   zv = A.z[(size_t)g * H + (threadIdx.x < H ? threadIdx.x : 0)];
   pv = A.pooled[(size_t)g * H + (threadIdx.x < H ? threadIdx.x : 0)];
   // ---- park in LDS ----------------------------------------------------------------------------
@@ -1092,8 +1097,8 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     if (idx < n * H) X[idx] = yr[i];
   }
   for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) X[idx] = yL[idx];
-  if ((int)threadIdx.x < HT) headw[threadIdx.x] = hw0;
-  if ((int)threadIdx.x + RT < HT) headw[threadIdx.x + RT] = hw1;
+  if ((int)threadIdx.x < HT) headw[threadIdx.x] = hval((int)threadIdx.x, hw0);
+  if ((int)threadIdx.x + RT < HT) headw[threadIdx.x + RT] = hval((int)threadIdx.x + RT, hw1);
   if (threadIdx.x < H) {
     zz[threadIdx.x] = zv;
     pol[threadIdx.x] = pv;
@@ -1543,9 +1548,9 @@ int launch_fwd_pair(FwdArgs& Al, FwdArgs& Av, int64_t B, hipStream_t st) {
 int fill_bwd_args(BwdArgs& A, const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                   const int32_t* eptr_ll, int64_t N, int F, int H, int L, int C, int head_act,
                   const void* const* W_ll_host, const float* W1, const float* W2, const float* acts,
-                  const float* pooled, const float* z, const float* g_pred, const int32_t* csr_rowptr_t,
-                  const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell, float* partials,
-                  float* grads, int32_t* flag) {
+                  const float* pooled, const float* z, const float* g_pred, const float* g_scale,
+                  const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
+                  float* partials, float* grads, int32_t* flag) {
   if (!x_local || !lptr || !eptr_ll || !W_ll_host || !W1 || !W2 || !acts || !pooled || !z || !g_pred ||
       !partials || !grads || !csr_rowptr_t || !dinv || (E_ll > 0 && !csr_col_t))
     return HSCN_E_BADARG;
@@ -1555,7 +1560,7 @@ int fill_bwd_args(BwdArgs& A, const float* x_local, const int64_t* ei_ll, int64_
     if (!W_ll_host[l]) return HSCN_E_BADARG;
     A.W_ll[l] = (const float*)W_ll_host[l];
   }
-  A.W1 = W1; A.W2 = W2; A.acts = acts; A.pooled = pooled; A.z = z; A.g_pred = g_pred;
+  A.W1 = W1; A.W2 = W2; A.acts = acts; A.pooled = pooled; A.z = z; A.g_pred = g_pred; A.g_scale = g_scale;
   A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_in = dinv;
   A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_ell = max_ell; A.P = (int)hscn_resident_param_count(F, H, L, C);
@@ -1616,16 +1621,16 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
 int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                       const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
                       const void* const* W_ll_host /* L */, const float* W1, const float* W2, const float* acts,
-                      const float* pooled, const float* z, const float* g_pred, const int32_t* csr_rowptr_t,
-                      const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
-                      float* partials /*[B][P]*/, float* grads /*[P]*/, int32_t* flag, void* stream_) {
+                      const float* pooled, const float* z, const float* g_pred, const float* g_scale,
+                      const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv, int max_n,
+                      int max_ell, float* partials /*[B][P]*/, float* grads /*[P]*/, int32_t* flag, void* stream_) {
   if (B < 0 || N < 0) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, 0, max_ell, 0)) return HSCN_E_UNSUPPORTED;
   BwdArgs A;
   if (int rc0 = fill_bwd_args(A, x_local, ei_ll, E_ll, lptr, eptr_ll, N, F, H, L, C, head_act, W_ll_host, W1, W2,
-                              acts, pooled, z, g_pred, csr_rowptr_t, csr_col_t, dinv, max_n, max_ell, partials,
-                              grads, flag))
+                              acts, pooled, z, g_pred, g_scale, csr_rowptr_t, csr_col_t, dinv, max_n, max_ell,
+                              partials, grads, flag))
     return rc0;
   hipStream_t st = hscn_stream(stream_);
   int rc = HSCN_E_UNSUPPORTED;
@@ -1644,16 +1649,16 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
                                    int head_act, const void* const* W_ll_host, const float* W1, const float* W2,
                                    const float* acts, const float* pooled, const float* z, const float* g_pred,
-                                   const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv,
-                                   int max_n, int max_ell, float* partials, float* grads, int32_t* flag,
-                                   const hscn_virtual_job* job, void* stream_) {
+                                   const float* g_scale, const int32_t* csr_rowptr_t, const int32_t* csr_col_t,
+                                   const float* dinv, int max_n, int max_ell, float* partials, float* grads,
+                                   int32_t* flag, const hscn_virtual_job* job, void* stream_) {
   if (B < 0 || N < 0 || !job) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, job->max_v, max_ell, job->max_evv)) return HSCN_E_UNSUPPORTED;
   BwdArgs Ab;
   if (int rc0 = fill_bwd_args(Ab, x_local, ei_ll, E_ll, lptr, eptr_ll, N, F, H, L, C, head_act, W_ll_host, W1,
-                              W2, acts, pooled, z, g_pred, csr_rowptr_t, csr_col_t, dinv, max_n, max_ell,
-                              partials, grads, flag))
+                              W2, acts, pooled, z, g_pred, g_scale, csr_rowptr_t, csr_col_t, dinv, max_n,
+                              max_ell, partials, grads, flag))
     return rc0;
   FwdArgs Af;
   if (int rc1 = fill_fwd_args(Af, x_local, job->x_virtual, nullptr, 0, job->ei_vv, job->E_vv, job->ei_lv,

@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -66,11 +66,11 @@ _SIGNATURES = {
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P, P, P, c_int,
                                   c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_bwd": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
-                                  P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
+                                  P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "hscn_resident_fwd_with_virtual": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                                c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_bwd_with_virtual": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int,
-                                               c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+                                               c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
 }
 
 
@@ -111,6 +111,8 @@ def ptr(t: Optional[torch.Tensor]):
     """Device pointer of a contiguous tensor (None -> NULL)."""
     if t is None:
         return None
+    if hasattr(t, "materialize"):      # loss.LazyScaled reaching an operator that wants plain values
+        t = t.materialize()
     if not t.is_cuda:
         raise RuntimeError(
             "graph_hscn operators take HIP device tensors only (got a CPU tensor): the hot path "

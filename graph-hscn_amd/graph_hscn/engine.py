@@ -182,11 +182,16 @@ class HSCNResidentFn(Function):
         P = int(_hip.lib().hscn_resident_param_count(F, H, L, C))
         partials = torch.empty(B, P, dtype=torch.float32, device=dev)
         grads = torch.empty(P, dtype=torch.float32, device=dev)
+        # the loss node hands its gradient over as (unscaled, scalar): the launch applies the scalar
+        from .loss import LazyScaled
+        g_scale = None
+        if isinstance(g_pred, LazyScaled):
+            g_pred, g_scale = g_pred.grad_unscaled, g_pred.scale
         g_pred = g_pred.contiguous()
         table = _ptr_table(list(W_ll))
         args = (ptr(x_local), ptr(ei_ll), ei_ll.size(1), ptr(meta.lptr), ptr(meta.eptr_ll), N, B,
                 F, H, L, C, ctx.head_act, table, ptr(W1), ptr(W2), ptr(acts), ptr(pooled), ptr(z), ptr(g_pred),
-                ptr(ctx.csr[0]), ptr(ctx.csr[1]), ptr(ctx.csr[2]), meta.max_n, meta.max_ell, ptr(partials),
+                ptr(g_scale), ptr(ctx.csr[0]), ptr(ctx.csr[1]), ptr(ctx.csr[2]), meta.max_n, meta.max_ell, ptr(partials),
                 ptr(grads), ptr(meta.flag))
         if ctx.virtual is not None:
             global last_deferred_virtual

@@ -11,6 +11,38 @@ from torch.autograd import Function
 from ._hip import call, ptr, stream
 
 
+class LazyScaled(torch.Tensor):
+    """``scale[0] * grad`` not yet multiplied out.  The loss node returns its input gradient in this
+    form; a consumer that can apply the scalar itself (the graph-resident HSCN backward takes it as
+    ``g_scale``) reads ``.grad_unscaled`` / ``.scale`` and no scaling launch happens; any other use
+    (an ordinary torch op, a hook, gradient accumulation) dispatches through ``materialize``."""
+
+    @staticmethod
+    def __new__(cls, grad, scale):
+        r = torch.Tensor._make_wrapper_subclass(cls, grad.shape, dtype=grad.dtype, device=grad.device,
+                                                requires_grad=False)
+        r.grad_unscaled = grad
+        r.scale = scale
+        r._dense = None
+        return r
+
+    def materialize(self) -> torch.Tensor:
+        if self._dense is None:
+            out = torch.empty_like(self.grad_unscaled)
+            call("hscn_scale", ptr(self.scale), ptr(self.grad_unscaled), ptr(out), out.numel(), stream())
+            self._dense = out
+        return self._dense
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        un = lambda t: t.materialize() if isinstance(t, LazyScaled) else t
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+    def __repr__(self):
+        return f"LazyScaled(shape={tuple(self.shape)})"
+
+
 class _CriterionFn(Function):
     @staticmethod
     def forward(ctx, pred, true, kind):
@@ -31,9 +63,7 @@ class _CriterionFn(Function):
         (grad,) = ctx.saved_tensors
         if g_loss is None:
             return None, None, None
-        out = torch.empty_like(grad)
-        call("hscn_scale", ptr(g_loss.reshape(1).contiguous()), ptr(grad), ptr(out), grad.numel(), stream())
-        return out, None, None
+        return LazyScaled(grad, g_loss.reshape(1).contiguous()), None, None
 
 
 def criterion(loss_fn: str, pred: torch.Tensor, true: torch.Tensor):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 1
+#define HSCN_ABI_VERSION 2
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -290,6 +290,8 @@ int hscn_scale(const float* g /*[1]*/, const float* x, float* y, int64_t count, 
  *     handed to the backward launch, which does not rebuild them (all three NULL = do not export)
  *   flag: bit 2 = an edge left its graph's node range, bit 4 = a graph exceeds
  *     max_n / max_v / max_ell / max_evv (the LDS budget the launch was sized for)
+ *   g_scale: optional device scalar; the upstream gradient is g_scale[0] * g_pred (the factor
+ *     the loss node would otherwise apply with a launch of its own, hscn_scale); NULL = 1
  * hscn_resident_bwd returns dL/d{W_ll, b_ll per layer, W1, b1, W2, b2} packed in
  * that order in grads[P] (P = hscn_resident_param_count); the virtual-branch
  * parameters receive no gradient, exactly as in the reference's autograd graph.
@@ -308,9 +310,9 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
 int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                       const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
                       const void* const* W_ll_host, const float* W1, const float* W2, const float* acts,
-                      const float* pooled, const float* z, const float* g_pred, const int32_t* csr_rowptr_t,
-                      const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
-                      float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+                      const float* pooled, const float* z, const float* g_pred, const float* g_scale /*[1] or NULL*/,
+                      const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv, int max_n,
+                      int max_ell, float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
 
 /* hscn_resident_bwd that also carries the virtual branch of the SAME step's forward: one launch
  * of 2B workgroups, even ones run the backward of graph g, odd ones what a compute_virtual = 2
@@ -356,9 +358,10 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
                                    int head_act, const void* const* W_ll_host, const float* W1, const float* W2,
                                    const float* acts, const float* pooled, const float* z, const float* g_pred,
-                                   const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv,
-                                   int max_n, int max_ell, float* partials /*[B,P]*/, float* grads /*[P]*/,
-                                   int32_t* flag, const hscn_virtual_job* job, void* stream);
+                                   const float* g_scale /*[1] or NULL*/, const int32_t* csr_rowptr_t,
+                                   const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
+                                   float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag,
+                                   const hscn_virtual_job* job, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * a2/a4/a6  stage A, graph-resident engine: the body of the reference's clustering loop

@@ -37,3 +37,51 @@ def test_stage_a_b_c_pipeline_runs_and_learns():
     hist = train(log, oc, tc, loaders, model)
     assert len(hist) == 3 and hist[-1][0] < hist[0][0]                              # loss goes down
     assert model.last_engine == "resident"
+
+
+def test_loss_gradient_scalar_is_applied_by_whoever_consumes_it():
+    """criterion's backward returns (unscaled gradient, scalar) as a LazyScaled tensor: the resident
+    backward applies the scalar in its launch, every other consumer sees the product.  All routes give
+    the gradients of the plain formulation, bit for bit where the arithmetic is the same."""
+    import numpy as np
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.data import HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.loss import LazyScaled, criterion
+    from graph_hscn.model.hscn import HSCN
+    dev = torch.device("cuda:0")
+    graphs = make_dataset("peptides_func", 6, seed=1)
+    rng = np.random.default_rng(0)
+    hb = HeteroBatch.from_data_list([hetero_from_clusters(g, rng.integers(0, 16, g.num_nodes), 16) for g in graphs]).to(dev)
+    torch.manual_seed(0)
+    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, 10, 3).to(dev)
+    y = (torch.rand(6, 10, device=dev) > 0.5).float()
+    res = {}
+    for eng in ("resident", "layered"):
+        for root in (None, 0.37):
+            model.engine = eng
+            model.zero_grad(set_to_none=True)
+            pred = model(hb.x_dict, hb.edge_index_dict, hb)
+            seen = []
+            pred.register_hook(lambda g: seen.append(type(g)))
+            loss, _ = criterion("cross_entropy", pred, y)
+            if root is None:
+                loss.backward()
+            else:
+                loss.backward(torch.tensor(root, device=dev))
+            assert seen and seen[0] is LazyScaled
+            res[(eng, root)] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    # reference: plain torch loss on the layered engine
+    for root in (None, 0.37):
+        model.engine = "layered"
+        model.zero_grad(set_to_none=True)
+        pred = model(hb.x_dict, hb.edge_index_dict, hb)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, y)
+        loss.backward() if root is None else loss.backward(torch.tensor(root, device=dev))
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        for eng in ("resident", "layered"):
+            got = res[(eng, root)]
+            assert got.keys() == ref.keys()
+            for n in ref:
+                assert torch.allclose(got[n], ref[n], atol=1e-6, rtol=1e-4), (eng, root, n)
