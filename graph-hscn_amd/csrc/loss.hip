@@ -7,32 +7,51 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_criterion(const float* __restrict__ pred, const float* __restrict__ target,
-                                                   int64_t count, int kind, float* __restrict__ loss,
-                                                   float* __restrict__ score, float* __restrict__ grad) {
-  __shared__ float red[4];
+// One workgroup of 16 waves; a thread requests its (up to four) elements of a 4096-element slab
+// before it computes any: a [128, 10] prediction is one memory round trip, not five.
+__global__ void __launch_bounds__(1024) k_criterion(const float* __restrict__ pred, const float* __restrict__ target,
+                                                    int64_t count, int kind, float* __restrict__ loss,
+                                                    float* __restrict__ score, float* __restrict__ grad) {
+  __shared__ float red[16];
   const float inv = 1.0f / (float)count;
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < count; i += 256) {
-    const float x = pred[i], y = target[i];
-    const float sg = 1.0f / (1.0f + expf(-x));
-    float l, g;
-    if (kind == 0) {  // BCE with logits: max(x,0) - x*y + log1p(exp(-|x|))
-      l = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
-      g = (sg - y) * inv;
-    } else {          // L1
-      const float d = x - y;
-      l = fabsf(d);
-      g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv;
+  for (int64_t base = 0; base < count; base += 4096) {
+    float xs[4], ys[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * 1024 + threadIdx.x;
+      xs[u] = pred[i < count ? i : 0];
+      ys[u] = target[i < count ? i : 0];
     }
-    s += l;
-    if (score) score[i] = sg;
-    grad[i] = g;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * 1024 + threadIdx.x;
+      if (i >= count) continue;
+      const float x = xs[u], y = ys[u];
+      const float sg = 1.0f / (1.0f + expf(-x));
+      float l, g;
+      if (kind == 0) {  // BCE with logits: max(x,0) - x*y + log1p(exp(-|x|))
+        l = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+        g = (sg - y) * inv;
+      } else {          // L1
+        const float d = x - y;
+        l = fabsf(d);
+        g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv;
+      }
+      s += l;
+      if (score) score[i] = sg;
+      grad[i] = g;
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    loss[0] = t * inv;
+  }
 }
 
 __global__ void k_scale(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
@@ -49,7 +68,7 @@ extern "C" {
 int hscn_criterion_fwd(const float* pred, const float* target, int64_t count, int kind, float* loss, float* score,
                        float* grad, void* stream_) {
   if (count < 1 || !pred || !target || !loss || !grad || (kind != 0 && kind != 1)) return HSCN_E_BADARG;
-  k_criterion<<<1, 256, 0, hscn_stream(stream_)>>>(pred, target, count, kind, loss, score, grad);
+  k_criterion<<<1, 1024, 0, hscn_stream(stream_)>>>(pred, target, count, kind, loss, score, grad);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -208,7 +208,14 @@ __global__ void __launch_bounds__(256) k_param_reduce(const float* __restrict__ 
   float s = 0.f;
   if (p < P) {
     int g = g0;
-    for (; g + 4 <= g1; g += 4) {  // four loads in flight, added in graph order
+    for (; g + 16 <= g1; g += 16) {  // sixteen loads in flight (a whole slice of a 128-graph batch), added in graph order
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = partials[(size_t)(g + u) * P + p];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; g + 4 <= g1; g += 4) {
       const float a = partials[(size_t)g * P + p], b = partials[(size_t)(g + 1) * P + p];
       const float c = partials[(size_t)(g + 2) * P + p], d = partials[(size_t)(g + 3) * P + p];
       s += a; s += b; s += c; s += d;
