@@ -970,11 +970,13 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
 // One launch, two kinds of workgroup: even blocks run the local chain + head of graph g, odd blocks
 // the part of the virtual branch that does not need them (its CSRs and layer 0, which reads the
 // input features); see k_hscn_bwd_virtual for the rest.
+struct FwdPair {
+  FwdArgs a[2];  // [0] local chain, [1] virtual part
+};
 template <int H, int RT>
-__global__ void __launch_bounds__(RT) k_hscn_fwd_pair(const FwdArgs Al, const FwdArgs Av) {
-  const int g = blockIdx.x >> 1;
-  if (blockIdx.x & 1) hscn_fwd_body<H, RT>(Av, g);
-  else hscn_fwd_body<H, RT>(Al, g);
+__global__ void __launch_bounds__(RT) k_hscn_fwd_pair(const FwdPair P) {
+  // one copy of the body, the argument block (in the kernarg segment) chosen by the parity of the workgroup
+  hscn_fwd_body<H, RT>(P.a[blockIdx.x & 1], blockIdx.x >> 1);
 }
 
 // =============================== backward =====================================================
@@ -1505,7 +1507,10 @@ int launch_fwd_pair_rt(const FwdArgs& Al, const FwdArgs& Av, int64_t B, size_t l
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)k_hscn_fwd_pair<H, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-  k_hscn_fwd_pair<H, RT><<<(unsigned)(2 * B), RT, lds, st>>>(Al, Av);
+  FwdPair P;
+  P.a[0] = Al;
+  P.a[1] = Av;
+  k_hscn_fwd_pair<H, RT><<<(unsigned)(2 * B), RT, lds, st>>>(P);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
