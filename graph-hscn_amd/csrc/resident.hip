@@ -1145,12 +1145,32 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
   }
   STAMP(3);
 
+  // weight-gradient tiles: NW waves x one 16 x 16 partial tile each; when all tiles of a layer fit one
+  // pass (GW1) the fold of the partial tiles is deferred past the next workgroup barrier that is
+  // there anyway (the top of the next layer, or the one after the loop)
+  constexpr int GW_TD = H / 16, GW_NT = GW_TD * GW_TD;
+  constexpr int GW_TPP = GW_NT < NW ? GW_NT : NW, GW_RG = NW / GW_TPP;
+  constexpr bool GW1 = GW_NT <= NW;
+  auto fold_gw = [&](int t0, int oW_, int fin_) {
+    for (int idx = threadIdx.x; idx < GW_TPP * 256; idx += RT) {
+      const int t_ = t0 + idx / 256, e_ = idx & 255;
+      if (t_ < GW_NT) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < GW_RG; ++r) s_ += red[(r * GW_TPP + idx / 256) * 256 + e_];
+        const int oo = (t_ / GW_TD) * 16 + (e_ >> 4), kk = (t_ % GW_TD) * 16 + (e_ & 15);
+        if (kk < fin_) part[oW_ + oo * fin_ + kk] = s_;
+      }
+    }
+  };
+  int pend_oW = -1, pend_fin = 0;
   int off = off_head;
   for (int l = L - 1; l >= 0; --l) {
     const int fin = l == 0 ? A.F : H;
     off -= H * fin + H;
     const int oW = off, ob = off + H * fin;
     lds_barrier();  // G (masked) complete; X free to be overwritten
+    if (GW1 && pend_oW >= 0) fold_gw(0, pend_oW, pend_fin);   // the previous layer's weight gradient
     // layer input -> X (zero padded) and this layer's W_ll -> LDS.  The loads are issued first and
     // parked in LDS after the gather-reduce: their HBM latency hides under it.
     float xr[XPT], wr_[(H * H + RT - 1) / RT];
@@ -1226,10 +1246,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     // in a fixed order.
     {
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      constexpr int TD = H / 16;                       // tiles per dimension
-      constexpr int NT = TD * TD;
-      constexpr int TPP = NT < NW ? NT : NW;           // tiles per pass
-      constexpr int RG = NW / TPP;                     // waves (row groups) per tile
+      constexpr int TD = GW_TD, NT = GW_NT, TPP = GW_TPP, RG = GW_RG;
       const int li = lane & 15, lj = lane >> 4;
       for (int t0 = 0; t0 < NT; t0 += TPP) {
         const int tl = wave % TPP, rg = wave / TPP;
@@ -1248,18 +1265,14 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) red[(rg * TPP + tl) * 256 + (lj * 4 + r) * 16 + li] = acc[r];
         }
-        lds_barrier();
-        for (int idx = threadIdx.x; idx < TPP * 256; idx += RT) {
-          const int t_ = t0 + idx / 256, e_ = idx & 255;
-          if (t_ < NT) {
-            float s_ = 0.f;
-#pragma unroll
-            for (int r = 0; r < RG; ++r) s_ += red[(r * TPP + idx / 256) * 256 + e_];
-            const int oo = (t_ / TD) * 16 + (e_ >> 4), kk = (t_ % TD) * 16 + (e_ & 15);
-            if (kk < fin) part[oW + oo * fin + kk] = s_;
-          }
+        if (GW1) {
+          pend_oW = oW;
+          pend_fin = fin;
+        } else {
+          lds_barrier();
+          fold_gw(t0, oW, fin);
+          if (t0 + TPP < NT) lds_barrier();   // the partial-tile buffer is reused by the next pass
         }
-        if (t0 + TPP < NT) lds_barrier();   // the partial-tile buffer is reused by the next pass
       }
     }
     STAMP(5 + 4 * l);
@@ -1300,6 +1313,10 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
       }
     }
     STAMP(6 + 4 * l);
+  }
+  if (GW1 && pend_oW >= 0) {   // layer 0's weight gradient
+    lds_barrier();
+    fold_gw(0, pend_oW, pend_fin);
   }
   STAMP(63);
 }
