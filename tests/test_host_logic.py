@@ -126,3 +126,40 @@ def test_state_dict_keys_equal_the_reference_naming():
     assert sorted(a.state_dict()) == sorted(b.state_dict())
     assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
     assert sum(p.numel() for p in a.parameters()) == 3306
+
+
+def test_epoch_metrics_equal_sklearn():
+    """graph_hscn.metrics (torch ops, device-resident in training) == the reference's sklearn calls
+    (metrics.py:6-36), including tied scores, NaN labels and single-class columns."""
+    import numpy as np
+    import pytest
+    import torch
+    from sklearn.metrics import average_precision_score, mean_absolute_error
+    from graph_hscn.metrics import eval_ap, eval_mae
+    rng = np.random.default_rng(0)
+    n, C = 257, 7
+    y = (rng.random((n, C)) < 0.3).astype(np.float64)
+    s = np.round(rng.random((n, C)), 2)          # many ties
+    y[:, 2] = 1.0                                # a column without negatives is skipped
+    y[rng.integers(0, n, 20), 4] = np.nan        # unlabeled entries are ignored
+    ref = []
+    for i in range(C):
+        if np.sum(y[:, i] == 1) > 0 and np.sum(y[:, i] == 0) > 0:
+            m = y[:, i] == y[:, i]
+            ref.append(average_precision_score(y[m, i], s[m, i]))
+    got = eval_ap(torch.from_numpy(y).float(), torch.from_numpy(s).float())
+    ref32 = []
+    y32, s32 = y.astype(np.float32), s.astype(np.float32)
+    for i in range(C):
+        if np.sum(y32[:, i] == 1) > 0 and np.sum(y32[:, i] == 0) > 0:
+            m = y32[:, i] == y32[:, i]
+            ref32.append(average_precision_score(y32[m, i], s32[m, i]))
+    assert abs(got - sum(ref32) / len(ref32)) < 1e-12
+    assert abs(got - sum(ref) / len(ref)) < 1e-6
+    with pytest.raises(RuntimeError):
+        eval_ap(torch.ones(5, 2), torch.rand(5, 2))
+    t, p = torch.randn(40, 11), torch.randn(40, 11)
+    assert abs(eval_mae(t, p) - mean_absolute_error(t.numpy(), p.numpy())) < 1e-6
+    p[3, 3] = float("nan")
+    with pytest.raises(Exception):
+        eval_mae(t, p)
