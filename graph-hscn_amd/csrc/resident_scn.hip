@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int SRT = 512;  // threads per workgroup
+constexpr int SRT = 1024;  // threads per workgroup (16 waves: latency hiding for the many short phases)
 constexpr int FP = 16;    // input features are zero padded to 16 in LDS
 
 struct ScnArgs {
@@ -31,15 +31,20 @@ struct ScnArgs {
   const int32_t *nptr, *eptr;  // node / edge ranges per graph
   const float *W_rel, *b_rel, *W_root, *W_mlp, *b_mlp;
   float *S, *y, *stats, *ss;   // outputs: [N,K], [N,H], [B,4], [B,K,K]
-  const float* g_losses;       // backward only: [2] device
+  const float *g_mc, *g_o;     // backward only: upstream scalars dL/dmincut, dL/dortho on the device (NULL = 0)
   float* partials;             // backward only: [B,P]
+  // both CSRs, the normalised aggregation and the binary out-degree: built by the forward launch,
+  // exported (graph g: rowptr at nptr[g] + g, columns at eptr[g]) and loaded by the backward launch
+  int32_t *ex_rowptr_d, *ex_col_d, *ex_rowptr_s, *ex_col_s;
+  float *ex_agg, *ex_dout;  // [N,FP], [N]
   int32_t* flag;
   int64_t N;
   int F, K, act, max_n, max_e, B, P;
 };
 
 struct ScnLayout {
-  size_t R1, R2, R3, dinv, dout, wt, red, vecs, rowptr_d, col_d, rowptr_s, col_s, cursor, tmp, wsum, ek, eo, total;
+  size_t R1, R2, R3, dinv, dout, wt, red, vecs, rowptr_d, col_d, rowptr_s, col_s, cursor, tmp, cursor2, tmp2, wsum, ek,
+      eo, total;
 };
 // R1: x | agg  (2 * n * FP), later S (n * K) in the forward; R2: y (n * H); R3 (backward): dS / dlogits (n * K)
 __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max_e, int bwd) {
@@ -63,8 +68,10 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   Y.col_d = take(max_e);
   Y.rowptr_s = take(max_n + 1);
   Y.col_s = take(max_e);
-  Y.cursor = take(max_n + 1);
-  Y.tmp = take(max_e);
+  Y.cursor = take(bwd ? 0 : max_n + 1);     // the backward loads the CSRs
+  Y.tmp = take(bwd ? 0 : max_e);
+  Y.cursor2 = take(bwd ? 0 : max_n + 1);
+  Y.tmp2 = take(bwd ? 0 : max_e);
   Y.wsum = take(32);
   Y.total = o;
   return Y;
@@ -126,44 +133,128 @@ __device__ void col_sum(const float* M, int ld, int C, int n, float* out) {
   }
 }
 
-// shared front end: stage edges, both CSRs (target-keyed for GraphConv, source-keyed for A S),
-// gcn_norm degrees, x into LDS, aggregation agg = A_hat x (edge order, loop last)
+// ---- forward front end ---------------------------------------------------------------------------
+// Every global input of the graph (weights, COO slice, features) is requested before anything is
+// consumed: one HBM round trip, not one per array.  Then the two CSRs (target-keyed for GraphConv,
+// source-keyed for A S) are built side by side by two wave groups between the same barriers, the
+// gcn_norm degrees follow from the row lengths, and agg = A_hat x is reduced in edge order, loop last.
+// Weights land transposed: WrT / WoT [FP][H] (rows k >= F zero), brl [H], WmT [H][K], bml [K].
 template <int H>
 __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* ib, int n0, int n, int e0, int ne,
-                          const Grp& ALL) {
+                          int g) {
+  constexpr int NW = SRT / 64;
+  const int K = A.K, F = A.F;
   float *xs = fb + Y.R1, *agg = fb + Y.R1 + (size_t)A.max_n * FP, *dinv = fb + Y.dinv, *dout = fb + Y.dout;
+  float* WrT = fb + Y.wt;
+  float* WoT = WrT + FP * H;
+  float* brl = WoT + FP * H;
+  float* WmT = brl + H;
+  float* bml = WmT + (size_t)H * K;
   int *ek = ib + Y.ek, *eo = ib + Y.eo;
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
-  int *cursor = ib + Y.cursor, *tmp = ib + Y.tmp, *wsum = ib + Y.wsum;
+  int* wsum = ib + Y.wsum;
+  const int wave = threadIdx.x >> 6;
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  // ---- requests ----
+  constexpr int WPT = (FP * H + SRT - 1) / SRT;
+  constexpr int MPT = (64 * H + SRT - 1) / SRT;   // K <= 64
+  constexpr int EPT = 2, XPT = 8;
+  float wr[WPT], wo[WPT], wm[MPT], vb = 0.f, vm = 0.f;
+  long long rd[EPT], rs[EPT];
+  float xr[XPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int d = threadIdx.x + i * SRT;          // slot k*H + o
+    const int k = d / H, o = d - k * H;
+    const bool ok = d < FP * H && k < F;
+    const float a = A.W_rel[ok ? o * F + k : 0], b = A.W_root[ok ? o * F + k : 0];
+    wr[i] = ok ? a : 0.f;
+    wo[i] = ok ? b : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) {
+    const int d = threadIdx.x + i * SRT;          // slot h*K + k
+    const int h = d / K, k = d - h * K;
+    const bool ok = d < H * K;
+    wm[i] = 0.f;
+    if (wbase + i * SRT < H * K) {
+      const float t = A.W_mlp[ok ? k * H + h : 0];
+      wm[i] = ok ? t : 0.f;
+    }
+  }
+  if (wbase < H) vb = A.b_rel[threadIdx.x < H ? threadIdx.x : 0];
+  if (wbase < K) vm = A.b_mlp[(int)threadIdx.x < K ? threadIdx.x : 0];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = threadIdx.x + i * SRT;
+    rd[i] = 0; rs[i] = 0;
+    if (wbase + i * SRT < ne) {
+      rd[i] = A.dst[e < ne ? e0 + e : e0];
+      rs[i] = A.src[e < ne ? e0 + e : e0];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * SRT;
+    const int r = idx / FP, k = idx - r * FP;
+    const bool ok = idx < n * FP && k < F;
+    xr[i] = 0.f;
+    if (wbase + i * SRT < n * FP) {
+      const float t = A.x[ok ? (size_t)(n0 + r) * F + k : 0];
+      xr[i] = ok ? t : 0.f;
+    }
+  }
+  // ---- park ----
   bool bad = false;
-  for (int e = threadIdx.x; e < ne; e += SRT) {
-    int k = (int)(A.dst[e0 + e] - n0);
-    const int o = (int)(A.src[e0 + e] - n0);
-    if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; }
-    if (k == o) k = -1;  // an existing self loop is replaced by the unit loop gcn_norm appends
+  auto stage_edge = [&](int e, long long d_, long long s_) {
+    int k = (int)(d_ - n0), o = (int)(s_ - n0);
+    if (k < 0 || k >= n || o < 0 || o >= n) { bad = true; k = -1; o = -1; }
+    if (k == o) { k = -1; o = -1; }  // an existing self loop is replaced by the unit loop gcn_norm appends
     ek[e] = k;
     eo[e] = o;
+  };
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = threadIdx.x + i * SRT;
+    if (e < ne) stage_edge(e, rd[i], rs[i]);
   }
+  for (int e = threadIdx.x + EPT * SRT; e < ne; e += SRT) stage_edge(e, A.dst[e0 + e], A.src[e0 + e]);
   if (bad && A.flag) atomicOr(A.flag, 2);
-  for (int idx = threadIdx.x; idx < n * FP; idx += SRT) {
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * SRT;
+    if (idx < n * FP) xs[idx] = xr[i];
+  }
+  for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
     const int i = idx / FP, k = idx - i * FP;
-    xs[idx] = k < A.F ? A.x[(size_t)(n0 + i) * A.F + k] : 0.f;
+    xs[idx] = k < F ? A.x[(size_t)(n0 + i) * F + k] : 0.f;
   }
-  __syncthreads();
-  build_csr_lds(ek, eo, ne, n, rowptr_d, col_d, cursor, tmp, wsum, ALL);   // rows = targets, cols = sources
-  // the source-keyed CSR: swap the roles (dropped edges keep key -1)
-  for (int e = threadIdx.x; e < ne; e += SRT) {
-    const int k = ek[e], o = eo[e];
-    if (k >= 0) { ek[e] = o; eo[e] = k; }
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int d = threadIdx.x + i * SRT;
+    if (d < FP * H) { WrT[d] = wr[i]; WoT[d] = wo[i]; }
   }
-  __syncthreads();
-  build_csr_lds(ek, eo, ne, n, rowptr_s, col_s, cursor, tmp, wsum, ALL);   // rows = sources, cols = targets
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) {
+    const int d = threadIdx.x + i * SRT;
+    if (d < H * K) WmT[d] = wm[i];
+  }
+  if (threadIdx.x < H) brl[threadIdx.x] = vb;
+  if ((int)threadIdx.x < K) bml[threadIdx.x] = vm;
+  lds_barrier();
+  // ---- structure: the two CSRs side by side (same barrier sequence in both wave groups) ----
+  {
+    const bool second = wave >= NW / 2;
+    const Grp GS{(int)threadIdx.x - (second ? (NW / 2) * 64 : 0), (NW / 2) * 64, wave - (second ? NW / 2 : 0), NW / 2};
+    if (!second) build_csr_lds(ek, eo, ne, n, rowptr_d, col_d, ib + Y.cursor, ib + Y.tmp, wsum, GS);   // rows = targets
+    else build_csr_lds(eo, ek, ne, n, rowptr_s, col_s, ib + Y.cursor2, ib + Y.tmp2, wsum + 16, GS);    // rows = sources
+  }
   for (int i = threadIdx.x; i < n; i += SRT) {
     const float deg = (float)(rowptr_d[i + 1] - rowptr_d[i]) + 1.0f;        // scatter_add of unit weights + loop
     dinv[i] = 1.0f / sqrtf(deg);
     dout[i] = (float)(rowptr_s[i + 1] - rowptr_s[i]) + 1.0f;               // row sum of binary A + I
   }
-  __syncthreads();
+  lds_barrier();
   // agg_i = sum_{j->i} (dinv_j * 1 * dinv_i) x_j  (edge order)  +  (dinv_i * 1 * dinv_i) x_i  (loop last)
   {
     constexpr int LPR = FP / 4;
@@ -183,18 +274,21 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       a.x = add_rn(a.x, mul_rn(wl, v.x)); a.y = add_rn(a.y, mul_rn(wl, v.y));
       a.z = add_rn(a.z, mul_rn(wl, v.z)); a.w = add_rn(a.w, mul_rn(wl, v.w));
       *reinterpret_cast<float4*>(agg + i * FP + f) = a;
+      if (A.ex_agg) *reinterpret_cast<float4*>(A.ex_agg + (size_t)(n0 + i) * FP + f) = a;
     }
   }
-  __syncthreads();
-}
-
-// stage W^T: W [O][I] (global) -> Wt[k][o] with row stride O, rows k >= I zero up to IP
-__device__ __forceinline__ void stage_t(const float* __restrict__ W, int O, int I, int IP, float* Wt) {
-  for (int idx = threadIdx.x; idx < O * I; idx += SRT) {
-    const int o = idx / I, k = idx - o * I;
-    Wt[k * O + o] = W[idx];
+  // hand the structure to the backward launch
+  if (A.ex_rowptr_d) {
+    for (int i = threadIdx.x; i <= n; i += SRT) {
+      A.ex_rowptr_d[(size_t)n0 + g + i] = rowptr_d[i];
+      A.ex_rowptr_s[(size_t)n0 + g + i] = rowptr_s[i];
+    }
+    const int cd = rowptr_d[n], cs = rowptr_s[n];
+    for (int p = threadIdx.x; p < cd; p += SRT) A.ex_col_d[(size_t)e0 + p] = col_d[p];
+    for (int p = threadIdx.x; p < cs; p += SRT) A.ex_col_s[(size_t)e0 + p] = col_s[p];
+    for (int i = threadIdx.x; i < n; i += SRT) A.ex_dout[(size_t)n0 + i] = dout[i];
   }
-  for (int idx = threadIdx.x + I * O; idx < IP * O; idx += SRT) Wt[idx] = 0.f;
+  lds_barrier();
 }
 
 template <int H>
@@ -212,7 +306,6 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const Grp ALL{(int)threadIdx.x, SRT, wave, NW};
   float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = fb + Y.R1, *yl = fb + Y.R2;
   float *dout = fb + Y.dout, *red = fb + Y.red;
   float* WrT = fb + Y.wt;            // [FP][H]
@@ -222,12 +315,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   float* bml = WmT + (size_t)H * K;  // [K]
   int *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
-  stage_t(A.W_rel, H, A.F, FP, WrT);
-  stage_t(A.W_root, H, A.F, FP, WoT);
-  for (int i = threadIdx.x; i < H; i += SRT) brl[i] = A.b_rel[i];
-  stage_t(A.W_mlp, K, H, H, WmT);
-  for (int i = threadIdx.x; i < K; i += SRT) bml[i] = A.b_mlp[i];
-  scn_front<H>(A, Y, fb, ib, n0, n, e0, ne, ALL);
+  scn_front<H>(A, Y, fb, ib, n0, n, e0, ne, g);
 
   // y = act(W_rel agg + b_rel + W_root x): thread (row, o); both weight columns in registers
   {
@@ -258,12 +346,21 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
     int KP = 1;
     while (KP < K) KP <<= 1;
     const int k = threadIdx.x % KP, r0 = threadIdx.x / KP;
+    float wcol[H];   // this lane's column of W_mlp^T
+#pragma unroll
+    for (int h = 0; h < H; ++h) wcol[h] = k < K ? WmT[h * K + k] : 0.f;
+    const float bk = k < K ? bml[k] : 0.f;
     for (int i = r0; i < n; i += SRT / KP) {
       float s = -INFINITY;
       if (k < K) {
         float a = 0.f;
-        for (int h = 0; h < H; ++h) a = fmaf(yl[i * H + h], WmT[h * K + k], a);
-        s = a + bml[k];
+#pragma unroll
+        for (int h4 = 0; h4 < H / 4; ++h4) {
+          const float4 yv = *reinterpret_cast<const float4*>(yl + i * H + 4 * h4);
+          a = fmaf(yv.x, wcol[4 * h4 + 0], a); a = fmaf(yv.y, wcol[4 * h4 + 1], a);
+          a = fmaf(yv.z, wcol[4 * h4 + 2], a); a = fmaf(yv.w, wcol[4 * h4 + 3], a);
+        }
+        s = a + bk;
       }
       float m = s;
       for (int off = KP >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -352,20 +449,101 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const Grp ALL{(int)threadIdx.x, SRT, wave, NW};
   float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = agg + (size_t)A.max_n * FP;
   float *yl = fb + Y.R2, *DL = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;
   float* WmT = fb + Y.wt + 2 * FP * H + H;   // [H][K] (same offsets as the forward's weight block)
   float* Gss = WmT + (size_t)H * K + K;      // [K][K]
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
-  stage_t(A.W_mlp, K, H, H, WmT);
-  scn_front<H>(A, Y, fb, ib, n0, n, e0, ne, ALL);
-  // S, y from the forward; Gss from ss/stats
-  for (int idx = threadIdx.x; idx < n * K; idx += SRT) Sl[idx] = A.S[(size_t)n0 * K + idx];
-  for (int idx = threadIdx.x; idx < n * H; idx += SRT) yl[idx] = A.y[(size_t)n0 * H + idx];
+  // ---- front: everything comes from HBM in one batch of requests -- the CSRs, agg and the binary
+  // out-degree the forward launch exported, x, S and y, W_mlp -- then is parked in LDS
+  {
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    constexpr int RPT = 2, EPT = 2, XPT = 8, MPT = (64 * H + SRT - 1) / SRT;
+    int rdp[RPT], rsp[RPT], cdp[EPT], csp[EPT];
+    float dop[RPT], agr[XPT], xr[XPT], sr[XPT], yr[XPT], wm[MPT];
+    const int32_t *prd = A.ex_rowptr_d + (size_t)n0 + g, *prs = A.ex_rowptr_s + (size_t)n0 + g;
+    const int32_t *pcd = A.ex_col_d + (size_t)e0, *pcs = A.ex_col_s + (size_t)e0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int idx = threadIdx.x + i * SRT;
+      rdp[i] = 0; rsp[i] = 0; dop[i] = 0.f;
+      if (wbase + i * SRT <= n) {
+        rdp[i] = prd[idx <= n ? idx : 0];
+        rsp[i] = prs[idx <= n ? idx : 0];
+        dop[i] = A.ex_dout[(size_t)n0 + (idx < n ? idx : 0)];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * SRT;
+      cdp[i] = 0; csp[i] = 0;
+      if (wbase + i * SRT < ne) {
+        cdp[i] = pcd[e < ne ? e : 0];
+        csp[i] = pcs[e < ne ? e : 0];
+      }
+    }
+    const float* pag = A.ex_agg + (size_t)n0 * FP;
+    const float* pS = A.S + (size_t)n0 * K;
+    const float* py = A.y + (size_t)n0 * H;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int idx = threadIdx.x + i * SRT;
+      const int r = idx / FP, k = idx - r * FP;
+      const bool okx = idx < n * FP && k < A.F;
+      agr[i] = 0.f; xr[i] = 0.f; sr[i] = 0.f; yr[i] = 0.f;
+      if (wbase + i * SRT < n * FP) {
+        agr[i] = pag[idx < n * FP ? idx : 0];
+        const float t = A.x[okx ? (size_t)(n0 + r) * A.F + k : 0];
+        xr[i] = okx ? t : 0.f;
+      }
+      if (wbase + i * SRT < n * K) sr[i] = pS[idx < n * K ? idx : 0];
+      if (wbase + i * SRT < n * H) yr[i] = py[idx < n * H ? idx : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < MPT; ++i) {
+      const int d = threadIdx.x + i * SRT;          // slot h*K + k
+      const int h = d / K, k = d - h * K;
+      wm[i] = 0.f;
+      if (wbase + i * SRT < H * K) wm[i] = A.W_mlp[d < H * K ? k * H + h : 0];
+    }
+    // ---- park ----
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int idx = threadIdx.x + i * SRT;
+      if (idx <= n) { rowptr_d[idx] = rdp[i]; rowptr_s[idx] = rsp[i]; }
+      if (idx < n) dout[idx] = dop[i];
+    }
+    for (int idx = threadIdx.x + RPT * SRT; idx <= n; idx += SRT) { rowptr_d[idx] = prd[idx]; rowptr_s[idx] = prs[idx]; }
+    for (int idx = threadIdx.x + RPT * SRT; idx < n; idx += SRT) dout[idx] = A.ex_dout[(size_t)n0 + idx];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * SRT;
+      if (e < ne) { col_d[e] = cdp[i]; col_s[e] = csp[i]; }
+    }
+    for (int e = threadIdx.x + EPT * SRT; e < ne; e += SRT) { col_d[e] = pcd[e]; col_s[e] = pcs[e]; }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int idx = threadIdx.x + i * SRT;
+      if (idx < n * FP) { agg[idx] = agr[i]; xs[idx] = xr[i]; }
+      if (idx < n * K) Sl[idx] = sr[i];
+      if (idx < n * H) yl[idx] = yr[i];
+    }
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
+      const int i = idx / FP, k = idx - i * FP;
+      agg[idx] = pag[idx];
+      xs[idx] = k < A.F ? A.x[(size_t)(n0 + i) * A.F + k] : 0.f;
+    }
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * K; idx += SRT) Sl[idx] = pS[idx];
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * H; idx += SRT) yl[idx] = py[idx];
+#pragma unroll
+    for (int i = 0; i < MPT; ++i) {
+      const int d = threadIdx.x + i * SRT;
+      if (d < H * K) WmT[d] = wm[i];
+    }
+  }
   const float num = A.stats[g * 4 + 0], den = A.stats[g * 4 + 1], nrm = A.stats[g * 4 + 2], o = A.stats[g * 4 + 3];
-  const float gmc = A.g_losses[0] / (float)A.B, go = A.g_losses[1] / (float)A.B;
+  const float gmc = (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
   const float isk = 1.0f / sqrtf((float)K);
   const float* ssg = A.ss + (size_t)g * KK;
   if (threadIdx.x < 64) {
@@ -490,16 +668,24 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
                           const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
-                          float* losses, int32_t* flag, void* stream_) {
+                          float* losses, int32_t* ex_rowptr_d, int32_t* ex_col_d, int32_t* ex_rowptr_s,
+                          int32_t* ex_col_s, float* ex_agg, float* ex_dout, int32_t* flag, void* stream_) {
   if (B < 1 || N < 0 || E < 0) return HSCN_E_BADARG;
   if (!hscn_scn_resident_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
   if (!x || !nptr || !eptr || !W_rel || !b_rel || !W_root || !W_mlp || !b_mlp || !S || !y || !stats || !ss ||
       !losses || (E > 0 && !edge_index))
     return HSCN_E_BADARG;
+  {
+    const int have = (ex_rowptr_d != nullptr) + (ex_col_d != nullptr) + (ex_rowptr_s != nullptr) +
+                     (ex_col_s != nullptr) + (ex_agg != nullptr) + (ex_dout != nullptr);
+    if (have != 0 && have != 6) return HSCN_E_BADARG;   // the structure is exported whole or not at all
+  }
   ScnArgs A{};
   A.x = x; A.src = edge_index; A.dst = edge_index ? edge_index + E : nullptr; A.nptr = nptr; A.eptr = eptr;
   A.W_rel = W_rel; A.b_rel = b_rel; A.W_root = W_root; A.W_mlp = W_mlp; A.b_mlp = b_mlp;
   A.S = S; A.y = y; A.stats = stats; A.ss = ss; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
+  A.ex_rowptr_d = ex_rowptr_d; A.ex_col_d = ex_col_d; A.ex_rowptr_s = ex_rowptr_s; A.ex_col_s = ex_col_s;
+  A.ex_agg = ex_agg; A.ex_dout = ex_dout;
   A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
   hipStream_t st = hscn_stream(stream_);
   int rc = H == 16 ? launch_scn<16>(A, 0, st) : launch_scn<32>(A, 0, st);
@@ -512,17 +698,22 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
 int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_mlp, const float* S, const float* y, const float* stats, const float* ss,
-                          const float* g_losses, int max_n, int max_e, float* partials, float* grads,
-                          int32_t* flag, void* stream_) {
+                          const float* g_mc, const float* g_o, const int32_t* ex_rowptr_d, const int32_t* ex_col_d,
+                          const int32_t* ex_rowptr_s, const int32_t* ex_col_s, const float* ex_agg,
+                          const float* ex_dout, int max_n, int max_e, float* partials, float* grads, int32_t* flag,
+                          void* stream_) {
   if (B < 1 || N < 0 || E < 0) return HSCN_E_BADARG;
   if (!hscn_scn_resident_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
-  if (!x || !nptr || !eptr || !W_mlp || !S || !y || !stats || !ss || !g_losses || !partials || !grads ||
-      (E > 0 && !edge_index))
+  if (!x || !nptr || !eptr || !W_mlp || !S || !y || !stats || !ss || !partials || !grads ||
+      !ex_rowptr_d || !ex_rowptr_s || !ex_agg || !ex_dout || (E > 0 && (!ex_col_d || !ex_col_s)))
     return HSCN_E_BADARG;
   ScnArgs A{};
   A.x = x; A.src = edge_index; A.dst = edge_index ? edge_index + E : nullptr; A.nptr = nptr; A.eptr = eptr;
   A.W_mlp = W_mlp; A.S = const_cast<float*>(S); A.y = const_cast<float*>(y);
-  A.stats = const_cast<float*>(stats); A.ss = const_cast<float*>(ss); A.g_losses = g_losses;
+  A.stats = const_cast<float*>(stats); A.ss = const_cast<float*>(ss); A.g_mc = g_mc; A.g_o = g_o;
+  A.ex_rowptr_d = const_cast<int32_t*>(ex_rowptr_d); A.ex_col_d = const_cast<int32_t*>(ex_col_d);
+  A.ex_rowptr_s = const_cast<int32_t*>(ex_rowptr_s); A.ex_col_s = const_cast<int32_t*>(ex_col_s);
+  A.ex_agg = const_cast<float*>(ex_agg); A.ex_dout = const_cast<float*>(ex_dout);
   A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
   A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
   hipStream_t st = hscn_stream(stream_);

@@ -263,7 +263,10 @@ def scn_meta(data, device) -> ScnMeta:
 
 
 class SCNResidentFn(Function):
-    """(x, raw edge_index, meta, act, W_rel, b_rel, W_root, W_mlp, b_mlp) -> (S, losses[2])."""
+    """(x, raw edge_index, meta, act, W_rel, b_rel, W_root, W_mlp, b_mlp) -> (S, mc_loss, o_loss).
+    The two losses are separate autograd outputs (0-dim views of one [2] buffer the launch fills), so
+    ``(mc + o).backward()`` reaches the backward launch as two scalar gradients with no glue kernels
+    in between (slicing one [2] output cost six fill / copy / add launches per step)."""
 
     @staticmethod
     def forward(ctx, x, edge_index, meta: ScnMeta, act: int, W_rel, b_rel, W_root, W_mlp, b_mlp):
@@ -280,17 +283,26 @@ class SCNResidentFn(Function):
         ss = torch.empty(B, K, K, dtype=torch.float32, device=dev)
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         E = edge_index.size(1)
+        # both CSRs, agg = A_hat x and the out-degree: built in LDS by the forward launch, kept for the backward
+        need_bwd = any(ctx.needs_input_grad[4:])
+        ex = None
+        if need_bwd:
+            ex = (torch.empty(N + B, dtype=torch.int32, device=dev), torch.empty(max(E, 1), dtype=torch.int32, device=dev),
+                  torch.empty(N + B, dtype=torch.int32, device=dev), torch.empty(max(E, 1), dtype=torch.int32, device=dev),
+                  torch.empty(max(N, 1), 16, dtype=torch.float32, device=dev), torch.empty(max(N, 1), dtype=torch.float32, device=dev))
         call("hscn_scn_resident_fwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
              F, H, K, act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), meta.max_n, meta.max_e,
-             ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(losses), ptr(meta.flag), stream())
+             ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(losses), *([ptr(t) for t in ex] if ex else [None] * 6),
+             ptr(meta.flag), stream())
+        ctx.ex = ex
         ctx.meta, ctx.act, ctx.dims = meta, act, (N, F, H, K, B, E)
         ctx.save_for_backward(x, edge_index, W_mlp, S, y, stats, ss)
         ctx.mark_non_differentiable(S)
         ctx.set_materialize_grads(False)
-        return S, losses
+        return S, losses[0], losses[1]
 
     @staticmethod
-    def backward(ctx, gS, g_losses):
+    def backward(ctx, gS, g_mc, g_o):
         x, edge_index, W_mlp, S, y, stats, ss = ctx.saved_tensors
         meta: ScnMeta = ctx.meta
         N, F, H, K, B, E = ctx.dims
@@ -298,9 +310,10 @@ class SCNResidentFn(Function):
         P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
         partials = torch.empty(B, P, dtype=torch.float32, device=dev)
         grads = torch.empty(P, dtype=torch.float32, device=dev)
-        gl = g_losses.contiguous() if g_losses is not None else torch.zeros(2, dtype=torch.float32, device=dev)
+        g_mc = None if g_mc is None else g_mc.reshape(1).contiguous()
+        g_o = None if g_o is None else g_o.reshape(1).contiguous()
         call("hscn_scn_resident_bwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
-             F, H, K, ctx.act, ptr(W_mlp), ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(gl), meta.max_n, meta.max_e,
+             F, H, K, ctx.act, ptr(W_mlp), ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(g_mc), ptr(g_o), *[ptr(t) for t in ctx.ex], meta.max_n, meta.max_e,
              ptr(partials), ptr(grads), ptr(meta.flag), stream())
         o = 0
         gW_rel = grads[o:o + H * F].view(H, F); o += H * F

@@ -101,10 +101,10 @@ class SCN(nn.Module):
             meta = _engine.scn_meta(data, dev)
             x = data.x if data.x.is_cuda else data.x.to(dev)
             ei = data.edge_index if data.edge_index.is_cuda else data.edge_index.to(dev)
-            S, losses = _engine.SCNResidentFn.apply(x.float(), ei, meta, _engine.ACT[self.mp.act], conv.lin_rel.weight,
-                                                    conv.lin_rel.bias, conv.lin_root.weight, lin.weight, lin.bias)
+            S, mc, o = _engine.SCNResidentFn.apply(x.float(), ei, meta, _engine.ACT[self.mp.act], conv.lin_rel.weight,
+                                                   conv.lin_rel.bias, conv.lin_root.weight, lin.weight, lin.bias)
             self.last_engine = "resident"
-            return S, losses[0], losses[1]
+            return S, mc, o
         from ..nn.pool import gcn_norm
         self.last_engine = "layered"
         ei, ew = gcn_norm(data.edge_index.to(dev), None, int(data.num_nodes), add_self_loops=True)

@@ -375,7 +375,12 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
  *   GraphConv output, kept for the backward), stats [B,4] {num, den, |S^T S|_F, ortho},
  *   ss [B,K,K], losses [2] = {mean mincut, mean ortho}.
  * hscn_scn_resident_bwd: grads packed as {W_rel [H,F], b_rel [H], W_root [H,F], W_mlp [K,H],
- * b_mlp [K]} given g_losses = {dL/dmincut, dL/dortho} on the device.
+ * b_mlp [K]} given the upstream scalars g_mc = dL/dmincut, g_o = dL/dortho as two device pointers
+ * (the two losses are separate autograd outputs; NULL = that loss received no gradient).
+ *   ex_*: both CSRs of the self-loop-free graph (target-keyed d, source-keyed s; graph g: rowptr at
+ *   nptr[g] + g, columns at eptr[g]), the normalised aggregation agg = A_hat x (16 columns, zero
+ *   padded) and the binary out-degree + 1: built in LDS by the forward launch, exported (all six or
+ *   none) and loaded by the backward launch, which does not rebuild them.
  * ------------------------------------------------------------------------- */
 int hscn_scn_resident_supported(int F, int H, int K, int max_n, int max_e);
 int64_t hscn_scn_resident_param_count(int F, int H, int K);
@@ -383,12 +388,16 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
                           const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
-                          float* losses, int32_t* flag, void* stream);
+                          float* losses, int32_t* ex_rowptr_d /*[N+B]*/, int32_t* ex_col_d /*[E]*/,
+                          int32_t* ex_rowptr_s /*[N+B]*/, int32_t* ex_col_s /*[E]*/, float* ex_agg /*[N,16]*/,
+                          float* ex_dout /*[N]*/, int32_t* flag, void* stream);
 int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_mlp, const float* S, const float* y, const float* stats, const float* ss,
-                          const float* g_losses, int max_n, int max_e, float* partials /*[B,P]*/, float* grads /*[P]*/,
-                          int32_t* flag, void* stream);
+                          const float* g_mc /*[1] or NULL*/, const float* g_o /*[1] or NULL*/,
+                          const int32_t* ex_rowptr_d, const int32_t* ex_col_d, const int32_t* ex_rowptr_s,
+                          const int32_t* ex_col_s, const float* ex_agg, const float* ex_dout, int max_n, int max_e,
+                          float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
 
 #ifdef __cplusplus
 }
