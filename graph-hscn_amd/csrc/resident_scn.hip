@@ -37,6 +37,10 @@ struct ScnArgs {
   // exported (graph g: rowptr at nptr[g] + g, columns at eptr[g]) and loaded by the backward launch
   int32_t *ex_rowptr_d, *ex_col_d, *ex_rowptr_s, *ex_col_s;
   float *ex_agg, *ex_dout;  // [N,FP], [N]
+  // forward only: losses [3] = {mean mincut, mean ortho, their sum}; with a ticket counter (zero before
+  // the first launch, left at zero) the workgroup that finishes last reduces the per-graph statistics
+  float* losses;
+  int32_t* ticket;
   int32_t* flag;
   int64_t N;
   int F, K, act, max_n, max_e, B, P;
@@ -44,7 +48,7 @@ struct ScnArgs {
 
 struct ScnLayout {
   size_t R1, R2, R3, dinv, dout, wt, red, vecs, rowptr_d, col_d, rowptr_s, col_s, cursor, tmp, cursor2, tmp2, wsum, ek,
-      eo, total;
+      eo, ssl, total;
 };
 // R1: x | agg  (2 * n * FP), later S (n * K) in the forward; R2: y (n * H); R3 (backward): dS / dlogits (n * K)
 __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max_e, int bwd) {
@@ -73,6 +77,7 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   Y.cursor2 = take(bwd ? 0 : max_n + 1);
   Y.tmp2 = take(bwd ? 0 : max_e);
   Y.wsum = take(32);
+  Y.ssl = take(bwd ? (size_t)K * K : 0);   // the forward's S^T S, fetched with the rest of the front
   Y.total = o;
   return Y;
 }
@@ -121,15 +126,59 @@ __device__ void outer_sum(const float* Gm, int ldg, int O, const float* Xm, int 
   }
 }
 
-// column sums of M[n][C] -> out[C]: wave per column, lanes split rows
+// column sums of M[n][C] -> out[C] (C a multiple of 4, C <= 64): a lane adds float4 pieces of a
+// strided row set (consecutive lanes on consecutive 16 B), the slots of a wave fold by shuffles, the
+// waves through `scratch` [NW][C] in wave order.  Contains one workgroup barrier.
 template <int NW>
-__device__ void col_sum(const float* M, int ld, int C, int n, float* out) {
+__device__ void col_sum(const float* M, int ld, int C, int n, float* out, float* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = wave; c < C; c += NW) {
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += M[(size_t)i * ld + c];
-    s = wave_sum(s);
-    if (lane == 0) out[c] = s;
+  if ((C & 3) != 0 || (64 % (C / 4)) != 0 || (ld & 3) != 0) {   // odd widths: wave per column, lanes split rows
+    for (int c = wave; c < C; c += NW) {
+      float s_ = 0.f;
+      for (int i = lane; i < n; i += 64) s_ += M[(size_t)i * ld + c];
+      s_ = wave_sum(s_);
+      if (lane == 0) out[c] = s_;
+    }
+    __syncthreads();
+    return;
+  }
+  const int LQ = C / 4, SQ = 64 / LQ;                 // lanes per row, row slots per wave
+  const int slot = lane / LQ, f = (lane % LQ) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = wave * SQ + slot; i < n; i += NW * SQ) {
+    const float4 v = *reinterpret_cast<const float4*>(M + (size_t)i * ld + f);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  for (int o_ = 32; o_ >= LQ; o_ >>= 1) {
+    acc.x += __shfl_xor(acc.x, o_, 64);
+    acc.y += __shfl_xor(acc.y, o_, 64);
+    acc.z += __shfl_xor(acc.z, o_, 64);
+    acc.w += __shfl_xor(acc.w, o_, 64);
+  }
+  if (slot == 0) *reinterpret_cast<float4*>(scratch + wave * C + f) = acc;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += SRT) {
+    float s_ = 0.f;
+    for (int w = 0; w < NW; ++w) s_ += scratch[w * C + c];
+    out[c] = s_;
+  }
+}
+
+// one wave: losses = {mean_g -num_g/den_g, mean_g ortho_g, their sum} from stats [G,4]
+__device__ __forceinline__ void scn_losses_wave(const float* stats, float* losses, int G) {
+  const int lane = threadIdx.x & 63;
+  float mc = 0.f, o = 0.f;
+  for (int g = lane; g < G; g += 64) {
+    mc += -(stats[(size_t)g * 4 + 0] / stats[(size_t)g * 4 + 1]);
+    o += stats[(size_t)g * 4 + 3];
+  }
+  mc = wave_sum(mc);
+  o = wave_sum(o);
+  if (lane == 0) {
+    const float a = mc / (float)G, b = o / (float)G;
+    losses[0] = a;
+    losses[1] = b;
+    losses[2] = a + b;
   }
 }
 
@@ -429,6 +478,22 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
       A.stats[g * 4 + 2] = nrm;
       A.stats[g * 4 + 3] = sqrtf(o2);
     }
+    // the batch losses without a launch of their own: the workgroup that takes the last ticket sums
+    // the per-graph statistics in graph order (the order, hence the result, does not depend on who
+    // it is); device-scope fences order the statistics stores against the ticket
+    if (A.ticket) {
+      int last = 0;
+      if (lane == 0) {
+        __threadfence();
+        last = atomicAdd(A.ticket, 1) == A.B - 1;
+      }
+      last = __builtin_amdgcn_readfirstlane(last);
+      if (last) {
+        __threadfence();
+        scn_losses_wave(A.stats, A.losses, A.B);
+        if (lane == 0) *A.ticket = 0;
+      }
+    }
   }
 }
 
@@ -453,6 +518,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   float *yl = fb + Y.R2, *DL = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;
   float* WmT = fb + Y.wt + 2 * FP * H + H;   // [H][K] (same offsets as the forward's weight block)
   float* Gss = WmT + (size_t)H * K + K;      // [K][K]
+  float* ssl = fb + Y.ssl;                   // [K][K] the forward's S^T S
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
   // ---- front: everything comes from HBM in one batch of requests -- the CSRs, agg and the binary
@@ -461,7 +527,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
     const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
     constexpr int RPT = 2, EPT = 2, XPT = 8, MPT = (64 * H + SRT - 1) / SRT;
     int rdp[RPT], rsp[RPT], cdp[EPT], csp[EPT];
-    float dop[RPT], agr[XPT], xr[XPT], sr[XPT], yr[XPT], wm[MPT];
+    float dop[RPT], agr[XPT], xr[XPT], sr[XPT], yr[XPT], wm[MPT], ssr[4];
     const int32_t *prd = A.ex_rowptr_d + (size_t)n0 + g, *prs = A.ex_rowptr_s + (size_t)n0 + g;
     const int32_t *pcd = A.ex_col_d + (size_t)e0, *pcs = A.ex_col_s + (size_t)e0;
 #pragma unroll
@@ -507,7 +573,18 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
       wm[i] = 0.f;
       if (wbase + i * SRT < H * K) wm[i] = A.W_mlp[d < H * K ? k * H + h : 0];
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                   // ss [K,K] of this graph (K <= 64: 4 words per thread)
+      const int d = threadIdx.x + i * SRT;
+      ssr[i] = 0.f;
+      if (wbase + i * SRT < KK) ssr[i] = A.ss[(size_t)g * KK + (d < KK ? d : 0)];
+    }
     // ---- park ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = threadIdx.x + i * SRT;
+      if (d < KK) ssl[d] = ssr[i];
+    }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int idx = threadIdx.x + i * SRT;
@@ -545,7 +622,8 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   const float num = A.stats[g * 4 + 0], den = A.stats[g * 4 + 1], nrm = A.stats[g * 4 + 2], o = A.stats[g * 4 + 3];
   const float gmc = (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
   const float isk = 1.0f / sqrtf((float)K);
-  const float* ssg = A.ss + (size_t)g * KK;
+  const float* ssg = ssl;
+  __syncthreads();   // the front's LDS stores
   if (threadIdx.x < 64) {
     float v = 0.f;
     if (o > 0.f)
@@ -570,6 +648,9 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
     int KP = 1;
     while (KP < K) KP <<= 1;
     const int k = threadIdx.x % KP, r0 = threadIdx.x / KP;
+    float gcol[32];   // this lane's column of Gss (K <= 32)
+#pragma unroll
+    for (int a = 0; a < 32; ++a) gcol[a] = (a < K && k < K && K <= 32) ? Gss[a * K + k] : 0.f;
     for (int i = r0; i < n; i += SRT / KP) {
       float dS = 0.f, sv = 0.f;
       if (k < K) {
@@ -579,7 +660,18 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
         for (int p = rowptr_d[i]; p < rowptr_d[i + 1]; ++p) as += Sl[col_d[p] * K + k];   // (A^T S)_i
         as += 2.f * sv;                                                                   // the two identity terms
         float orth = 0.f;
-        for (int a = 0; a < K; ++a) orth = fmaf(Sl[i * K + a], Gss[a * K + k], orth);
+        if (K <= 32 && (K & 3) == 0) {
+#pragma unroll
+          for (int a4 = 0; a4 < 8; ++a4) {
+            if (4 * a4 < K) {
+              const float4 sv4 = *reinterpret_cast<const float4*>(Sl + i * K + 4 * a4);
+              orth = fmaf(sv4.x, gcol[4 * a4 + 0], orth); orth = fmaf(sv4.y, gcol[4 * a4 + 1], orth);
+              orth = fmaf(sv4.z, gcol[4 * a4 + 2], orth); orth = fmaf(sv4.w, gcol[4 * a4 + 3], orth);
+            }
+          }
+        } else {
+          for (int a = 0; a < K; ++a) orth = fmaf(Sl[i * K + a], Gss[a * K + k], orth);
+        }
         dS = c_num * as + c_den * 2.f * dout[i] * sv + go * 2.f * orth;
       }
       float dot = dS * sv;
@@ -600,35 +692,43 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
       part[oWmlp + idx] = s;
     }
   }
-  col_sum<NW>(DL, K, K, n, part + obmlp);
+  col_sum<NW>(DL, K, K, n, part + obmlp, red);
   __syncthreads();
   // dz = (DL W_mlp) * act'(y)  in place over y: thread (row, h)
   {
     const int h = threadIdx.x % H, r0 = threadIdx.x / H;
-    for (int i = r0; i < n; i += SRT / H) {
-      float a = 0.f;
-      for (int k = 0; k < K; ++k) a = fmaf(DL[i * K + k], WmT[h * K + k], a);
-      yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
+    if (K <= 32 && (K & 3) == 0) {
+      float wrow[32];   // row h of W_mlp^T (K <= 32)
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wrow[k] = k < K ? WmT[h * K + k] : 0.f;
+      for (int i = r0; i < n; i += SRT / H) {
+        float a = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+          if (4 * k4 < K) {
+            const float4 d4 = *reinterpret_cast<const float4*>(DL + i * K + 4 * k4);
+            a = fmaf(d4.x, wrow[4 * k4 + 0], a); a = fmaf(d4.y, wrow[4 * k4 + 1], a);
+            a = fmaf(d4.z, wrow[4 * k4 + 2], a); a = fmaf(d4.w, wrow[4 * k4 + 3], a);
+          }
+        }
+        yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
+      }
+    } else {
+      for (int i = r0; i < n; i += SRT / H) {
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a = fmaf(DL[i * K + k], WmT[h * K + k], a);
+        yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
+      }
     }
   }
   __syncthreads();
   outer_sum<NW>(yl, H, H, agg, FP, FP, n, part + oWrel, A.F, A.F);     // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
   outer_sum<NW>(yl, H, H, xs, FP, FP, n, part + oWroot, A.F, A.F);     // dW_root[o][k] = sum_i dz[i][o] x[i][k]
-  col_sum<NW>(yl, H, H, n, part + obrel);
+  col_sum<NW>(yl, H, H, n, part + obrel, red);
 }
 
 __global__ void k_scn_losses(const float* __restrict__ stats, float* __restrict__ losses, int G) {
-  float mc = 0.f, o = 0.f;
-  for (int g = threadIdx.x; g < G; g += 64) {
-    mc += -(stats[g * 4 + 0] / stats[g * 4 + 1]);
-    o += stats[g * 4 + 3];
-  }
-  mc = wave_sum(mc);
-  o = wave_sum(o);
-  if (threadIdx.x == 0) {
-    losses[0] = mc / (float)G;
-    losses[1] = o / (float)G;
-  }
+  scn_losses_wave(stats, losses, G);
 }
 
 inline int64_t scn_param_count(int F, int H, int K) { return (int64_t)2 * H * F + H + (int64_t)K * H + K; }
@@ -668,8 +768,9 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
                           const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
-                          float* losses, int32_t* ex_rowptr_d, int32_t* ex_col_d, int32_t* ex_rowptr_s,
-                          int32_t* ex_col_s, float* ex_agg, float* ex_dout, int32_t* flag, void* stream_) {
+                          float* losses, int32_t* ticket, int32_t* ex_rowptr_d, int32_t* ex_col_d,
+                          int32_t* ex_rowptr_s, int32_t* ex_col_s, float* ex_agg, float* ex_dout, int32_t* flag,
+                          void* stream_) {
   if (B < 1 || N < 0 || E < 0) return HSCN_E_BADARG;
   if (!hscn_scn_resident_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
   if (!x || !nptr || !eptr || !W_rel || !b_rel || !W_root || !W_mlp || !b_mlp || !S || !y || !stats || !ss ||
@@ -685,13 +786,15 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
   A.W_rel = W_rel; A.b_rel = b_rel; A.W_root = W_root; A.W_mlp = W_mlp; A.b_mlp = b_mlp;
   A.S = S; A.y = y; A.stats = stats; A.ss = ss; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
   A.ex_rowptr_d = ex_rowptr_d; A.ex_col_d = ex_col_d; A.ex_rowptr_s = ex_rowptr_s; A.ex_col_s = ex_col_s;
-  A.ex_agg = ex_agg; A.ex_dout = ex_dout;
+  A.ex_agg = ex_agg; A.ex_dout = ex_dout; A.losses = losses; A.ticket = ticket;
   A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
   hipStream_t st = hscn_stream(stream_);
   int rc = H == 16 ? launch_scn<16>(A, 0, st) : launch_scn<32>(A, 0, st);
   if (rc) return rc;
-  k_scn_losses<<<1, 64, 0, st>>>(stats, losses, (int)B);
-  HSCN_RETURN_IF_LAUNCH_FAILED();
+  if (!ticket) {   // no ticket counter: the statistics are reduced by a launch of their own
+    k_scn_losses<<<1, 64, 0, st>>>(stats, losses, (int)B);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
   return 0;
 }
 

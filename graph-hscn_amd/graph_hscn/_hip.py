@@ -57,7 +57,7 @@ _SIGNATURES = {
     "hscn_scn_resident_supported": (c_int, [c_int] * 5),
     "hscn_scn_resident_param_count": (c_int64, [c_int] * 3),
     "hscn_scn_resident_fwd": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P, P, P,
-                                      c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+                                      c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "hscn_scn_resident_bwd": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P, P, P,
                                       P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "hscn_resident_supported": (c_int, [c_int] * 8),

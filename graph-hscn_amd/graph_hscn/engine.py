@@ -233,6 +233,7 @@ class ScnMeta:
     max_n: int
     max_e: int
     flag: Tensor
+    ticket: Optional[Tensor] = None     # device counter of the in-launch loss reduction (stays zero between launches)
 
     def check(self) -> None:
         f = int(self.flag.item())
@@ -249,11 +250,13 @@ def scn_meta(data, device) -> ScnMeta:
         return cached
     if "ptr32" in data and "eptr32" in data:
         meta = ScnMeta(data.ptr32.to(device), data.eptr32.to(device), int(data.num_graphs), int(data.max_nodes),
-                       int(data.max_edges), torch.zeros(1, dtype=torch.int32, device=device))
+                       int(data.max_edges), torch.zeros(1, dtype=torch.int32, device=device),
+                       torch.zeros(1, dtype=torch.int32, device=device))
     else:
         n, e = int(data.num_nodes), int(data.edge_index.size(1))
         meta = ScnMeta(torch.tensor([0, n], dtype=torch.int32, device=device),
                        torch.tensor([0, e], dtype=torch.int32, device=device), 1, n, e,
+                       torch.zeros(1, dtype=torch.int32, device=device),
                        torch.zeros(1, dtype=torch.int32, device=device))
     try:
         data._scn_meta = meta
@@ -263,7 +266,7 @@ def scn_meta(data, device) -> ScnMeta:
 
 
 class SCNResidentFn(Function):
-    """(x, raw edge_index, meta, act, W_rel, b_rel, W_root, W_mlp, b_mlp) -> (S, mc_loss, o_loss).
+    """(x, raw edge_index, meta, act, W_rel, b_rel, W_root, W_mlp, b_mlp) -> (S, mc_loss, o_loss, mc_loss + o_loss).
     The two losses are separate autograd outputs (0-dim views of one [2] buffer the launch fills), so
     ``(mc + o).backward()`` reaches the backward launch as two scalar gradients with no glue kernels
     in between (slicing one [2] output cost six fill / copy / add launches per step)."""
@@ -281,7 +284,9 @@ class SCNResidentFn(Function):
         y = torch.empty(N, H, dtype=torch.float32, device=dev)
         stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
         ss = torch.empty(B, K, K, dtype=torch.float32, device=dev)
-        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        if meta.ticket is None:
+            meta.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         E = edge_index.size(1)
         # both CSRs, agg = A_hat x and the out-degree: built in LDS by the forward launch, kept for the backward
         need_bwd = any(ctx.needs_input_grad[4:])
@@ -292,17 +297,17 @@ class SCNResidentFn(Function):
                   torch.empty(max(N, 1), 16, dtype=torch.float32, device=dev), torch.empty(max(N, 1), dtype=torch.float32, device=dev))
         call("hscn_scn_resident_fwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
              F, H, K, act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), meta.max_n, meta.max_e,
-             ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(losses), *([ptr(t) for t in ex] if ex else [None] * 6),
+             ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(losses), ptr(meta.ticket), *([ptr(t) for t in ex] if ex else [None] * 6),
              ptr(meta.flag), stream())
         ctx.ex = ex
         ctx.meta, ctx.act, ctx.dims = meta, act, (N, F, H, K, B, E)
         ctx.save_for_backward(x, edge_index, W_mlp, S, y, stats, ss)
         ctx.mark_non_differentiable(S)
         ctx.set_materialize_grads(False)
-        return S, losses[0], losses[1]
+        return S, losses[0], losses[1], losses[2]
 
     @staticmethod
-    def backward(ctx, gS, g_mc, g_o):
+    def backward(ctx, gS, g_mc, g_o, g_total):
         x, edge_index, W_mlp, S, y, stats, ss = ctx.saved_tensors
         meta: ScnMeta = ctx.meta
         N, F, H, K, B, E = ctx.dims
@@ -310,6 +315,9 @@ class SCNResidentFn(Function):
         P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
         partials = torch.empty(B, P, dtype=torch.float32, device=dev)
         grads = torch.empty(P, dtype=torch.float32, device=dev)
+        if g_total is not None:            # d(mc + o): the same scalar reaches both losses
+            g_mc = g_total if g_mc is None else g_mc + g_total
+            g_o = g_total if g_o is None else g_o + g_total
         g_mc = None if g_mc is None else g_mc.reshape(1).contiguous()
         g_o = None if g_o is None else g_o.reshape(1).contiguous()
         call("hscn_scn_resident_bwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,

@@ -89,28 +89,31 @@ class SCN(nn.Module):
         from .._hip import lib
         return bool(lib().hscn_scn_resident_supported(F, H, K, meta.max_n, meta.max_e))
 
-    def forward_graphs(self, data):
+    def forward_graphs(self, data, with_total: bool = False):
         """The body of the reference's clustering loop (train/train_clustering.py:37-47) for one
         ``Data`` graph or a block-diagonal ``Batch`` of RAW graphs: gcn_norm(add_self_loops=True),
         forward, MinCUT + orthogonality losses -- one fused launch when the model is the
         reference's shape (mp_units=[H], mlp_units=[]), else the layered operators.
-        Returns ``(softmax [N,K], mc_loss, o_loss)`` (losses = mean over the graphs)."""
+        Returns ``(softmax [N,K], mc_loss, o_loss)`` (losses = mean over the graphs); with
+        ``with_total`` also ``mc_loss + o_loss`` (train_clustering.py:48), which the fused launch
+        produces itself -- no add launch, and its backward reaches the kernel as one scalar."""
         dev = self.mp.module_0.lin_rel.weight.device
         if self.resident_ok(data):
             conv, lin = self.mp.module_0, list(self.mlp)[0]
             meta = _engine.scn_meta(data, dev)
             x = data.x if data.x.is_cuda else data.x.to(dev)
             ei = data.edge_index if data.edge_index.is_cuda else data.edge_index.to(dev)
-            S, mc, o = _engine.SCNResidentFn.apply(x.float(), ei, meta, _engine.ACT[self.mp.act], conv.lin_rel.weight,
-                                                   conv.lin_rel.bias, conv.lin_root.weight, lin.weight, lin.bias)
+            S, mc, o, total = _engine.SCNResidentFn.apply(x.float(), ei, meta, _engine.ACT[self.mp.act],
+                                                          conv.lin_rel.weight, conv.lin_rel.bias, conv.lin_root.weight,
+                                                          lin.weight, lin.bias)
             self.last_engine = "resident"
-            return S, mc, o
+            return (S, mc, o, total) if with_total else (S, mc, o)
         from ..nn.pool import gcn_norm
         self.last_engine = "layered"
         ei, ew = gcn_norm(data.edge_index.to(dev), None, int(data.num_nodes), add_self_loops=True)
         node_ptr = data.ptr.to(dev).to(torch.int32) if "ptr" in data and data.ptr is not None else None
         S, mc, o, _ = self.forward(data.x.to(dev).float(), ei, ew, node_ptr=node_ptr)
-        return S, mc, o
+        return (S, mc, o, mc + o) if with_total else (S, mc, o)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
                 node_ptr: Optional[Tensor] = None):

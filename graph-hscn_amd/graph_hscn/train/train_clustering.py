@@ -34,8 +34,8 @@ def _forward(model: SCN, graphs: Sequence, device) -> tuple:
     # fused graph-resident path (gcn_norm folded into the kernel) whenever the model/graphs qualify
     data = graphs[0] if len(graphs) == 1 else Batch.from_data_list(list(graphs))
     if getattr(data, "edge_weight", None) is None and model.resident_ok(data):
-        S, mc, o = model.forward_graphs(data)
-        return (S, mc, o, None), (None if len(graphs) == 1 else data.ptr)
+        S, mc, o, total = model.forward_graphs(data, with_total=True)
+        return (S, mc, o, total), (None if len(graphs) == 1 else data.ptr)
     if len(graphs) == 1:
         g = graphs[0]
         ei, ew = gcn_norm(g.edge_index.to(device), getattr(g, "edge_weight", None), g.num_nodes,
@@ -61,8 +61,10 @@ def train_clustering(logger, dataset, model: SCN, model_cfg, optim_cfg, training
         for i in range(0, n, batch_graphs):
             graphs = [dataset[j] for j in range(i, min(i + batch_graphs, n))]
             optimizer.zero_grad()
-            (_, mc_loss, o_loss, _), _ = _forward(model, graphs, device)
-            loss = mc_loss + o_loss
+            (_, mc_loss, o_loss, total), _ = _forward(model, graphs, device)
+            # train_clustering.py:48  loss = mc_loss + o_loss (the fused launch already holds the sum;
+            # on the layered path the 4th slot is the dense adjacency placeholder, not a loss)
+            loss = total if model.last_engine == "resident" and total is not None else mc_loss + o_loss
             loss.backward()
             optimizer.step()
     cluster_all_lst: List[np.ndarray] = []

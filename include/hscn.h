@@ -373,7 +373,10 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
  *   graph g owns nodes [nptr[g],nptr[g+1]) and edges [eptr[g],eptr[g+1]);
  *   outputs S [N,K] (= softmax, the reference's first return), y [N,H] (post-activation
  *   GraphConv output, kept for the backward), stats [B,4] {num, den, |S^T S|_F, ortho},
- *   ss [B,K,K], losses [2] = {mean mincut, mean ortho}.
+ *   ss [B,K,K], losses [3] = {mean mincut, mean ortho, their sum (what the training loop minimises,
+ *   train/train_clustering.py:48)}.  ticket: a device int32 that is zero before the first launch; with
+ *   it the workgroup that finishes last reduces the per-graph statistics inside the launch (and leaves
+ *   the counter at zero), without it a one-wave launch does.  Same summation order either way.
  * hscn_scn_resident_bwd: grads packed as {W_rel [H,F], b_rel [H], W_root [H,F], W_mlp [K,H],
  * b_mlp [K]} given the upstream scalars g_mc = dL/dmincut, g_o = dL/dortho as two device pointers
  * (the two losses are separate autograd outputs; NULL = that loss received no gradient).
@@ -388,7 +391,8 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
                           const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
-                          float* losses, int32_t* ex_rowptr_d /*[N+B]*/, int32_t* ex_col_d /*[E]*/,
+                          float* losses /*[3]*/, int32_t* ticket /*[1] or NULL*/, int32_t* ex_rowptr_d /*[N+B]*/,
+                          int32_t* ex_col_d /*[E]*/,
                           int32_t* ex_rowptr_s /*[N+B]*/, int32_t* ex_col_s /*[E]*/, float* ex_agg /*[N,16]*/,
                           float* ex_dout /*[N]*/, int32_t* flag, void* stream);
 int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,

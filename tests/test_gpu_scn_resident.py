@@ -101,3 +101,53 @@ def test_reproducible_and_flags_bad_edges():
     pm.forward_graphs(big)
     with pytest.raises(IndexError):
         big._scn_meta.check()
+
+
+def test_total_loss_from_the_launch_equals_the_sum_and_its_gradients():
+    """forward_graphs(with_total=True)[3] (mc + o written by the forward launch, reduced by the
+    workgroup that finishes last) == mc + o, and backward through it == backward through the explicit
+    sum, over repeated launches (the ticket counter returns to zero) and under a captured replay."""
+    from graph_hscn.data import Batch
+    from graph_hscn.loader.synthetic import make_dataset
+    _, pm = _models(16)
+    big = Batch.from_data_list(make_dataset("peptides_func", 40, seed=2)).to(DEV)
+    big.x = big.x.float()
+    ref = None
+    for rep in range(3):
+        pm.zero_grad(set_to_none=True)
+        S, mc, o, total = pm.forward_graphs(big, with_total=True)
+        assert torch.equal(total, mc + o)
+        (mc + o).backward()
+        g_sum = [p.grad.clone() for p in pm.parameters()]
+        pm.zero_grad(set_to_none=True)
+        pm.forward_graphs(big, with_total=True)[3].backward()
+        g_tot = [p.grad.clone() for p in pm.parameters()]
+        assert all(torch.equal(a, b) for a, b in zip(g_sum, g_tot))
+        assert int(big._scn_meta.ticket.item()) == 0
+        if ref is None:
+            ref = (mc.detach().clone(), o.detach().clone(), g_tot)
+        else:
+            assert torch.equal(mc, ref[0]) and torch.equal(o, ref[1])
+    del S, mc, o, total
+
+    def step():
+        pm.zero_grad(set_to_none=True)
+        t = pm.forward_graphs(big, with_total=True)[3]
+        t.backward()
+        return t.detach()
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tot = step()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tot, ref[0] + ref[1])
+    assert all(torch.equal(p.grad, g) for p, g in zip(pm.parameters(), ref[2]))
