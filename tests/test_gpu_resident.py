@@ -232,3 +232,54 @@ def test_deferred_virtual_branch_inside_a_captured_step():
     for n, p in pm.named_parameters():
         if n in eager:
             assert torch.equal(p.grad, eager[n]), n
+
+
+def test_degenerate_graphs_in_a_batch():
+    """Ragged / empty inputs through both launches of a training step: a single node without edges, a
+    graph with nodes but no edges, a graph whose nodes all fall in one cluster, a two-node graph, next to
+    ordinary graphs.  Compared with the CPU oracle (prediction, final virtual features, gradients)."""
+    from graph_hscn.data import Data, HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn import engine
+    K, H, L, C = 8, 16, 3, 10
+    normal = make_dataset("peptides_func", 3, seed=11)
+    F = normal[0].x.size(1)
+    g = torch.Generator().manual_seed(5)
+
+    def mk(n, edges):
+        ei = torch.tensor(edges, dtype=torch.int64).t().reshape(2, -1) if edges else torch.zeros(2, 0, dtype=torch.int64)
+        return Data(x=torch.randint(0, 5, (n, F), generator=g).float(), edge_index=ei,
+                    y=torch.zeros(1, C), num_nodes=n)
+
+    graphs = [normal[0], mk(1, []), mk(5, []), normal[1], mk(7, [(0, 1), (1, 0), (2, 3), (3, 2), (5, 6), (6, 5)]),
+              mk(2, [(0, 1), (1, 0)]), normal[2]]
+    rng = np.random.default_rng(3)
+    ids = [rng.integers(0, K, gr.num_nodes) for gr in graphs]
+    ids[4] = np.full(7, 3)                       # one cluster only
+    ob = OH.collate_hetero([OH.hetero_from_clusters(gr.x, gr.edge_index, gr.y, i, K) for gr, i in zip(graphs, ids)])
+    pb = HeteroBatch.from_data_list([hetero_from_clusters(gr, i, K) for gr, i in zip(graphs, ids)]).to(DEV)
+    B = len(graphs)
+    om, pm = _models(F, H, C, L, "relu", seed=9)
+    pm.engine = "resident"
+    out_o = om(ob["x_dict"], ob["edge_index_dict"], ob["batch_local"], B)
+    gsel = torch.randn(B, C, generator=torch.Generator().manual_seed(1))
+    (out_o * gsel).sum().backward()
+    xo = ob["x_dict"]
+    for conv in om.convs:
+        xo = {k: v.relu() for k, v in conv(xo, ob["edge_index_dict"]).items()}
+    for overlap in (False, True):
+        pm.overlap_virtual, pm.keep_virtual = overlap, not overlap
+        pm.zero_grad(set_to_none=True)
+        out_d = pm(pb.x_dict, pb.edge_index_dict, pb)
+        (out_d * gsel.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        pb._resident_meta.check()
+        assert close(out_d, out_o, atol=ATOL, rtol=1e-5)
+        xv = engine.last_deferred_virtual if overlap else pm.last_virtual
+        assert close(xv[: xo["virtual"].size(0)], xo["virtual"], atol=3e-5, rtol=1e-5)
+        go = {n: p.grad for n, p in om.named_parameters() if p.grad is not None}
+        gd = {n: p.grad for n, p in pm.named_parameters() if p.grad is not None}
+        assert go.keys() == gd.keys()
+        for n in go:
+            assert close(gd[n], go[n], atol=1e-4, rtol=1e-3), n

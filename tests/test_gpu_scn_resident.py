@@ -151,3 +151,38 @@ def test_total_loss_from_the_launch_equals_the_sum_and_its_gradients():
     torch.cuda.synchronize()
     assert torch.equal(tot, ref[0] + ref[1])
     assert all(torch.equal(p.grad, g) for p, g in zip(pm.parameters(), ref[2]))
+
+
+@pytest.mark.parametrize("K", [5, 16])
+def test_degenerate_graphs_match_the_oracle_loop_body(K):
+    """A single node without edges, nodes without edges, a two-node graph, a star: each through the fused
+    launches as a graph of its own and as one batch (odd K takes the scalar paths of the kernels)."""
+    from graph_hscn.data import Batch, Data
+    om, pm = _models(K, 16, "elu", 9, seed=7)
+    g = torch.Generator().manual_seed(3)
+
+    def mk(n, edges):
+        ei = torch.tensor(edges, dtype=torch.int64).t().reshape(2, -1) if edges else torch.zeros(2, 0, dtype=torch.int64)
+        return Data(x=torch.randint(0, 7, (n, 9), generator=g).float(), edge_index=ei, num_nodes=n)
+
+    star = [(0, i) for i in range(1, 9)] + [(i, 0) for i in range(1, 9)]
+    graphs = [mk(1, []), mk(4, []), mk(2, [(0, 1), (1, 0)]), mk(9, star)]
+    ref = []
+    for gr in graphs:
+        om.zero_grad(); pm.zero_grad()
+        S_o, mc_o, o_o, *_ = OM.scn_step_single_graph(om, gr.x, gr.edge_index)
+        (mc_o + o_o).backward()
+        S_d, mc_d, o_d = pm.forward_graphs(gr)
+        assert pm.last_engine == "resident"
+        (mc_d + o_d).backward()
+        gr._scn_meta.check()
+        assert close(S_d, S_o)
+        assert abs(mc_d.item() - mc_o.item()) < ATOL and abs(o_d.item() - o_o.item()) < ATOL
+        for (n_, po), (_, pp) in zip(om.named_parameters(), pm.named_parameters()):
+            assert close(pp.grad, po.grad, atol=1e-4, rtol=2e-3), n_
+        ref.append((mc_o.item(), o_o.item()))
+    big = Batch.from_data_list(graphs)
+    with torch.no_grad():
+        _, mc, o = pm.forward_graphs(big)
+    assert abs(mc.item() - np.mean([r[0] for r in ref])) < ATOL
+    assert abs(o.item() - np.mean([r[1] for r in ref])) < ATOL
