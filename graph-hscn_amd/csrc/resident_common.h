@@ -72,6 +72,28 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   const float r2 = __int_as_float(__builtin_amdgcn_readlane(r, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(r, 48));
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+// reductions over aligned groups of KP consecutive lanes (KP a power of two; every lane of the group
+// receives the result): DPP inside a 16-lane row (xor 1, xor 2, mirror inside 8, mirror inside 16),
+// bpermute only across rows
+__device__ __forceinline__ float seg_sum(float v, int KP) {
+  if (KP >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  if (KP >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  if (KP >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  if (KP >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  if (KP >= 32) v += __shfl_xor(v, 16, 64);
+  if (KP >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float seg_max(float v, int KP) {
+  if (KP >= 2) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  if (KP >= 4) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  if (KP >= 8) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  if (KP >= 16) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  if (KP >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  if (KP >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
 // v + (the lane `off` away inside the 16-lane DPP row, rotation): with off = 8 then 4 every lane ends
 // with the sum over the four lanes congruent to it mod 4 (the same pairs as an xor butterfly)
 template <int OFF>

@@ -66,7 +66,7 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   Y.dinv = take(max_n);
   Y.dout = take(max_n);
   Y.wt = take((size_t)2 * H * FP + H + (size_t)K * H + K + (size_t)K * K);  // W_rel^T | W_root^T | b_rel | W_mlp^T | b_mlp | Gss
-  Y.red = take(1024);
+  Y.red = take(64 + 4096);   // 64 words of wave partials, then 16 waves x one 16 x 16 partial tile (gram_mfma)
   Y.vecs = take(64);
   Y.rowptr_d = take(max_n + 1);
   Y.col_d = take(max_e);
@@ -82,47 +82,46 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   return Y;
 }
 
-// gW[o][k] (O x Kc, row stride ldo) += sum_j Gm[j][o] * Xm[j][k] over the graph's n rows:
-// 4x4 tiles, a 16-lane DPP row per tile, rows split over the row's lanes; written to out.
-// O, Kc multiples of 4 (zero padded columns allowed); kmax: only k < kmax is stored.
+// out[o][k] = sum_j Am[j][o] * Bm[j][k]  (o < O, k < Kc; O, Kc <= 64; k < kmax stored) on
+// v_mfma_f32_16x16x4_f32: a wave owns one 16 x 16 tile and a strided set of 4-row chunks of j (operands
+// are single LDS words per lane, consecutive lanes on consecutive addresses, ragged edges read as 0);
+// the waves that share a tile fold their partial tiles through `scratch` [NW][256] in a fixed order.
+// Contains workgroup barriers.  `out` may be LDS or global.
 template <int NW>
-__device__ void outer_sum(const float* Gm, int ldg, int O, const float* Xm, int ldx, int Kc, int n, float* out,
-                          int ldo, int kmax) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = lane >> 4, l16 = lane & 15;
-  const int tk = Kc / 4, nt = (O / 4) * tk;
-  for (int t0 = wave * 4; t0 < nt; t0 += NW * 4) {
-    const int tile = t0 + row;
-    const bool live = tile < nt;
-    const int o4 = live ? (tile / tk) * 4 : 0, k4 = live ? (tile % tk) * 4 : 0;
-    float acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    if (live)
-      for (int j = l16; j < n; j += 16) {
-        const float4 gv = *reinterpret_cast<const float4*>(Gm + (size_t)j * ldg + o4);
-        const float4 xv = *reinterpret_cast<const float4*>(Xm + (size_t)j * ldx + k4);
-        const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
-        const float xb[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(ga[a], xb[b], acc[a][b]);
-      }
-    float mine = 0.f;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float v = row16_sum(acc[a][b]);
-        if (l16 == a * 4 + b) mine = v;
-      }
+__device__ void gram_mfma(const float* Am, int lda, int O, const float* Bm, int ldb, int Kc, int n, float* scratch,
+                          float* out, int ldo, int kmax) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lj = lane >> 4;
+  const int TO = (O + 15) >> 4, TK = (Kc + 15) >> 4, NT = TO * TK;
+  const int TPP = NT < NW ? NT : NW, RG = NW / TPP;
+  for (int t0 = 0; t0 < NT; t0 += TPP) {
+    const int tl = wave % TPP, rg = wave / TPP, tile = t0 + tl;
+    const bool live = tile < NT && rg < RG;
     if (live) {
-      const int oo = o4 + (l16 >> 2), kk = k4 + (l16 & 3);
-      if (kk < kmax) out[(size_t)oo * ldo + kk] = mine;
+      const int o0 = (tile / TK) * 16, k0 = (tile % TK) * 16;
+      const bool oa = o0 + li < O, ob = k0 + li < Kc;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int j0 = rg * 4; j0 < n; j0 += 4 * RG) {
+        const int j = j0 + lj;
+        const bool ok = j < n;
+        const float av = (ok && oa) ? Am[(size_t)j * lda + o0 + li] : 0.f;
+        const float bv = (ok && ob) ? Bm[(size_t)j * ldb + k0 + li] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scratch[(rg * TPP + tl) * 256 + (lj * 4 + r) * 16 + li] = acc[r];
     }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TPP * 256; idx += SRT) {
+      const int t_ = t0 + idx / 256, e_ = idx & 255;
+      if (t_ < NT) {
+        float s_ = 0.f;
+        for (int r = 0; r < RG; ++r) s_ += scratch[(r * TPP + idx / 256) * 256 + e_];
+        const int oo = (t_ / TK) * 16 + (e_ >> 4), kk = (t_ % TK) * 16 + (e_ & 15);
+        if (oo < O && kk < kmax) out[(size_t)oo * ldo + kk] = s_;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -162,6 +161,24 @@ __device__ void col_sum(const float* M, int ld, int C, int n, float* out, float*
     for (int w = 0; w < NW; ++w) s_ += scratch[w * C + c];
     out[c] = s_;
   }
+}
+
+// sum_{p in [s, t)} M[col[p] * ld + k], added in p order; four column reads and four row reads of a
+// trip are issued together (the rows have a handful of entries: latency, not bandwidth)
+__device__ __forceinline__ float gather_sum(const int* col, int s, int t, const float* M, int ld, int k) {
+  float a = 0.f;
+  for (int p0 = s; p0 < t; p0 += 4) {
+    int j[4];
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) j[u] = (p0 + u < t) ? col[p0 + u] : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = M[j[u] * ld + k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u < t) a += v[u];
+  }
+  return a;
 }
 
 // one wave: losses = {mean_g -num_g/den_g, mean_g ortho_g, their sum} from stats [G,4]
@@ -291,6 +308,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   if (threadIdx.x < H) brl[threadIdx.x] = vb;
   if ((int)threadIdx.x < K) bml[threadIdx.x] = vm;
   lds_barrier();
+  STAMP(1);
   // ---- structure: the two CSRs side by side (same barrier sequence in both wave groups) ----
   {
     const bool second = wave >= NW / 2;
@@ -304,6 +322,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
     dout[i] = (float)(rowptr_s[i + 1] - rowptr_s[i]) + 1.0f;               // row sum of binary A + I
   }
   lds_barrier();
+  STAMP(2);
   // agg_i = sum_{j->i} (dinv_j * 1 * dinv_i) x_j  (edge order)  +  (dinv_i * 1 * dinv_i) x_i  (loop last)
   {
     constexpr int LPR = FP / 4;
@@ -338,6 +357,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
     for (int i = threadIdx.x; i < n; i += SRT) A.ex_dout[(size_t)n0 + i] = dout[i];
   }
   lds_barrier();
+  STAMP(3);
 }
 
 template <int H>
@@ -364,6 +384,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   float* bml = WmT + (size_t)H * K;  // [K]
   int *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
+  STAMP(0);
   scn_front<H>(A, Y, fb, ib, n0, n, e0, ne, g);
 
   // y = act(W_rel agg + b_rel + W_root x): thread (row, o); both weight columns in registers
@@ -390,6 +411,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
     }
   }
   __syncthreads();
+  STAMP(4);
   // logits + softmax: KP lanes per row (KP = pow2 >= K), x / agg are dead: S overlays them
   {
     int KP = 1;
@@ -411,11 +433,9 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
         }
         s = a + bk;
       }
-      float m = s;
-      for (int off = KP >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      const float m = seg_max(s, KP);
       const float ex = k < K ? expf(s - m) : 0.f;
-      float sum = ex;
-      for (int off = KP >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      const float sum = seg_sum(ex, KP);
       // all rows of this pass were read (y) before S overwrites x/agg: y lives in R2, S in R1 -- no overlap
       if (k < K) {
         const float v = ex / sum;
@@ -425,6 +445,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
     }
   }
   __syncthreads();
+  STAMP(5);
   // MinCUT statistics on the binary A + I
   //   num = sum_i S_i . (sum_{p in row_s(i)} S[col] + S_i),  den = sum_i dout_i |S_i|^2,  ss = S^T S
   {
@@ -432,8 +453,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
     for (int idx = threadIdx.x; idx < n * K; idx += SRT) {
       const int i = idx / K, k = idx - i * K;
       const float sv = Sl[idx];
-      float as = 0.f;
-      for (int p = rowptr_s[i]; p < rowptr_s[i + 1]; ++p) as += Sl[col_s[p] * K + k];
+      float as = gather_sum(col_s, rowptr_s[i], rowptr_s[i + 1], Sl, K, k);
       as += sv;
       num = fmaf(sv, as, num);
       den = fmaf(dout[i], sv * sv, den);
@@ -445,17 +465,9 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   // ss = S^T S through the tile outer product into LDS, then to global
   float* ssl = bml + K;  // [K][K] (the slot the backward uses for Gss)
   const int KK = K * K;
-  if ((K & 3) == 0) {
-    outer_sum<NW>(Sl, K, K, Sl, K, K, n, ssl, K, K);
-  } else {
-    for (int idx = threadIdx.x; idx < KK; idx += SRT) {
-      const int a = idx / K, b = idx - a * K;
-      float s = 0.f;
-      for (int i = 0; i < n; ++i) s = fmaf(Sl[i * K + a], Sl[i * K + b], s);
-      ssl[idx] = s;
-    }
-  }
+  gram_mfma<NW>(Sl, K, K, Sl, K, K, n, red + 64, ssl, K, K);
   __syncthreads();
+  STAMP(6);
   for (int idx = threadIdx.x; idx < KK; idx += SRT) A.ss[(size_t)g * KK + idx] = ssl[idx];
   if (threadIdx.x < 64) {
     float num = 0.f, den = 0.f;
@@ -495,6 +507,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
       }
     }
   }
+  STAMP(63);
 }
 
 template <int H>
@@ -513,7 +526,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   const ScnLayout Y = scn_layout(H, K, A.max_n, A.max_e, 1);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
   float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = agg + (size_t)A.max_n * FP;
   float *yl = fb + Y.R2, *DL = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;
   float* WmT = fb + Y.wt + 2 * FP * H + H;   // [H][K] (same offsets as the forward's weight block)
@@ -521,6 +534,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   float* ssl = fb + Y.ssl;                   // [K][K] the forward's S^T S
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
+  STAMP(0);
   // ---- front: everything comes from HBM in one batch of requests -- the CSRs, agg and the binary
   // out-degree the forward launch exported, x, S and y, W_mlp -- then is parked in LDS
   {
@@ -624,6 +638,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   const float isk = 1.0f / sqrtf((float)K);
   const float* ssg = ssl;
   __syncthreads();   // the front's LDS stores
+  STAMP(1);
   if (threadIdx.x < 64) {
     float v = 0.f;
     if (o > 0.f)
@@ -635,6 +650,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
     if (lane == 0) red[0] = v;
   }
   __syncthreads();
+  STAMP(2);
   const float inner = red[0];
   for (int i = threadIdx.x; i < KK; i += SRT) {
     const int a = i / K, b = i - a * K;
@@ -642,6 +658,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
     Gss[i] = (gq - inner / (nrm * nrm) * ssg[i]) / nrm;
   }
   __syncthreads();
+  STAMP(3);
   // dS -> DL, then dlogits = S * (dS - <dS, S>) in place (KP lanes per row)
   const float c_num = -gmc / den, c_den = gmc * num / (den * den);
   {
@@ -655,9 +672,8 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
       float dS = 0.f, sv = 0.f;
       if (k < K) {
         sv = Sl[i * K + k];
-        float as = 0.f;
-        for (int p = rowptr_s[i]; p < rowptr_s[i + 1]; ++p) as += Sl[col_s[p] * K + k];   // (A S)_i
-        for (int p = rowptr_d[i]; p < rowptr_d[i + 1]; ++p) as += Sl[col_d[p] * K + k];   // (A^T S)_i
+        float as = gather_sum(col_s, rowptr_s[i], rowptr_s[i + 1], Sl, K, k);             // (A S)_i
+        as += gather_sum(col_d, rowptr_d[i], rowptr_d[i + 1], Sl, K, k);                  // (A^T S)_i
         as += 2.f * sv;                                                                   // the two identity terms
         float orth = 0.f;
         if (K <= 32 && (K & 3) == 0) {
@@ -674,26 +690,18 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
         }
         dS = c_num * as + c_den * 2.f * dout[i] * sv + go * 2.f * orth;
       }
-      float dot = dS * sv;
-      for (int off = KP >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+      const float dot = seg_sum(dS * sv, KP);
       if (k < K) DL[i * K + k] = sv * (dS - dot);
     }
   }
   __syncthreads();
+  STAMP(4);
   // parameter-gradient partials.  layout: W_rel [H*F], b_rel [H], W_root [H*F], W_mlp [K*H], b_mlp [K]
   const int oWrel = 0, obrel = H * A.F, oWroot = obrel + H, oWmlp = oWroot + H * A.F, obmlp = oWmlp + K * H;
-  if ((K & 3) == 0) {
-    outer_sum<NW>(DL, K, K, yl, H, H, n, part + oWmlp, H, H);          // dW_mlp[k][h] = sum_i DL[i][k] y[i][h]
-  } else {
-    for (int idx = threadIdx.x; idx < K * H; idx += SRT) {
-      const int k = idx / H, h = idx - k * H;
-      float s = 0.f;
-      for (int i = 0; i < n; ++i) s = fmaf(DL[i * K + k], yl[i * H + h], s);
-      part[oWmlp + idx] = s;
-    }
-  }
+  gram_mfma<NW>(DL, K, K, yl, H, H, n, red + 64, part + oWmlp, H, H);   // dW_mlp[k][h] = sum_i DL[i][k] y[i][h]
   col_sum<NW>(DL, K, K, n, part + obmlp, red);
   __syncthreads();
+  STAMP(5);
   // dz = (DL W_mlp) * act'(y)  in place over y: thread (row, h)
   {
     const int h = threadIdx.x % H, r0 = threadIdx.x / H;
@@ -722,9 +730,11 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
     }
   }
   __syncthreads();
-  outer_sum<NW>(yl, H, H, agg, FP, FP, n, part + oWrel, A.F, A.F);     // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
-  outer_sum<NW>(yl, H, H, xs, FP, FP, n, part + oWroot, A.F, A.F);     // dW_root[o][k] = sum_i dz[i][o] x[i][k]
+  STAMP(6);
+  gram_mfma<NW>(yl, H, H, agg, FP, FP, n, red + 64, part + oWrel, A.F, A.F);    // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
+  gram_mfma<NW>(yl, H, H, xs, FP, FP, n, red + 64, part + oWroot, A.F, A.F);    // dW_root[o][k] = sum_i dz[i][o] x[i][k]
   col_sum<NW>(yl, H, H, n, part + obrel, red);
+  STAMP(63);
 }
 
 __global__ void k_scn_losses(const float* __restrict__ stats, float* __restrict__ losses, int G) {
@@ -753,6 +763,12 @@ int launch_scn(ScnArgs& A, int bwd, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+#ifdef HSCN_STAMPS
+int hscn_diag_set_stamp_buffer_scn(long long* buf) {   // this translation unit's copy of the stamp pointer
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+}
+#endif
 
 int hscn_scn_resident_supported(int F, int H, int K, int max_n, int max_e) {
   if (!(H == 16 || H == 32) || F < 1 || F > FP || K < 1 || K > 64 || max_n < 0 || max_e < 0) return 0;
