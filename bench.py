@@ -207,9 +207,7 @@ def main():
     torch.manual_seed(0)  # identical replicas
     model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], F, args.hidden, C, args.layers).to(dev)
     model.engine = args.engine
-    reducer = FlatGradReducer(model) if (world > 1 or force_dist) else None
-    if reducer is not None and force_dist:
-        reducer.__class__ = type("ForcedReducer", (FlatGradReducer,), {"world_size": property(lambda self: 2)})
+    reducer = FlatGradReducer(model, single_rank_collective=force_dist) if (world > 1 or force_dist) else None
     x_dict, ei_dict = hb.x_dict, hb.edge_index_dict
     root_grad = torch.ones((), dtype=torch.float32, device=dev)   # = loss.backward()'s implicit ones_like(loss)
 

@@ -56,9 +56,11 @@ class FlatGradReducer:
     gradient of the mean loss over the whole (unsharded) batch -- the reference's
     ``criterion`` is a mean over B x C elements (loss.py:9,16)."""
 
-    def __init__(self, module: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, module: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None,
+                 single_rank_collective: bool = False):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.group = process_group
+        self.always = single_rank_collective   # issue the collective even in a world of one (exercises the RCCL path)
         self._flat: Optional[torch.Tensor] = None
         self._mask: Optional[List[bool]] = None
         self.last_path: Optional[str] = None
@@ -110,7 +112,7 @@ class FlatGradReducer:
         if not grads:
             return
         ws = self.world_size
-        if ws <= 1:
+        if ws <= 1 and not (self.always and dist.is_initialized()):
             return
         if total_weight is not None:
             scale = float(local_weight) / float(total_weight)      # known up front: no host sync
