@@ -229,20 +229,23 @@ def main():
 
     graph = None
     if args.mode == "graph":
+        # HSCN_BENCH_GRAPH_ALLREDUCE=1 captures the gradient all-reduce into the step's hipGraph as well
+        # (RCCL kernels are capturable); default: the collective is issued eagerly after each replay
+        in_graph = reducer is not None and os.environ.get("HSCN_BENCH_GRAPH_ALLREDUCE") == "1"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                fwd_bwd()
+                step_eager() if in_graph else fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            static_loss = fwd_bwd()
+            static_loss = step_eager() if in_graph else fwd_bwd()
 
         def step():
             graph.replay()
-            if reducer is not None:
+            if reducer is not None and not in_graph:
                 reducer.reduce(B, B * world)
             return static_loss
     else:
