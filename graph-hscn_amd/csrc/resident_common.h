@@ -137,26 +137,50 @@ __device__ void scan_inclusive_lds(int* a, int n, int* wsum /*[nw]*/, const Grp&
 }
 
 // ---- stable CSR from staged edges (local ids; key -1 = dropped): low-degree rows --------------
-// rowptr[0..nrows], col[ne]; rows keep ascending edge order.  Placement by LDS int atomics
-// (arrival order), then every edge ranks itself inside its row by edge number: O(degree) per
-// edge, meant for rows of a few edges.  cursor: [nrows+1], tmp: [ne].  Six barriers.
+// rowptr[0..nrows], col[ne]; rows keep ascending edge order.  Counting and placement by LDS int
+// atomics on ONE counter array (counted up, then taken back down to zero by the placement: the slot
+// an edge receives is arbitrary, the final order is not), then every edge ranks itself inside its row
+// by edge number: O(degree) per edge, meant for rows of a few edges.  The prefix sum needs no barrier
+// of its own: a wave re-adds the counts in front of its slice instead of waiting for the waves that
+// own them.  cursor: [nrows+1], ZERO on entry unless zero_first, zero again on exit; tmp: [ne].
+// Four workgroup barriers (five with zero_first).
+constexpr int CSR_BUILD_BARRIERS = 4;
 __device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, int* rowptr, int* col, int* cursor,
-                              int* tmp, int* wsum, const Grp& G) {
-  for (int i = G.t; i <= nrows; i += G.nt) {
-    rowptr[i] = 0;
-    cursor[i] = 0;
+                              int* tmp, const Grp& G, bool zero_first) {
+  if (zero_first) {
+    for (int i = G.t; i <= nrows; i += G.nt) cursor[i] = 0;
+    lds_barrier();
   }
-  lds_barrier();
   for (int e = G.t; e < ne; e += G.nt) {
     const int k = ek[e];
-    if (k >= 0) atomicAdd(&rowptr[k + 1], 1);
+    if (k >= 0) atomicAdd(&cursor[k], 1);
   }
   lds_barrier();
-  scan_inclusive_lds(rowptr, nrows + 1, wsum, G);
+  {  // rowptr[i] = sum of the counts of rows < i  (exclusive scan), rowptr[nrows] = total
+    const int lane = threadIdx.x & 63;
+    const int per = (nrows + G.nt - 1) / G.nt;
+    const int wb = G.w * 64 * per;                         // first row of this wave's slice
+    int front = 0;
+    for (int j = lane; j < wb && j < nrows; j += 64) front += cursor[j];
+    front = __builtin_amdgcn_readlane(wave_incl_scan(front), 63);
+    const int b = G.t * per;
+    int s = 0;
+    for (int i = 0; i < per; ++i)
+      if (b + i < nrows) s += cursor[b + i];
+    int run = front + wave_incl_scan(s) - s;
+    for (int i = 0; i < per; ++i)
+      if (b + i < nrows) {
+        rowptr[b + i] = run;
+        run += cursor[b + i];
+        if (b + i == nrows - 1) rowptr[nrows] = run;
+      }
+    if (nrows == 0 && G.t == 0) rowptr[0] = 0;
+  }
+  lds_barrier();
   for (int e = G.t; e < ne; e += G.nt) {
     const int k = ek[e];
     if (k < 0) continue;
-    const int p = atomicAdd(&cursor[k], 1);
+    const int p = atomicAdd(&cursor[k], -1) - 1;
     tmp[rowptr[k] + p] = e;
   }
   lds_barrier();
@@ -176,6 +200,7 @@ __device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, i
 // cnt[row][chunk] by ballot, one scan over (row-major, chunk-minor) gives every
 // (row, chunk) its base slot, the rank inside the chunk is popcount(ballot & lanes below).
 // cnt: [nrows * ceil(ne/64)] ints, tmp: [ne].  Five barriers.
+constexpr int CSR_MULTISPLIT_BARRIERS = 5;
 __device__ void build_csr_multisplit_lds(const int* ek, const int* eo, int ne, int nrows, int* rowptr, int* col,
                                          int* cnt, int* tmp, int* wsum, const Grp& G) {
   const int nchunk = (ne + 63) >> 6;

@@ -218,7 +218,6 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   float* bml = WmT + (size_t)H * K;
   int *ek = ib + Y.ek, *eo = ib + Y.eo;
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
-  int* wsum = ib + Y.wsum;
   const int wave = threadIdx.x >> 6;
   const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
   // ---- requests ----
@@ -307,14 +306,18 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   }
   if (threadIdx.x < H) brl[threadIdx.x] = vb;
   if ((int)threadIdx.x < K) bml[threadIdx.x] = vm;
+  for (int i = threadIdx.x; i <= n; i += SRT) {   // the CSR builds count in these (and hand them back zeroed)
+    (ib + Y.cursor)[i] = 0;
+    (ib + Y.cursor2)[i] = 0;
+  }
   lds_barrier();
   STAMP(1);
   // ---- structure: the two CSRs side by side (same barrier sequence in both wave groups) ----
   {
     const bool second = wave >= NW / 2;
     const Grp GS{(int)threadIdx.x - (second ? (NW / 2) * 64 : 0), (NW / 2) * 64, wave - (second ? NW / 2 : 0), NW / 2};
-    if (!second) build_csr_lds(ek, eo, ne, n, rowptr_d, col_d, ib + Y.cursor, ib + Y.tmp, wsum, GS);   // rows = targets
-    else build_csr_lds(eo, ek, ne, n, rowptr_s, col_s, ib + Y.cursor2, ib + Y.tmp2, wsum + 16, GS);    // rows = sources
+    if (!second) build_csr_lds(ek, eo, ne, n, rowptr_d, col_d, ib + Y.cursor, ib + Y.tmp, GS, false);   // rows = targets
+    else build_csr_lds(eo, ek, ne, n, rowptr_s, col_s, ib + Y.cursor2, ib + Y.tmp2, GS, false);        // rows = sources
   }
   for (int i = threadIdx.x; i < n; i += SRT) {
     const float deg = (float)(rowptr_d[i + 1] - rowptr_d[i]) + 1.0f;        // scatter_add of unit weights + loop
