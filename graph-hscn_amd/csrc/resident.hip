@@ -562,11 +562,19 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       headw[H * H + H + A.C * H + idx] = idx == (int)threadIdx.x ? hb2 : A.b2[idx];
   }
   ws.store(wt);
+  // the CSR builds count in these (they hand them back zeroed)
+  for (int i = threadIdx.x; i <= n; i += RT) {
+    (ib + Y.cursorA)[i] = 0;
+    if (A.exp) (ib + Y.cursorT)[i] = 0;
+  }
+  if (cv)
+    for (int i = threadIdx.x; i <= nv; i += RT) (ib + Y.cursorV)[i] = 0;
   lds_barrier();
   STAMP(1);
   // ---- structure: the CSRs are independent, so wave groups build them side by side between the
-  // same six barriers: ll keyed by target (forward), ll keyed by source (exported for the backward
-  // launch), vv, and lv (multisplit: five barriers + one idle)
+  // same barriers: ll keyed by target (forward), ll keyed by source (exported for the backward
+  // launch), vv (four barriers each, one idle when the lv build runs beside them), and lv (multisplit:
+  // five barriers)
   {
     int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
     const int w_t = !A.exp ? 0 : (cv ? (NW * 3) / 8 : NW - NW / 2);          // 6 of 16 waves (1 of 4)
@@ -577,20 +585,22 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     const int wbase = wa == 0 ? 0 : (wa == 1 ? w_ll : (wa == 2 ? w_ll + w_t : w_ll + w_t + w_vv));
     const int wcnt = wa == 0 ? w_ll : (wa == 1 ? w_t : (wa == 2 ? w_vv : w_lv));
     const Grp GS{(int)threadIdx.x - wbase * 64, wcnt * 64, wave - wbase, wcnt};
+    static_assert(CSR_MULTISPLIT_BARRIERS == CSR_BUILD_BARRIERS + 1, "barrier sequences of the wave groups must match");
     if (wa == 0) {
-      build_csr_lds(ib + Y.ek_ll, ib + Y.eo_ll, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, wsum, GS);
+      build_csr_lds(ib + Y.ek_ll, ib + Y.eo_ll, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, GS, false);
       dinv_from_rowptr(rowptr, n, dinv, GS);
+      if (cv) lds_barrier();   // keeps step with the lv multisplit
     } else if (wa == 1) {
-      build_csr_lds(ib + Y.eo_ll, ib + Y.ek_ll, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, wsum + 8, GS);
+      build_csr_lds(ib + Y.eo_ll, ib + Y.ek_ll, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, GS, false);
+      if (cv) lds_barrier();
     } else if (wa == 2) {
-      build_csr_lds(ib + Y.ek_vv, ib + Y.eo_vv, nev, nv, rowptr_vv, col_vv, ib + Y.cursorV, ib + Y.tmpV, wsum + 16,
-                    GS);
+      build_csr_lds(ib + Y.ek_vv, ib + Y.eo_vv, nev, nv, rowptr_vv, col_vv, ib + Y.cursorV, ib + Y.tmpV, GS, false);
       dinv_from_rowptr(rowptr_vv, nv, dinv_v, GS);
+      lds_barrier();
     } else {
       build_csr_multisplit_lds(ib + Y.ek_lv, ib + Y.eo_lv, nel, nv, rowptr_lv, col_lv, ib + Y.cursorB, ib + Y.tmpB,
                                wsum + 24, GS);
       if (GS.w == 0) build_chunk_table();
-      lds_barrier();  // the multisplit has one barrier less than the rank build
     }
     STAMP(2);
     lds_barrier();
@@ -1368,7 +1378,6 @@ __global__ void __launch_bounds__(256) k_ll_csr_t(const FwdArgs A) {
   int* col_t = rowptr_t + A.max_n + 1;
   int* cursor = col_t + A.max_ell;    // [max_n+1]  (in-degree counts first)
   int* tmp = cursor + A.max_n + 1;
-  int* wsum = tmp + A.max_ell;
   const Grp ALL{(int)threadIdx.x, 256, (int)threadIdx.x >> 6, 4};
   for (int i = threadIdx.x; i <= n; i += 256) cursor[i] = 0;
   for (int e = threadIdx.x; e < ne; e += 256) {
@@ -1385,7 +1394,7 @@ __global__ void __launch_bounds__(256) k_ll_csr_t(const FwdArgs A) {
     A.dinv_out[(size_t)n0 + i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
   }
   lds_barrier();
-  build_csr_lds(ek, eo, ne, n, rowptr_t, col_t, cursor, tmp, wsum, ALL);
+  build_csr_lds(ek, eo, ne, n, rowptr_t, col_t, cursor, tmp, ALL, true);
   for (int i = threadIdx.x; i <= n; i += 256) A.csr_rowptr_t[(size_t)n0 + g + i] = rowptr_t[i];
   const int cnt_t = rowptr_t[n];
   for (int p = threadIdx.x; p < cnt_t; p += 256) A.csr_col_t[(size_t)e0 + p] = col_t[p];
