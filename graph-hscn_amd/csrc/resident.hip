@@ -410,7 +410,6 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   WStage<H, RT> ws;
   const bool resume = vonly && A.l_begin > 0;
   if (!resume) {
-  ws.fetch(A.layer[0], !vonly, cv, F);
   constexpr int EPT = 2;   // edges per thread held in registers (covers RT*EPT edges per relation)
   constexpr int XPT = 8;   // feature words per thread held in registers
   // raw 64-bit ids first (clamped addresses, no arithmetic on the results yet): all requests of the
@@ -434,6 +433,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     if (cv && eb < nel) { rvd[i] = pvd[o2 ? el0 + e : 0]; rvs[i] = pvs[o2 ? el0 + e : 0]; }
     if (cv && eb < nev) { rwd[i] = pwd[o3 ? ev0 + e : 0]; rws[i] = pws[o3 ? ev0 + e : 0]; }
   }
+  ws.fetch(A.layer[0], !vonly, cv, F);   // after the edges: they are consumed first
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int idx = threadIdx.x + i * RT;
@@ -525,43 +525,6 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     }
     if (bad && A.flag) atomicOr(A.flag, 2);
   }
-#pragma unroll
-  for (int i = 0; i < XPT; ++i) {
-    const int idx = threadIdx.x + i * RT;
-    if (idx < n * H) xa[idx] = xr[i];
-  }
-  for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) {
-    const int r = idx / H, k = idx - r * H;
-    xa[idx] = k < F ? A.x_local[(size_t)(n0 + r) * F + k] : 0.f;
-  }
-  if (cv) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = threadIdx.x + i * RT;
-      if (idx < nv * H) xva[idx] = xvr[i];
-    }
-    for (int idx = threadIdx.x + 2 * RT; idx < nv * H; idx += RT) {
-      const int r = idx / H, k = idx - r * H;
-      xva[idx] = k < F ? A.x_virtual[(size_t)(v0 + r) * F + k] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < HPT; ++i) {
-    const int idx = threadIdx.x + i * RT;
-    if (idx < H * H) headw[idx] = hw1r[i];
-  }
-  if (threadIdx.x < H) headw[H * H + threadIdx.x] = hb1;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = threadIdx.x + i * RT;
-    if (idx < A.C * H) headw[H * H + H + idx] = hw2r[i];
-  }
-  if (!vonly) {
-    for (int idx = threadIdx.x + 2 * RT; idx < A.C * H; idx += RT) headw[H * H + H + idx] = A.W2[idx];
-    for (int idx = threadIdx.x; idx < A.C; idx += RT)
-      headw[H * H + H + A.C * H + idx] = idx == (int)threadIdx.x ? hb2 : A.b2[idx];
-  }
-  ws.store(wt);
   // the CSR builds count in these (they hand them back zeroed)
   for (int i = threadIdx.x; i <= n; i += RT) {
     (ib + Y.cursorA)[i] = 0;
@@ -602,6 +565,45 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
                                wsum + 24, GS);
       if (GS.w == 0) build_chunk_table();
     }
+    // features and weights were requested with the edges but are not needed before layer 0: they are
+    // parked now, their latency spent under the CSR builds
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx < n * H) xa[idx] = xr[i];
+  }
+  for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) {
+    const int r = idx / H, k = idx - r * H;
+    xa[idx] = k < F ? A.x_local[(size_t)(n0 + r) * F + k] : 0.f;
+  }
+  if (cv) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      if (idx < nv * H) xva[idx] = xvr[i];
+    }
+    for (int idx = threadIdx.x + 2 * RT; idx < nv * H; idx += RT) {
+      const int r = idx / H, k = idx - r * H;
+      xva[idx] = k < F ? A.x_virtual[(size_t)(v0 + r) * F + k] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx < H * H) headw[idx] = hw1r[i];
+  }
+  if (threadIdx.x < H) headw[H * H + threadIdx.x] = hb1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    if (idx < A.C * H) headw[H * H + H + idx] = hw2r[i];
+  }
+  if (!vonly) {
+    for (int idx = threadIdx.x + 2 * RT; idx < A.C * H; idx += RT) headw[H * H + H + idx] = A.W2[idx];
+    for (int idx = threadIdx.x; idx < A.C; idx += RT)
+      headw[H * H + H + A.C * H + idx] = idx == (int)threadIdx.x ? hb2 : A.b2[idx];
+  }
+  ws.store(wt);
     STAMP(2);
     lds_barrier();
     // export the source-keyed CSR and the degree norm for the backward launch
