@@ -55,10 +55,16 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   ScnLayout Y;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
-  const size_t xa = (size_t)2 * max_n * FP, sk = (size_t)max_n * K;
-  Y.R1 = take(bwd ? xa + sk : (xa > sk ? xa : sk));   // backward keeps x, agg AND S
+  // (the partial tiles of gram_mfma, 16 waves x 256 words, reuse a buffer that is dead by then: y in the
+  // forward; in the backward S, then dlogits -- all kept at least that large)
+  // Backward: R1 = S, later x; R3 = dlogits, later agg.  x and agg wait in registers until the buffers
+  // they take over are dead, so a Peptides graph of 444 nodes fits (x, agg AND S resident did not).
+  constexpr size_t GSCR = 4096;
+  const int KF = K > FP ? K : FP;
+  const size_t xa = (size_t)2 * max_n * FP, sk0 = (size_t)max_n * (bwd ? KF : K), sk = (bwd && sk0 < GSCR) ? GSCR : sk0;
+  Y.R1 = take(bwd ? sk : (xa > sk ? xa : sk));
   const size_t st = (size_t)2 * (((size_t)max_e + 3) / 4 * 4);
-  const size_t yh = (size_t)max_n * H;
+  const size_t yh0 = (size_t)max_n * H, yh = (!bwd && yh0 < GSCR) ? GSCR : yh0;
   Y.R2 = take(yh > st ? yh : st);                      // y; the staged COO slice overlays it first
   Y.ek = Y.R2;
   Y.eo = Y.R2 + ((size_t)max_e + 3) / 4 * 4;
@@ -66,7 +72,7 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   Y.dinv = take(max_n);
   Y.dout = take(max_n);
   Y.wt = take((size_t)2 * H * FP + H + (size_t)K * H + K + (size_t)K * K);  // W_rel^T | W_root^T | b_rel | W_mlp^T | b_mlp | Gss
-  Y.red = take(64 + 4096);   // 64 words of wave partials, then 16 waves x one 16 x 16 partial tile (gram_mfma)
+  Y.red = take(1024);        // wave partials, column-sum scratch
   Y.vecs = take(64);
   Y.rowptr_d = take(max_n + 1);
   Y.col_d = take(max_e);
@@ -468,7 +474,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   // ss = S^T S through the tile outer product into LDS, then to global
   float* ssl = bml + K;  // [K][K] (the slot the backward uses for Gss)
   const int KK = K * K;
-  gram_mfma<NW>(Sl, K, K, Sl, K, K, n, red + 64, ssl, K, K);
+  gram_mfma<NW>(Sl, K, K, Sl, K, K, n, yl, ssl, K, K);   // (y is in HBM already: its LDS copy is the scratch)
   __syncthreads();
   STAMP(6);
   for (int idx = threadIdx.x; idx < KK; idx += SRT) A.ss[(size_t)g * KK + idx] = ssl[idx];
@@ -530,8 +536,8 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   const int lane = threadIdx.x & 63;
-  float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = agg + (size_t)A.max_n * FP;
-  float *yl = fb + Y.R2, *DL = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;
+  float *Sl = fb + Y.R1, *xs = fb + Y.R1;      // S, and x once S is dead
+  float *yl = fb + Y.R2, *DL = fb + Y.R3, *agg = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;   // dlogits, then agg
   float* WmT = fb + Y.wt + 2 * FP * H + H;   // [H][K] (same offsets as the forward's weight block)
   float* Gss = WmT + (size_t)H * K + K;      // [K][K]
   float* ssl = fb + Y.ssl;                   // [K][K] the forward's S^T S
@@ -540,11 +546,14 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   STAMP(0);
   // ---- front: everything comes from HBM in one batch of requests -- the CSRs, agg and the binary
   // out-degree the forward launch exported, x, S and y, W_mlp -- then is parked in LDS
+  constexpr int XPT = 8;
+  float agr[XPT], xr[XPT];   // agg and x wait in registers until the LDS buffers they take over are dead
+  const float* pag = A.ex_agg + (size_t)n0 * FP;
   {
     const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
-    constexpr int RPT = 2, EPT = 2, XPT = 8, MPT = (64 * H + SRT - 1) / SRT;
+    constexpr int RPT = 2, EPT = 2, MPT = (64 * H + SRT - 1) / SRT;
     int rdp[RPT], rsp[RPT], cdp[EPT], csp[EPT];
-    float dop[RPT], agr[XPT], xr[XPT], sr[XPT], yr[XPT], wm[MPT], ssr[4];
+    float dop[RPT], sr[XPT], yr[XPT], wm[MPT], ssr[4];
     const int32_t *prd = A.ex_rowptr_d + (size_t)n0 + g, *prs = A.ex_rowptr_s + (size_t)n0 + g;
     const int32_t *pcd = A.ex_col_d + (size_t)e0, *pcs = A.ex_col_s + (size_t)e0;
 #pragma unroll
@@ -566,7 +575,6 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
         csp[i] = pcs[e < ne ? e : 0];
       }
     }
-    const float* pag = A.ex_agg + (size_t)n0 * FP;
     const float* pS = A.S + (size_t)n0 * K;
     const float* py = A.y + (size_t)n0 * H;
 #pragma unroll
@@ -619,14 +627,8 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int idx = threadIdx.x + i * SRT;
-      if (idx < n * FP) { agg[idx] = agr[i]; xs[idx] = xr[i]; }
       if (idx < n * K) Sl[idx] = sr[i];
       if (idx < n * H) yl[idx] = yr[i];
-    }
-    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
-      const int i = idx / FP, k = idx - i * FP;
-      agg[idx] = pag[idx];
-      xs[idx] = k < A.F ? A.x[(size_t)(n0 + i) * A.F + k] : 0.f;
     }
     for (int idx = threadIdx.x + XPT * SRT; idx < n * K; idx += SRT) Sl[idx] = pS[idx];
     for (int idx = threadIdx.x + XPT * SRT; idx < n * H; idx += SRT) yl[idx] = py[idx];
@@ -701,7 +703,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   STAMP(4);
   // parameter-gradient partials.  layout: W_rel [H*F], b_rel [H], W_root [H*F], W_mlp [K*H], b_mlp [K]
   const int oWrel = 0, obrel = H * A.F, oWroot = obrel + H, oWmlp = oWroot + H * A.F, obmlp = oWmlp + K * H;
-  gram_mfma<NW>(DL, K, K, yl, H, H, n, red + 64, part + oWmlp, H, H);   // dW_mlp[k][h] = sum_i DL[i][k] y[i][h]
+  gram_mfma<NW>(DL, K, K, yl, H, H, n, Sl, part + oWmlp, H, H);   // dW_mlp[k][h] = sum_i DL[i][k] y[i][h]  (S is dead: scratch)
   col_sum<NW>(DL, K, K, n, part + obmlp, red);
   __syncthreads();
   STAMP(5);
@@ -734,8 +736,27 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   }
   __syncthreads();
   STAMP(6);
-  gram_mfma<NW>(yl, H, H, agg, FP, FP, n, red + 64, part + oWrel, A.F, A.F);    // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
-  gram_mfma<NW>(yl, H, H, xs, FP, FP, n, red + 64, part + oWroot, A.F, A.F);    // dW_root[o][k] = sum_i dz[i][o] x[i][k]
+  // dlogits are dead: agg takes their buffer (R3), S's buffer (R1) is the scratch of the first product
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * SRT;
+    if (idx < n * FP) agg[idx] = agr[i];
+  }
+  for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = pag[idx];
+  __syncthreads();
+  gram_mfma<NW>(yl, H, H, agg, FP, FP, n, Sl, part + oWrel, A.F, A.F);    // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
+  // x takes S's buffer, agg's is the scratch of the second product
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * SRT;
+    if (idx < n * FP) xs[idx] = xr[i];
+  }
+  for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
+    const int i = idx / FP, k = idx - i * FP;
+    xs[idx] = k < A.F ? A.x[(size_t)(n0 + i) * A.F + k] : 0.f;
+  }
+  __syncthreads();
+  gram_mfma<NW>(yl, H, H, xs, FP, FP, n, agg, part + oWroot, A.F, A.F);   // dW_root[o][k] = sum_i dz[i][o] x[i][k]
   col_sum<NW>(yl, H, H, n, part + obrel, red);
   STAMP(63);
 }

@@ -30,8 +30,8 @@ def test_single_graph_step_matches_oracle(K, H, act, name):
         om.zero_grad(); pm.zero_grad()
         S_o, mc_o, o_o, *_ = OM.scn_step_single_graph(om, g.x, g.edge_index)
         (mc_o + 0.5 * o_o).backward()
-        fits = name != "pascalvoc_sp"      # n ~ 480, e ~ 2700 exceeds the fused backward's LDS: layered operators
-        assert pm.resident_ok(g) == fits
+        fits = pm.resident_ok(g)           # (since the backward keeps x / agg in registers PascalVOC-SP sizes fit too)
+        assert fits or name == "pascalvoc_sp"
         S_d, mc_d, o_d = pm.forward_graphs(g)
         assert pm.last_engine == ("resident" if fits else "layered")
         (mc_d + 0.5 * o_d).backward()
