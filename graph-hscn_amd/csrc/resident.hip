@@ -84,6 +84,7 @@ struct BwdArgs {
   int32_t* flag;
   int64_t N;
   int F, L, C, head_act, max_n, max_ell, P;
+  int two;  // 1: two n x H buffers instead of three (one more barrier per layer; for graphs that need the LDS)
 };
 
 // ---- layer weights: global -> registers (prefetch) -> LDS (transposed Wt[k][o], rows k>=fin zero) ----
@@ -286,6 +287,15 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };  // keep 16-B alignment
   Y.xa = take((size_t)max_n * H);
+  // scratch of the CSR builds lives inside xa while it can: the features are parked there only after the
+  // builds (they wait in registers), so the counters / slot lists need no LDS of their own
+  size_t xq = Y.xa;
+  const size_t xend = Y.xa + (size_t)max_n * H;
+  auto scratch = [&](size_t n) {
+    const size_t need = (n + 3) & ~(size_t)3;
+    if (xq + need <= xend) { const size_t r = xq; xq += need; return r; }
+    return take(n);
+  };
   // transform outputs bh | bs; the staged COO slices (needed only before layer 0) overlay them
   const size_t stage = (size_t)2 * (((size_t)max_ell + 3) / 4 * 4 + ((size_t)max_n + 3) / 4 * 4 +
                                     ((size_t)max_evv + 3) / 4 * 4);
@@ -318,7 +328,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   Y.col_lv = take(max_n);
   Y.rowptr_vv = take(max_v + 1);
   Y.col_vv = take(max_evv);
-  Y.cursorA = take(max_n + 1);
+  Y.cursorA = scratch(max_n + 1);
   // softmax chunk partials (layers only) share the words of the ll build's scratch (structure only)
   const size_t maxck = (size_t)max_n / 64 + max_v + 1;   // sum over clusters of max(1, ceil(size / 64))
   const size_t gwords = max_v ? maxck * H : 0;
@@ -327,15 +337,15 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   const int nchunk = (max_n + 63) / 64;
   size_t cb = (size_t)max_v + 1;
   if ((size_t)max_v * nchunk > cb) cb = (size_t)max_v * nchunk;  // multisplit counters
-  Y.cursorB = take(cb);
-  Y.tmpB = take(max_n > max_evv ? max_n : max_evv);
+  Y.cursorB = scratch(cb);
+  Y.tmpB = scratch(max_n > max_evv ? max_n : max_evv);
   Y.wsum = take(32);
   Y.rowptr_t = take(exp ? max_n + 1 : 0);
   Y.col_t = take(exp ? max_ell : 0);
-  Y.cursorT = take(exp ? max_n + 1 : 0);
-  Y.tmpT = take(exp ? max_ell : 0);
-  Y.cursorV = take(max_v + 1);
-  Y.tmpV = take(max_evv);
+  Y.cursorT = scratch(exp ? max_n + 1 : 0);
+  Y.tmpT = scratch(exp ? max_ell : 0);
+  Y.cursorV = scratch(max_v + 1);
+  Y.tmpV = scratch(max_evv);
   Y.ck_tab = take(max_v ? maxck : 0);
   Y.ck_first = take(max_v ? max_v + 1 : 0);
   Y.ck_arrive = take(max_v);
@@ -995,13 +1005,13 @@ __global__ void __launch_bounds__(RT) k_hscn_fwd_pair(const FwdPair P) {
 struct BwdLayout {
   size_t G, GH, X, dinv, vec, red, bred, wl, headw, rowptr_t, col_t, total;
 };
-__host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max_ell) {
+__host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max_ell, int two) {
   BwdLayout Y;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
   Y.G = take((size_t)max_n * H);
   Y.GH = take((size_t)max_n * H);
-  Y.X = take((size_t)max_n * H);
+  Y.X = two ? Y.G : take((size_t)max_n * H);   // two-buffer mode: the layer input takes over the buffer of the dead gradient
   Y.dinv = take(max_n);
   Y.vec = take(256 + 64);
   Y.red = take((size_t)(RT_MAX / 64) * 256);  // weight gradient: one 16 x 16 partial tile per wave
@@ -1027,9 +1037,13 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     for (int i = threadIdx.x; i < A.P; i += RT) part[i] = 0.f;
     return;
   }
-  const BwdLayout Y = bwd_layout(H, A.C, A.max_n, A.max_ell);
+  const BwdLayout Y = bwd_layout(H, A.C, A.max_n, A.max_ell, A.two);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
+  // three buffers: G (gradient of a layer's output), GH (= A_hat^T G), X (the layer's input).  With two,
+  // X moves into G's buffer once the gather-reduce has consumed G (one more barrier), the input gradient
+  // overwrites GH in place (row tiles are independent) and the two buffers swap roles every layer.
+  const bool two = A.two != 0;
   float *G = fb + Y.G, *GH = fb + Y.GH, *X = fb + Y.X, *dinv = fb + Y.dinv, *vec = fb + Y.vec;
   float *red = fb + Y.red, *bred = fb + Y.bred, *wl = fb + Y.wl, *headw = fb + Y.headw;
   int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
@@ -1229,6 +1243,10 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     }
     // dL/d(transform output) = A_hat^T G  (transposed CSR, edge order)
     agg_gcn_lds<H>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, nullptr, ALL);
+    if (two) {          // every wave is done with G before the layer input lands in its buffer
+      lds_barrier();
+      X = G;
+    }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int idx = threadIdx.x + i * RT;
@@ -1291,7 +1309,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     // input gradient: G[j][k] = relu'(x_l[j][k]) * sum_o GH[j][o] * W[o][k]   (W is [H][H] here;
     // x_l = this layer's input = previous layer's output, already in X)
     if (l > 0 && H <= 32) {
-      lin_mfma<H, true>(GH, wl, G, n, X, ALL);
+      lin_mfma<H, true>(GH, wl, two ? GH : G, n, X, ALL);
     } else if (l > 0) {
       constexpr int LPR = H / OPT;
       constexpr int RS = RT / LPR;
@@ -1320,11 +1338,16 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
             }
           }
 #pragma unroll
-          for (int q = 0; q < OPT; ++q) G[j * H + k0 + q] = X[j * H + k0 + q] > 0.f ? acc[q] : 0.f;
+          for (int q = 0; q < OPT; ++q) (two ? GH : G)[j * H + k0 + q] = X[j * H + k0 + q] > 0.f ? acc[q] : 0.f;
         }
       }
     }
     STAMP(6 + 4 * l);
+    if (two) {   // the input gradient was written over GH: the buffers swap roles
+      float* t_ = G;
+      G = GH;
+      GH = t_;
+    }
   }
   if (GW1 && pend_oW >= 0) {   // layer 0's weight gradient
     lds_barrier();
@@ -1350,8 +1373,18 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd_virtual(const BwdArgs Ab, const
 inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int spec, int exp) {
   return fwd_layout(H, C, max_n, max_v, max_ell, max_evv, spec, exp).total * 4;
 }
-inline size_t bwd_lds_bytes(int H, int C, int max_n, int max_ell) {
-  return bwd_layout(H, C, max_n, max_ell).total * 4;
+inline size_t bwd_lds_bytes(int H, int C, int max_n, int max_ell, int two) {
+  return bwd_layout(H, C, max_n, max_ell, two).total * 4;
+}
+// three n x H buffers when they fit, else two (one more barrier per layer)
+inline size_t pick_bwd_lds(BwdArgs& A, int H) {
+  A.two = 0;
+  size_t lds = bwd_lds_bytes(H, A.C, A.max_n, A.max_ell, 0);
+  if (lds > 160 * 1024) {
+    A.two = 1;
+    lds = bwd_lds_bytes(H, A.C, A.max_n, A.max_ell, 1);
+  }
+  return lds;
 }
 
 // Workgroup size: 16 waves (4 per SIMD) hide the LDS / global latency of the many short
@@ -1443,8 +1476,8 @@ int launch_bwd_rt(const BwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
   return 0;
 }
 template <int H>
-int launch_bwd(const BwdArgs& A, int64_t B, hipStream_t st) {
-  const size_t lds = bwd_lds_bytes(H, A.C, A.max_n, A.max_ell);
+int launch_bwd(BwdArgs& A, int64_t B, hipStream_t st) {
+  const size_t lds = pick_bwd_lds(A, H);
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
   static const int rt_env = getenv("HSCN_RT") ? atoi(getenv("HSCN_RT")) : 0;
   if (A.max_n <= 64 || rt_env == 256) return launch_bwd_rt<H, 256>(A, B, lds, st);
@@ -1462,8 +1495,8 @@ int launch_bwd_virtual_rt(const BwdArgs& Ab, const FwdArgs& Af, int64_t B, size_
   return 0;
 }
 template <int H>
-int launch_bwd_virtual(const BwdArgs& Ab, FwdArgs& Af, int64_t B, hipStream_t st) {
-  const size_t lb = bwd_lds_bytes(H, Ab.C, Ab.max_n, Ab.max_ell);
+int launch_bwd_virtual(BwdArgs& Ab, FwdArgs& Af, int64_t B, hipStream_t st) {
+  const size_t lb = pick_bwd_lds(Ab, H);
   size_t lf = 0;
   bool ok = false;
   for (int spec = 1; spec >= 0 && !ok; --spec) {
@@ -1614,7 +1647,7 @@ int hscn_resident_supported(int F, int H, int L, int C, int max_n, int max_v, in
   if (!(H == 16 || H == 32 || H == 64) || F < 1 || F > H || L < 1 || L > MAXL || C < 1 || C > 4096) return 0;
   if (max_n < 0 || max_v < 0 || max_ell < 0 || max_evv < 0) return 0;
   if (fwd_lds_bytes(H, C, max_n, max_v, max_ell, max_evv, 0, 0) > 160 * 1024) return 0;
-  if (bwd_lds_bytes(H, C, max_n, max_ell) > 160 * 1024) return 0;
+  if (bwd_lds_bytes(H, C, max_n, max_ell, 1) > 160 * 1024) return 0;
   return 1;
 }
 

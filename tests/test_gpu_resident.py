@@ -283,3 +283,49 @@ def test_degenerate_graphs_in_a_batch():
         assert go.keys() == gd.keys()
         for n in go:
             assert close(gd[n], go[n], atol=1e-4, rtol=1e-3), n
+
+
+def test_wide_model_on_a_large_graph_takes_the_two_buffer_backward():
+    """H = 32 with a 440-node graph: the backward's three n x H buffers exceed a CU's LDS, the launch
+    switches to two buffers (layer input in the dead gradient's buffer, input gradient in place).
+    Prediction and gradients match the CPU oracle and the layered engine."""
+    from graph_hscn.data import Data, HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn import _hip
+    K, H, L, C, F = 16, 32, 3, 10, 9
+    g = torch.Generator().manual_seed(2)
+    n = 440
+    par = torch.cat([torch.zeros(1, dtype=torch.int64), (torch.rand(n - 1, generator=g) * torch.arange(1, n)).long()])
+    src = torch.arange(1, n)
+    extra_a = torch.randint(0, n, (20,), generator=g)
+    extra_b = (extra_a + 1 + torch.randint(0, n - 1, (20,), generator=g)) % n
+    u = torch.cat([src, extra_a]); v = torch.cat([par[1:], extra_b])
+    ei = torch.stack([torch.cat([u, v]), torch.cat([v, u])])
+    big = Data(x=torch.randint(0, 5, (n, F), generator=g).float(), edge_index=ei, y=torch.zeros(1, C), num_nodes=n)
+    graphs = make_dataset("peptides_func", 2, seed=5) + [big]
+    assert _hip.lib().hscn_resident_supported(F, H, L, C, n, K, ei.size(1), K * (K + 1) // 2) == 1
+    rng = np.random.default_rng(0)
+    ids = [rng.integers(0, K, gr.num_nodes) for gr in graphs]
+    ob = OH.collate_hetero([OH.hetero_from_clusters(gr.x, gr.edge_index, gr.y, i, K) for gr, i in zip(graphs, ids)])
+    pb = HeteroBatch.from_data_list([hetero_from_clusters(gr, i, K) for gr, i in zip(graphs, ids)]).to(DEV)
+    B = len(graphs)
+    om, pm = _models(F, H, C, L, "relu", seed=3)
+    out_o = om(ob["x_dict"], ob["edge_index_dict"], ob["batch_local"], B)
+    gsel = torch.randn(B, C, generator=torch.Generator().manual_seed(1))
+    (out_o * gsel).sum().backward()
+    go = {k: p.grad for k, p in om.named_parameters() if p.grad is not None}
+    res = {}
+    for eng in ("resident", "layered"):
+        pm.engine = eng
+        pm.zero_grad(set_to_none=True)
+        out_d = pm(pb.x_dict, pb.edge_index_dict, pb)
+        assert pm.last_engine == eng
+        (out_d * gsel.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        assert close(out_d, out_o, atol=ATOL, rtol=1e-5)
+        gd = {k: p.grad for k, p in pm.named_parameters() if p.grad is not None}
+        assert gd.keys() == go.keys()
+        for k in go:
+            assert close(gd[k], go[k], atol=2e-4, rtol=1e-3), (eng, k)
+    pb._resident_meta.check()
