@@ -99,6 +99,16 @@ class _VirtualJob(ctypes.Structure):
 last_deferred_virtual: Optional[Tensor] = None
 
 
+_CUS: Dict[int, int] = {}
+
+
+def _cu_count(dev: torch.device) -> int:
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _CUS:
+        _CUS[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return _CUS[idx]
+
+
 class HSCNResidentFn(Function):
     """inputs: x_local, x_virtual, ei_ll, ei_vv, ei_lv, meta, cfg, then parameters in
     the order  [W_ll, b_ll, W_vv, b_vv, W_src, W_dst, att_src, att_dst, b_gat] x L,
@@ -127,7 +137,9 @@ class HSCNResidentFn(Function):
         B = meta.num_graphs
         dev = x_local.device
         need_bwd = any(ctx.needs_input_grad[7:])   # False under no_grad
-        defer = bool(compute_virtual and overlap and V > 0 and need_bwd and not keep_virtual and L >= 2)
+        # (the extra workgroups pay only while they land on CUs the batch leaves idle: 2B <= number of CUs)
+        defer = bool(compute_virtual and overlap and V > 0 and need_bwd and not keep_virtual and L >= 2
+                     and 2 * B <= _cu_count(dev))
         acts = torch.empty(L, N, H, dtype=torch.float32, device=dev)
         pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
         z = torch.empty(B, H, dtype=torch.float32, device=dev)
