@@ -27,13 +27,20 @@ constexpr int GK = 32;   // reduction depth per LDS stage
 constexpr int GNMAX = 64;
 
 // C[b] (M x N) = op(A[b]) (M x Kd) * B[b] (Kd x N);  op = transpose when TA (A stored Kd x M)
-template <int TA>
+// Two LDS stages: the next k-slab travels HBM -> registers while the matrix cores work on the current
+// one and is parked in the other stage afterwards -- one barrier per slab, loads hidden under MFMA.
+// NT (N tiles of 16) is a template parameter: the slab loop is branch-free, the operand reads of a slab
+// are issued together and the MFMAs follow back to back.
+template <int TA, int NT>
 __global__ void __launch_bounds__(256)
 k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, int M, int N, int Kd,
-        int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int NT /* N tiles of 16 */) {
-  constexpr int AST = GK + 4;                        // padded row stride of the [m][k] image (bank spread, 16-B aligned)
-  __shared__ __align__(16) float As[GM * AST];     // TA=0: [m][k];  TA=1: [k][m] (stride GM)
-  __shared__ __align__(16) float Bs[GK * GNMAX];   // [k][n]
+        int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC) {
+  constexpr int AST = GK + 4;                           // padded row stride of the [m][k] image (bank spread, 16-B aligned)
+  constexpr int ASZ = TA ? GK * GM : GM * AST;
+  __shared__ __align__(16) float As[2][ASZ];          // TA=0: [m][k];  TA=1: [k][m] (stride GM)
+  // [k][n], rows padded by 16 words: the four k-rows a wave reads together (lane>>4) fall on disjoint banks
+  constexpr int BST = GNMAX + 16;
+  __shared__ __align__(16) float Bs[2][GK * BST];
   const int b = blockIdx.y;
   const int m0 = blockIdx.x * GM;
   A += (size_t)b * sA;
@@ -41,91 +48,105 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
   C += (size_t)b * sC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  f32x4 acc[GNMAX / 16];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < GNMAX / 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int NP = NT * 16;
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NP = NT * 16;
+  constexpr int APT = GM * GK / 4 / 256;   // float4 pieces of the A slab per thread (2)
+  constexpr int BPT = GK * GNMAX / 4 / 256;  // of the B slab, at most (2)
+  float4 ra[APT], rb[BPT];
 
+  auto ld_guard = [](const float* p, int c, int lim) {   // p[0..3] with columns c..c+3 < lim, else 0
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < lim) v = ld4u(p);
+    else {
+      if (c < lim) v.x = p[0];
+      if (c + 1 < lim) v.y = p[1];
+      if (c + 2 < lim) v.z = p[2];
+      if (c + 3 < lim) v.w = p[3];
+    }
+    return v;
+  };
+  // a thread's pieces of a slab sit at the same (row, column) of every slab: the index arithmetic
+  // (divisions by the runtime tile width) is done once, the slab loop only adds k0
+  int a_r[APT], a_c[APT], b_r[BPT], b_c[BPT], a_lds[APT], b_lds[BPT];
+  bool b_on[BPT];
+#pragma unroll
+  for (int u = 0; u < APT; ++u) {
+    const int idx = threadIdx.x + u * 256;
+    if (TA == 0) { a_r[u] = idx / (GK / 4); a_c[u] = (idx % (GK / 4)) * 4; a_lds[u] = a_r[u] * AST + a_c[u]; }
+    else { a_r[u] = idx / (GM / 4); a_c[u] = (idx % (GM / 4)) * 4; a_lds[u] = a_r[u] * GM + a_c[u]; }
+  }
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const int idx = threadIdx.x + u * 256;
+    b_on[u] = idx < GK * NP / 4;
+    b_r[u] = idx / (NP / 4);
+    b_c[u] = (idx % (NP / 4)) * 4;
+    b_lds[u] = b_r[u] * BST + b_c[u];
+  }
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (TA == 0) {   // A tile rows m0.., cols k0..k0+31
+        const int gr = m0 + a_r[u], gc = k0 + a_c[u];
+        if (gr < M) ra[u] = ld_guard(A + (size_t)gr * lda + gc, gc, Kd);
+      } else {         // A stored [Kd][M]: tile rows k0.., cols m0..m0+63
+        const int gr = k0 + a_r[u], gc = m0 + a_c[u];
+        if (gr < Kd) ra[u] = ld_guard(A + (size_t)gr * lda + gc, gc, M);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) {
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gr = k0 + b_r[u];
+      if (b_on[u] && gr < Kd) rb[u] = ld_guard(Bm + (size_t)gr * ldb + b_c[u], b_c[u], N);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < APT; ++u) *reinterpret_cast<float4*>(&As[buf][a_lds[u]]) = ra[u];
+#pragma unroll
+    for (int u = 0; u < BPT; ++u)
+      if (b_on[u]) *reinterpret_cast<float4*>(&Bs[buf][b_lds[u]]) = rb[u];
+  };
+
+  fetch(0);
+  park(0);
+  __syncthreads();
+  int buf = 0;
   for (int k0 = 0; k0 < Kd; k0 += GK) {
-    __syncthreads();
-    if (TA == 0) {
-      // A tile rows m0..m0+63, cols k0..k0+31: 64 x 32 floats = 512 float4, two per thread
-      for (int idx = threadIdx.x; idx < GM * GK / 4; idx += 256) {
-        const int r = idx / (GK / 4), c4 = (idx % (GK / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int gr = m0 + r, gc = k0 + c4;
-        if (gr < M) {
-          const float* p = A + (size_t)gr * lda + gc;
-          if (gc + 3 < Kd) v = ld4u(p);
-          else {
-            if (gc < Kd) v.x = p[0];
-            if (gc + 1 < Kd) v.y = p[1];
-            if (gc + 2 < Kd) v.z = p[2];
-            if (gc + 3 < Kd) v.w = p[3];
-          }
-        }
-        *reinterpret_cast<float4*>(&As[r * AST + c4]) = v;
-      }
-    } else {
-      // A stored [Kd][M]: tile rows k0..k0+31, cols m0..m0+63 -> LDS [k][m]
-      for (int idx = threadIdx.x; idx < GK * GM / 4; idx += 256) {
-        const int r = idx / (GM / 4), c4 = (idx % (GM / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int gr = k0 + r, gc = m0 + c4;
-        if (gr < Kd) {
-          const float* p = A + (size_t)gr * lda + gc;
-          if (gc + 3 < M) v = ld4u(p);
-          else {
-            if (gc < M) v.x = p[0];
-            if (gc + 1 < M) v.y = p[1];
-            if (gc + 2 < M) v.z = p[2];
-            if (gc + 3 < M) v.w = p[3];
-          }
-        }
-        *reinterpret_cast<float4*>(&As[r * GM + c4]) = v;
-      }
-    }
-    // B tile rows k0..k0+31, cols 0..NP-1
-    for (int idx = threadIdx.x; idx < GK * NP / 4; idx += 256) {
-      const int r = idx / (NP / 4), c4 = (idx % (NP / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int gr = k0 + r;
-      if (gr < Kd) {
-        const float* p = Bm + (size_t)gr * ldb + c4;
-        if (c4 + 3 < N) v = ld4u(p);
-        else {
-          if (c4 < N) v.x = p[0];
-          if (c4 + 1 < N) v.y = p[1];
-          if (c4 + 2 < N) v.z = p[2];
-          if (c4 + 3 < N) v.w = p[3];
-        }
-      }
-      *reinterpret_cast<float4*>(&Bs[r * GNMAX + c4]) = v;
-    }
-    __syncthreads();
+    const bool more = k0 + GK < Kd;
+    if (more) fetch(k0 + GK);
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
+    // operands of the whole slab first (A: lane holds A[i = lane&15][k = lane>>4]; B[k = lane>>4][j = lane&15]),
+    // then GK/4 x NT MFMAs
+    float av[GK / 4], bv[GK / 4][NT];
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 4) {
-      // A operand: lane holds A[i = lane&15][k = lane>>4]
-      const float a = TA ? As[(kk + lk) * GM + wave * 16 + li] : As[(wave * 16 + li) * AST + kk + lk];
+    for (int q = 0; q < GK / 4; ++q) {
+      const int kk = q * 4;
+      av[q] = TA ? as[(kk + lk) * GM + wave * 16 + li] : as[(wave * 16 + li) * AST + kk + lk];
 #pragma unroll
-      for (int t = 0; t < GNMAX / 16; ++t) {
-        if (t < NT) {
-          const float bv = Bs[(kk + lk) * GNMAX + t * 16 + li];  // B[k = lane>>4][j = lane&15]
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
-        }
-      }
+      for (int t = 0; t < NT; ++t) bv[q][t] = bs[(kk + lk) * BST + t * 16 + li];
     }
+#pragma unroll
+    for (int q = 0; q < GK / 4; ++q)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q][t], acc[t], 0, 0, 0);
+    if (more) park(buf ^ 1);   // the other stage: nobody reads it during this slab
+    __syncthreads();
+    buf ^= 1;
   }
   // C/D layout: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
-  for (int t = 0; t < GNMAX / 16; ++t) {
-    if (t < NT) {
-      const int col = t * 16 + li;
+  for (int t = 0; t < NT; ++t) {
+    const int col = t * 16 + li;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wave * 16 + lk * 4 + r;
-        if (row < M && col < N) C[(size_t)row * ldc + col] = acc[t][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wave * 16 + lk * 4 + r;
+      if (row < M && col < N) C[(size_t)row * ldc + col] = acc[t][r];
     }
   }
 }
@@ -297,10 +318,23 @@ int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N
   if (N < 1 || N > GNMAX) return HSCN_E_UNSUPPORTED;
   const int NT = (N + 15) / 16;
   dim3 grid((M + GM - 1) / GM, (unsigned)batch);
-  if (transA)
-    k_bgemm<1><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, NT);
-  else
-    k_bgemm<0><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, NT);
+#define HSCN_BGEMM(TA_, NT_) k_bgemm<TA_, NT_><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC)
+  if (transA) {
+    switch (NT) {
+      case 1: HSCN_BGEMM(1, 1); break;
+      case 2: HSCN_BGEMM(1, 2); break;
+      case 3: HSCN_BGEMM(1, 3); break;
+      default: HSCN_BGEMM(1, 4); break;
+    }
+  } else {
+    switch (NT) {
+      case 1: HSCN_BGEMM(0, 1); break;
+      case 2: HSCN_BGEMM(0, 2); break;
+      case 3: HSCN_BGEMM(0, 3); break;
+      default: HSCN_BGEMM(0, 4); break;
+    }
+  }
+#undef HSCN_BGEMM
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
