@@ -31,10 +31,13 @@ constexpr int GNMAX = 64;
 // one and is parked in the other stage afterwards -- one barrier per slab, loads hidden under MFMA.
 // NT (N tiles of 16) is a template parameter: the slab loop is branch-free, the operand reads of a slab
 // are issued together and the MFMAs follow back to back.
-template <int TA, int NT>
+// RS (TA = 0 only): also write the row sums of A (the degrees, adj . 1) to rsum [batch][M]: the tile is in
+// LDS anyway -- four threads add a row's 32 slab entries, quads fold by DPP -- which saves a pass over the
+// adjacency (the largest array of the dense route) and a launch.
+template <int TA, int NT, int RS>
 __global__ void __launch_bounds__(256)
 k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, int M, int N, int Kd,
-        int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC) {
+        int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC, float* __restrict__ rsum) {
   constexpr int AST = GK + 4;                           // padded row stride of the [m][k] image (bank spread, 16-B aligned)
   constexpr int ASZ = TA ? GK * GM : GM * AST;
   __shared__ __align__(16) float As[2][ASZ];          // TA=0: [m][k];  TA=1: [k][m] (stride GM)
@@ -116,6 +119,7 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
   park(0);
   __syncthreads();
   int buf = 0;
+  float rs = 0.f;   // RS: running sum of row (threadIdx.x / 4) of the A tile
   for (int k0 = 0; k0 < Kd; k0 += GK) {
     const bool more = k0 + GK < Kd;
     if (more) fetch(k0 + GK);
@@ -131,6 +135,14 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[q][t] = bs[(kk + lk) * BST + t * 16 + li];
     }
+    if (RS && TA == 0) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&as[(threadIdx.x >> 2) * AST + (threadIdx.x & 3) * 8]);
+      const float4 p1 = *reinterpret_cast<const float4*>(&as[(threadIdx.x >> 2) * AST + (threadIdx.x & 3) * 8 + 4]);
+      float q8 = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w));
+      q8 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q8), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+      q8 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q8), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+      rs += q8;
+    }
 #pragma unroll
     for (int q = 0; q < GK / 4; ++q)
 #pragma unroll
@@ -138,6 +150,10 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
     if (more) park(buf ^ 1);   // the other stage: nobody reads it during this slab
     __syncthreads();
     buf ^= 1;
+  }
+  if (RS && TA == 0 && (threadIdx.x & 3) == 0) {
+    const int row = m0 + (threadIdx.x >> 2);
+    if (row < M) rsum[(size_t)b * M + row] = rs;
   }
   // C/D layout: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -151,15 +167,20 @@ k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __rest
   }
 }
 
-__global__ void k_softmax_rows_d(const float* __restrict__ logits, float* __restrict__ S, int64_t n, int K) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* r = logits + i * K;
-  float m = r[0];
-  for (int k = 1; k < K; ++k) m = fmaxf(m, r[k]);
-  float sum = 0.f;
-  for (int k = 0; k < K; ++k) sum += expf(r[k] - m);
-  for (int k = 0; k < K; ++k) S[i * K + k] = expf(r[k] - m) / sum;
+// row softmax, KP = pow2 >= K lanes per row (K <= 64): consecutive lanes on consecutive addresses
+__global__ void __launch_bounds__(256)
+k_softmax_rows_d(const float* __restrict__ logits, float* __restrict__ S, int64_t n, int K, int KP) {
+  const int k = threadIdx.x % KP;
+  const int64_t rpb = 256 / KP;
+  for (int64_t i = (int64_t)blockIdx.x * rpb + threadIdx.x / KP; i < n; i += (int64_t)gridDim.x * rpb) {
+    const float v = k < K ? logits[i * K + k] : -INFINITY;
+    float m = v;
+    for (int off = KP >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const float ex = k < K ? expf(v - m) : 0.f;
+    float sum = ex;
+    for (int off = KP >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (k < K) S[i * K + k] = ex / sum;
+  }
 }
 
 // deg[b][i] = sum_k adj[b][i][k]   (wave per row, ordered fold)
@@ -188,17 +209,24 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
   const float* ssg = ss + (size_t)g * KK;
   float* oag = oa + (size_t)g * KK;
   const int lane = threadIdx.x & 63;
+  // den = sum_i deg_i |S_i|^2 = sum over all elements of deg[row] * S^2: every thread takes a strided,
+  // coalesced share, the four waves fold in order
+  {
+    float part = 0.f;
+    const int tot = n * K;
+    for (int idx = threadIdx.x; idx < tot; idx += 256) {
+      const float v = Sg[idx];
+      part = fmaf(dg[idx / K], v * v, part);
+    }
+    part = wave_sum(part);
+    if (lane == 0) red[threadIdx.x >> 6] = part;
+  }
+  __syncthreads();
   if (threadIdx.x < 64) {
     float num = 0.f;
     for (int a = lane; a < K; a += 64) num += oag[a * K + a];
     num = wave_sum(num);
-    float den = 0.f;
-    for (int i = lane; i < n; i += 64) {
-      float q = 0.f;
-      for (int k = 0; k < K; ++k) q = fmaf(Sg[(size_t)i * K + k], Sg[(size_t)i * K + k], q);
-      den = fmaf(dg[i], q, den);
-    }
-    den = wave_sum(den);
+    const float den = ((red[0] + red[1]) + red[2]) + red[3];
     float n2 = 0.f;
     for (int i = lane; i < KK; i += 64) n2 += ssg[i] * ssg[i];
     n2 = wave_sum(n2);
@@ -229,7 +257,6 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
     const int a = idx / K, b = idx - a * K;
     oag[idx] = (a == b) ? 0.f : (oag[idx] / dn[b]) / dn[a];
   }
-  (void)red;
 }
 
 __global__ void k_losses_d(const float* __restrict__ stats, float* __restrict__ losses, int G) {
@@ -314,11 +341,23 @@ k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const flo
 }
 
 int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N, int Kd, int64_t lda, int64_t ldb,
-          int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int transA, hipStream_t st) {
+          int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int transA, hipStream_t st, float* rsum = nullptr) {
   if (N < 1 || N > GNMAX) return HSCN_E_UNSUPPORTED;
   const int NT = (N + 15) / 16;
   dim3 grid((M + GM - 1) / GM, (unsigned)batch);
-#define HSCN_BGEMM(TA_, NT_) k_bgemm<TA_, NT_><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC)
+  if (rsum && !transA) {   // A . B and the row sums of A in one pass
+#define HSCN_BGEMM_RS(NT_) k_bgemm<0, NT_, 1><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, rsum)
+    switch (NT) {
+      case 1: HSCN_BGEMM_RS(1); break;
+      case 2: HSCN_BGEMM_RS(2); break;
+      case 3: HSCN_BGEMM_RS(3); break;
+      default: HSCN_BGEMM_RS(4); break;
+    }
+#undef HSCN_BGEMM_RS
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
+#define HSCN_BGEMM(TA_, NT_) k_bgemm<TA_, NT_, 0><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, nullptr)
   if (transA) {
     switch (NT) {
       case 1: HSCN_BGEMM(1, 1); break;
@@ -359,12 +398,17 @@ int hscn_mincut_dense_fwd(const float* x, const float* adj, const float* logits,
   if (!adj || !logits || !S || !AS || !deg || !stats || !ss || !pooled_adj || !losses) return HSCN_E_BADARG;
   hipStream_t st = hscn_stream(stream_);
   const int64_t rows = B * n;
-  k_softmax_rows_d<<<hscn_blocks(rows, 256), 256, 0, st>>>(logits, S, rows, K);
-  k_rowsum<<<hscn_blocks(rows, 4), 256, 0, st>>>(adj, deg, rows, n);
+  {
+    int KP = 1;
+    while (KP < K) KP <<= 1;
+    unsigned nb = hscn_blocks(rows, 256 / KP);
+    if (nb > 16384) nb = 16384;
+    k_softmax_rows_d<<<nb, 256, 0, st>>>(logits, S, rows, K, KP);
+  }
   HSCN_RETURN_IF_LAUNCH_FAILED();
   int rc;
-  // A S
-  if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st))) return rc;
+  // A S, and deg = A . 1 from the same pass over the adjacency (0/1 entries: the sums are exact in any order)
+  if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st, deg))) return rc;
   // S^T (A S)  -> pooled_adj (raw), S^T S -> ss, S^T X -> pooled_x
   if ((rc = bgemm(S, AS, pooled_adj, B, K, K, n, K, K, K, (int64_t)n * K, (int64_t)n * K, (int64_t)K * K, 1, st))) return rc;
   if ((rc = bgemm(S, S, ss, B, K, K, n, K, K, K, (int64_t)n * K, (int64_t)n * K, (int64_t)K * K, 1, st))) return rc;

@@ -306,14 +306,14 @@ class MinCutSparseFn(Function):
         ctx.mark_non_differentiable(S, padj)
         if px is not None:
             ctx.mark_non_differentiable(px)
-        return S, losses, px, padj
+        return S, losses[0], losses[1], px, padj
 
     @staticmethod
-    def backward(ctx, gS, g_losses, g_px, g_padj):
+    def backward(ctx, gS, g_mc, g_o, g_px, g_padj):
         S, stats, ss, node_ptr = ctx.saved_tensors
         rel: Relation = ctx.rel
         dev = S.device
-        gl = _c(g_losses) if g_losses is not None else torch.zeros(2, dtype=torch.float32, device=dev)
+        gl = _pack_loss_grads(g_mc, g_o, dev)
         g_logits = torch.empty_like(S)
         row_csr, col_csr = rel.csr_t, rel.csr
         call("hscn_mincut_sparse_bwd", ptr(S), ptr(stats), ptr(ss), ptr(row_csr.rowptr), ptr(row_csr.col),
@@ -322,11 +322,22 @@ class MinCutSparseFn(Function):
         return g_logits, None, None, None, None
 
 
+def _pack_loss_grads(g_mc: Optional[Tensor], g_o: Optional[Tensor], dev) -> Tensor:
+    """[dL/dmincut, dL/dortho] as one device pair: the two losses are separate autograd outputs (slicing
+    one [2] output costs six fill / copy / add launches in the backward), packing their scalar gradients is one."""
+    if g_mc is None and g_o is None:
+        return torch.zeros(2, dtype=torch.float32, device=dev)
+    z = None
+    if g_mc is None or g_o is None:
+        z = torch.zeros((), dtype=torch.float32, device=dev)
+    return torch.stack([(g_mc if g_mc is not None else z).reshape(()), (g_o if g_o is not None else z).reshape(())])
+
+
 # --------------------------------------------------------------------------- #
 # MinCUT pooling, dense route (matrix cores)
 # --------------------------------------------------------------------------- #
 class MinCutDenseFn(Function):
-    """(logits [B,n,K], x [B,n,F] | None, adj [B,n,n]) -> (S, losses[2], pooled_x, pooled_adj).
+    """(logits [B,n,K], x [B,n,F] | None, adj [B,n,n]) -> (S, mincut, ortho, pooled_x, pooled_adj).
     Gradients flow from the two losses to ``logits``."""
 
     @staticmethod
@@ -350,13 +361,13 @@ class MinCutDenseFn(Function):
         ctx.mark_non_differentiable(S, padj)
         if px is not None:
             ctx.mark_non_differentiable(px)
-        return S, losses, px, padj
+        return S, losses[0], losses[1], px, padj
 
     @staticmethod
-    def backward(ctx, gS, g_losses, g_px, g_padj):
+    def backward(ctx, gS, g_mc, g_o, g_px, g_padj):
         adj, S, AS, deg, stats, ss = ctx.saved_tensors
         B, n, K = S.shape
-        gl = _c(g_losses) if g_losses is not None else torch.zeros(2, dtype=torch.float32, device=S.device)
+        gl = _pack_loss_grads(g_mc, g_o, S.device)
         AtS = torch.empty_like(S)
         SG = torch.empty_like(S)
         Gss = torch.empty_like(ss)

@@ -81,8 +81,8 @@ def mincut_pool_sparse(x: Optional[Tensor], edge_index: Union[Tensor, Relation],
     if node_ptr is None:
         node_ptr = torch.tensor([0, n], dtype=torch.int32, device=s.device)
     G = int(node_ptr.numel()) - 1
-    S, losses, px, padj = Fh.MinCutSparseFn.apply(s, x, rel, node_ptr.to(torch.int32).contiguous(), G)
-    return S, px, padj, losses[0], losses[1]
+    S, mc, o, px, padj = Fh.MinCutSparseFn.apply(s, x, rel, node_ptr.to(torch.int32).contiguous(), G)
+    return S, px, padj, mc, o
 
 
 def dense_mincut_pool(x: Tensor, adj: Tensor, s: Tensor, mask: Optional[Tensor] = None):
@@ -96,5 +96,5 @@ def dense_mincut_pool(x: Tensor, adj: Tensor, s: Tensor, mask: Optional[Tensor] 
     x = x.unsqueeze(0) if x.dim() == 2 else x
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
     s = s.unsqueeze(0) if s.dim() == 2 else s
-    S, losses, px, padj = Fh.MinCutDenseFn.apply(s, x, adj)
-    return px, padj, losses[0], losses[1]
+    S, mc, o, px, padj = Fh.MinCutDenseFn.apply(s, x, adj)
+    return px, padj, mc, o
