@@ -34,10 +34,26 @@ constexpr int GNMAX = 64;
 // RS (TA = 0 only): also write the row sums of A (the degrees, adj . 1) to rsum [batch][M]: the tile is in
 // LDS anyway -- four threads add a row's 32 slab entries, quads fold by DPP -- which saves a pass over the
 // adjacency (the largest array of the dense route) and a launch.
+// Up to three products that share op(A) run as one launch (blockIdx.z picks the right-hand side): the
+// cluster-space contractions S^T (A S), S^T S, S^T X are 128-workgroup launches each -- together they fill
+// the chip.
+struct BRhs {
+  const float* B;
+  float* C;
+  int N;
+  int64_t ldb, ldc, sB, sC;
+};
+struct BRhs3 {
+  BRhs r[3];
+};
 template <int TA, int NT, int RS>
 __global__ void __launch_bounds__(256)
-k_bgemm(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, int M, int N, int Kd,
-        int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC, float* __restrict__ rsum) {
+k_bgemm(const float* __restrict__ A, const BRhs3 R, int M, int Kd, int64_t lda, int64_t sA,
+        float* __restrict__ rsum) {
+  const float* __restrict__ Bm = R.r[blockIdx.z].B;
+  float* __restrict__ C = R.r[blockIdx.z].C;
+  const int N = R.r[blockIdx.z].N;
+  const int64_t ldb = R.r[blockIdx.z].ldb, ldc = R.r[blockIdx.z].ldc, sB = R.r[blockIdx.z].sB, sC = R.r[blockIdx.z].sC;
   constexpr int AST = GK + 4;                           // padded row stride of the [m][k] image (bank spread, 16-B aligned)
   constexpr int ASZ = TA ? GK * GM : GM * AST;
   __shared__ __align__(16) float As[2][ASZ];          // TA=0: [m][k];  TA=1: [k][m] (stride GM)
@@ -195,67 +211,80 @@ __global__ void k_rowsum(const float* __restrict__ adj, float* __restrict__ deg,
   if (lane == 0) deg[row] = s;
 }
 
-// per graph: num = tr(oa), den = sum_i deg_i |S_i|^2, |ss|_F, ortho; normalise oa in place
+// sum over the 256 threads of a workgroup, waves folded in order (red: 4 floats of LDS); every thread
+// receives the total.  Two barriers.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();   // red may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// per graph: num = tr(oa), den = sum_i deg_i |S_i|^2, |ss|_F, ortho; normalise oa in place.
+// One workgroup per graph, all 256 threads in every reduction; oa and ss are staged in LDS with rows
+// padded by one word (the row sums walk a row per thread).
 __global__ void __launch_bounds__(256)
 k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, const float* __restrict__ ss,
                  float* __restrict__ oa, float* __restrict__ stats, int n, int K) {
   extern __shared__ float lds[];
-  float* dn = lds;          // [K]
-  float* red = lds + K;     // [4]
+  const int KS = K + 1, KK = K * K;
+  float* oal = lds;                  // [K][KS]
+  float* ssl = oal + K * KS;         // [K][KS]
+  float* dn = ssl + K * KS;          // [K]
+  float* red = dn + K;               // [4]
   const int g = blockIdx.x;
-  const int KK = K * K;
   const float* Sg = S + (size_t)g * n * K;
   const float* dg = deg + (size_t)g * n;
   const float* ssg = ss + (size_t)g * KK;
   float* oag = oa + (size_t)g * KK;
-  const int lane = threadIdx.x & 63;
-  // den = sum_i deg_i |S_i|^2 = sum over all elements of deg[row] * S^2: every thread takes a strided,
-  // coalesced share, the four waves fold in order
+  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+    const int a = idx / K, b = idx - a * K;
+    oal[a * KS + b] = oag[idx];
+    ssl[a * KS + b] = ssg[idx];
+  }
+  // den = sum_i deg_i |S_i|^2 = sum over all elements of deg[row] * S^2 (strided, coalesced)
+  float part = 0.f;
   {
-    float part = 0.f;
     const int tot = n * K;
     for (int idx = threadIdx.x; idx < tot; idx += 256) {
       const float v = Sg[idx];
       part = fmaf(dg[idx / K], v * v, part);
     }
-    part = wave_sum(part);
-    if (lane == 0) red[threadIdx.x >> 6] = part;
   }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    float num = 0.f;
-    for (int a = lane; a < K; a += 64) num += oag[a * K + a];
-    num = wave_sum(num);
-    const float den = ((red[0] + red[1]) + red[2]) + red[3];
-    float n2 = 0.f;
-    for (int i = lane; i < KK; i += 64) n2 += ssg[i] * ssg[i];
-    n2 = wave_sum(n2);
-    const float nrm = sqrtf(n2);
-    const float isk = 1.0f / sqrtf((float)K);
-    float o2 = 0.f;
-    for (int i = lane; i < KK; i += 64) {
-      const int a = i / K, b = i - a * K;
-      const float q = ssg[i] / nrm - (a == b ? isk : 0.f);
-      o2 += q * q;
-    }
-    o2 = wave_sum(o2);
-    if (lane == 0) {
-      stats[g * 4 + 0] = num;
-      stats[g * 4 + 1] = den;
-      stats[g * 4 + 2] = nrm;
-      stats[g * 4 + 3] = sqrtf(o2);
-    }
+  const float den = block_sum_256(part, red);   // (its barriers also publish oal / ssl)
+  float t = 0.f;
+  for (int a = threadIdx.x; a < K; a += 256) t += oal[a * KS + a];
+  const float num = block_sum_256(t, red);
+  t = 0.f;
+  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+    const float v = ssl[(idx / K) * KS + idx % K];
+    t = fmaf(v, v, t);
   }
-  __syncthreads();
+  const float nrm = sqrtf(block_sum_256(t, red));
+  const float isk = 1.0f / sqrtf((float)K);
+  t = 0.f;
+  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+    const int a = idx / K, b = idx - a * K;
+    const float q = ssl[a * KS + b] / nrm - (a == b ? isk : 0.f);
+    t = fmaf(q, q, t);
+  }
+  const float o2 = block_sum_256(t, red);
+  if (threadIdx.x == 0) {
+    stats[g * 4 + 0] = num;
+    stats[g * 4 + 1] = den;
+    stats[g * 4 + 2] = nrm;
+    stats[g * 4 + 3] = sqrtf(o2);
+  }
   for (int a = threadIdx.x; a < K; a += 256) {
-    float s = 0.f;
-    for (int b = 0; b < K; ++b) s += (a == b) ? 0.f : oag[a * K + b];
-    dn[a] = sqrtf(s) + 1e-15f;
+    float s_ = 0.f;
+    for (int b = 0; b < K; ++b) s_ += (a == b) ? 0.f : oal[a * KS + b];
+    dn[a] = sqrtf(s_) + 1e-15f;
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < KK; idx += 256) {
     const int a = idx / K, b = idx - a * K;
-    oag[idx] = (a == b) ? 0.f : (oag[idx] / dn[b]) / dn[a];
+    oag[idx] = (a == b) ? 0.f : (oal[a * KS + b] / dn[b]) / dn[a];
   }
 }
 
@@ -277,29 +306,41 @@ __global__ void k_losses_d(const float* __restrict__ stats, float* __restrict__ 
 __global__ void __launch_bounds__(256)
 k_dense_gss(const float* __restrict__ stats, const float* __restrict__ ss, const float* __restrict__ g_losses,
             float* __restrict__ Gss, int K, int G) {
-  __shared__ float red[1];
+  __shared__ float red[4];
   const int g = blockIdx.x;
   const int KK = K * K;
   const float nrm = stats[g * 4 + 2], o = stats[g * 4 + 3];
   const float go2 = 2.f * g_losses[1] / (float)G;
   const float isk = 1.0f / sqrtf((float)K);
   const float* ssg = ss + (size_t)g * KK;
-  if (threadIdx.x < 64) {
-    float v = 0.f;
-    if (o > 0.f)
-      for (int i = threadIdx.x; i < KK; i += 64) {
-        const int a = i / K, b = i - a * K;
-        v += ((ssg[i] / nrm - (a == b ? isk : 0.f)) / o) * ssg[i];
-      }
-    v = wave_sum(v);
-    if (threadIdx.x == 0) red[0] = v;
+  // every thread keeps its (up to 16) entries in registers: one pass over ss
+  constexpr int EPT = 16;   // K <= 64: K*K / 256
+  float e[EPT];
+  float v = 0.f;
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int i = threadIdx.x + u * 256;
+    e[u] = i < KK ? ssg[i] : 0.f;
   }
-  __syncthreads();
-  const float inner = red[0];
-  for (int i = threadIdx.x; i < KK; i += 256) {
-    const int a = i / K, b = i - a * K;
-    const float gq = o > 0.f ? (ssg[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
-    Gss[(size_t)g * KK + i] = go2 * ((gq - inner / (nrm * nrm) * ssg[i]) / nrm);
+  if (o > 0.f) {
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      const int i = threadIdx.x + u * 256;
+      if (i < KK) {
+        const int a = i / K, b = i - a * K;
+        v += ((e[u] / nrm - (a == b ? isk : 0.f)) / o) * e[u];
+      }
+    }
+  }
+  const float inner = block_sum_256(v, red);
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int i = threadIdx.x + u * 256;
+    if (i < KK) {
+      const int a = i / K, b = i - a * K;
+      const float gq = o > 0.f ? (e[u] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
+      Gss[(size_t)g * KK + i] = go2 * ((gq - inner / (nrm * nrm) * e[u]) / nrm);
+    }
   }
 }
 
@@ -340,13 +381,18 @@ k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const flo
   }
 }
 
-int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N, int Kd, int64_t lda, int64_t ldb,
-          int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int transA, hipStream_t st, float* rsum = nullptr) {
-  if (N < 1 || N > GNMAX) return HSCN_E_UNSUPPORTED;
-  const int NT = (N + 15) / 16;
-  dim3 grid((M + GM - 1) / GM, (unsigned)batch);
-  if (rsum && !transA) {   // A . B and the row sums of A in one pass
-#define HSCN_BGEMM_RS(NT_) k_bgemm<0, NT_, 1><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, rsum)
+// nr products op(A) * B_z (z < nr <= 3) in one launch; NT covers the widest right-hand side
+int bgemm_multi(const float* A, const BRhs3& R, int nr, int64_t batch, int M, int Kd, int64_t lda, int64_t sA,
+                int transA, hipStream_t st, float* rsum = nullptr) {
+  int nmax = 0;
+  for (int z = 0; z < nr; ++z) {
+    if (R.r[z].N < 1 || R.r[z].N > GNMAX) return HSCN_E_UNSUPPORTED;
+    if (R.r[z].N > nmax) nmax = R.r[z].N;
+  }
+  const int NT = (nmax + 15) / 16;
+  dim3 grid((M + GM - 1) / GM, (unsigned)batch, (unsigned)nr);
+  if (rsum && !transA && nr == 1) {   // A . B and the row sums of A in one pass
+#define HSCN_BGEMM_RS(NT_) k_bgemm<0, NT_, 1><<<grid, 256, 0, st>>>(A, R, M, Kd, lda, sA, rsum)
     switch (NT) {
       case 1: HSCN_BGEMM_RS(1); break;
       case 2: HSCN_BGEMM_RS(2); break;
@@ -357,7 +403,7 @@ int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N
     HSCN_RETURN_IF_LAUNCH_FAILED();
     return 0;
   }
-#define HSCN_BGEMM(TA_, NT_) k_bgemm<TA_, NT_, 0><<<grid, 256, 0, st>>>(A, Bm, C, M, N, Kd, lda, ldb, ldc, sA, sB, sC, nullptr)
+#define HSCN_BGEMM(TA_, NT_) k_bgemm<TA_, NT_, 0><<<grid, 256, 0, st>>>(A, R, M, Kd, lda, sA, nullptr)
   if (transA) {
     switch (NT) {
       case 1: HSCN_BGEMM(1, 1); break;
@@ -376,6 +422,13 @@ int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N
 #undef HSCN_BGEMM
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+
+int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N, int Kd, int64_t lda, int64_t ldb,
+          int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int transA, hipStream_t st, float* rsum = nullptr) {
+  BRhs3 R{};
+  R.r[0] = BRhs{Bm, C, N, ldb, ldc, sB, sC};
+  return bgemm_multi(A, R, 1, batch, M, Kd, lda, sA, transA, st, rsum);
 }
 
 }  // namespace
@@ -410,11 +463,15 @@ int hscn_mincut_dense_fwd(const float* x, const float* adj, const float* logits,
   // A S, and deg = A . 1 from the same pass over the adjacency (0/1 entries: the sums are exact in any order)
   if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st, deg))) return rc;
   // S^T (A S)  -> pooled_adj (raw), S^T S -> ss, S^T X -> pooled_x
-  if ((rc = bgemm(S, AS, pooled_adj, B, K, K, n, K, K, K, (int64_t)n * K, (int64_t)n * K, (int64_t)K * K, 1, st))) return rc;
-  if ((rc = bgemm(S, S, ss, B, K, K, n, K, K, K, (int64_t)n * K, (int64_t)n * K, (int64_t)K * K, 1, st))) return rc;
-  if (x && pooled_x && F > 0)
-    if ((rc = bgemm(S, x, pooled_x, B, K, F, n, K, F, F, (int64_t)n * K, (int64_t)n * F, (int64_t)K * F, 1, st))) return rc;
-  k_dense_finalize<<<(unsigned)B, 256, (K + 4) * 4, st>>>(S, deg, ss, pooled_adj, stats, n, K);
+  {
+    BRhs3 R{};
+    R.r[0] = BRhs{AS, pooled_adj, K, K, K, (int64_t)n * K, (int64_t)K * K};
+    R.r[1] = BRhs{S, ss, K, K, K, (int64_t)n * K, (int64_t)K * K};
+    int nr = 2;
+    if (x && pooled_x && F > 0) R.r[nr++] = BRhs{x, pooled_x, F, F, F, (int64_t)n * F, (int64_t)K * F};
+    if ((rc = bgemm_multi(S, R, nr, B, K, n, K, (int64_t)n * K, 1, st))) return rc;
+  }
+  k_dense_finalize<<<(unsigned)B, 256, (size_t)(2 * K * (K + 1) + K + 4) * 4, st>>>(S, deg, ss, pooled_adj, stats, n, K);
   k_losses_d<<<1, 64, 0, st>>>(stats, losses, (int)B);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
