@@ -247,9 +247,28 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
   float part = 0.f;
   {
     const int tot = n * K;
-    for (int idx = threadIdx.x; idx < tot; idx += 256) {
-      const float v = Sg[idx];
-      part = fmaf(dg[idx / K], v * v, part);
+    if ((K & 3) == 0) {   // float4 pieces, eight requests in flight per trip
+      const int tot4 = tot >> 2, kq = K >> 2;
+      const float4* S4 = reinterpret_cast<const float4*>(Sg);
+      for (int base = threadIdx.x; base < tot4; base += 8 * 256) {
+        float4 v[8];
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i4 = base + u * 256;
+          const bool ok = i4 < tot4;
+          v[u] = S4[ok ? i4 : 0];
+          d[u] = ok ? dg[i4 / kq] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          part = fmaf(d[u], (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w), part);
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < tot; idx += 256) {
+        const float v = Sg[idx];
+        part = fmaf(dg[idx / K], v * v, part);
+      }
     }
   }
   const float den = block_sum_256(part, red);   // (its barriers also publish oal / ssl)
