@@ -63,6 +63,7 @@ def _worker(rank, world, port, q):
     _grads(model, mine)
     with_grad = [p for p in model.parameters() if p.grad is not None]
     flat = torch.cat([p.grad.reshape(-1) for p in with_grad]).clone()
+    flat0 = flat.clone()
     o = 0
     for p in with_grad:
         p.grad = flat[o:o + p.numel()].view_as(p)
@@ -70,6 +71,12 @@ def _worker(rank, world, port, q):
     red.reduce(len(mine), len(hs))
     assert red.last_path == "aliased"
     g3 = torch.cat([p.grad.reshape(-1) for p in with_grad])
+    # a replayed step writes the same buffers again: the reducer reuses its flat view (no layout check)
+    assert red._fast is not None
+    flat.copy_(flat0)
+    red.reduce(len(mine), len(hs))
+    g4 = torch.cat([p.grad.reshape(-1) for p in with_grad])
+    assert torch.equal(g3, g4)
     q.put((rank, g1.numpy(), g2.numpy(), [p.grad is None for p in model.parameters()], g3.numpy()))
     dist.destroy_process_group()
 
