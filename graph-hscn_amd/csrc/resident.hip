@@ -1,36 +1,41 @@
-// Graph-resident HSCN engine: one workgroup per graph, every layer in LDS.
+// Graph-resident HSCN engine: a workgroup keeps one graph's features, CSRs and weights in LDS for
+// every layer.
 //
 // A batch of LRGB graphs is block-diagonal: graph g owns local nodes
 // [lptr[g], lptr[g+1]), virtual nodes [vptr[g], vptr[g+1]) and a contiguous slice
 // of each relation's edge list.  A Peptides graph (n <= 444, e <= ~1000, H = 16)
 // fits in a fraction of one CU's 160 KB LDS, so the whole HSCN forward
 // (reference model/hscn.py:102-114: L x HeteroConv{ll GCN, vv GCN, lv GAT} + ReLU,
-// mean pool, 2-layer head) runs in ONE launch with workgroup barriers only.
+// mean pool, 2-layer head) runs with workgroup barriers only.
 //
-// The kernel is latency-bound (a few MB for the whole batch), so
-// it is organised around the number of dependent steps, not around bandwidth:
-//   prologue : every global input of the graph (features, the three COO slices, layer-0
-//              and head weights) is requested before anything is consumed: one HBM
-//              round trip instead of one per array;
-//   structure: COO slices -> stable CSR in LDS.  Wave group A builds local->local while
-//              group B builds virtual->virtual (LDS int atomics + rank by edge number),
-//              then all waves build local->virtual with a wave-ballot multisplit (its
-//              rows are whole clusters);
-//   layers   : two barriers per layer.  Phase 1: group A transforms for the ll relation,
-//              group B for the lv / vv relations (register-blocked: a lane owns 2-4
-//              outputs of a row, W columns in registers, X row broadcast from LDS).
-//              Phase 2: group A gather-reduces ll (+bias, ReLU, activations to HBM for
-//              the backward), group B runs one wave per cluster: vv gather-reduce +
-//              lv segment softmax (__shfl reductions) + ReLU.  The next layer's weights
-//              are fetched into registers at the top of the layer and parked in the
-//              other LDS weight buffer under this layer's math;
+// Launch shapes (hscn_fwd_body / hscn_bwd_body are the per-workgroup programs):
+//   k_hscn_fwd         one workgroup per graph, both branches (inference, keep_virtual, large batches);
+//   k_hscn_fwd_pair    2 workgroups per graph: even = local chain + head, odd = the part of the virtual
+//                      branch that does not need it (its CSRs + layer 0), state left in HBM;
+//   k_hscn_bwd_virtual 2 workgroups per graph: even = backward, odd = virtual layers 1.. resumed from that
+//                      state and the stored local activations;
+//   k_hscn_bwd         one workgroup per graph.
+// The virtual branch cannot influence the prediction in the reference architecture ("local" only
+// receives ll); it is computed for fidelity, on CUs a 128-graph batch would leave idle.
+//
+// The kernels are latency-bound (a few MB for the whole batch), so they are
+// organised around the number of dependent steps, not around bandwidth:
+//   prologue : every global input of the graph is requested before anything is consumed (edges first:
+//              they are consumed first; features and weights are parked under the CSR builds);
+//   structure: COO slices -> stable CSR in LDS, the independent CSRs side by side on wave groups between
+//              the same barriers (LDS int atomics + rank by edge number; lv, whose rows are whole
+//              clusters, by a wave-ballot multisplit); scratch lives inside the not-yet-used feature
+//              buffer; the source-keyed ll CSR is exported for the backward launch;
+//   layers   : two barriers per layer.  Local chain: X W^T on v_mfma_f32_16x16x4_f32, then the CSR
+//              gather-reduce (+bias, ReLU, activations to HBM).  Virtual branch: register-blocked
+//              transforms, lv segment softmax per 64-member chunk (last chunk wave of a cluster folds the
+//              partials and adds the vv row).  Next layer's weights are fetched at the top of the layer
+//              and parked in the other LDS weight buffer under this layer's math;
 //   epilogue : mean pool over all waves, head by wave 0.
-// The virtual branch cannot influence the prediction in the reference architecture
-// ("local" only receives ll); it is computed for fidelity and runs beside the ll path.
 //
-// The backward mirrors it (transposed CSR in LDS, wave-tile outer-product weight
-// gradients with DPP row reductions, per-graph parameter-gradient partials, then one
-// ordered reduction over graphs): no float atomics, bitwise reproducible.
+// The backward mirrors it (exported transposed CSR, MFMA weight / input gradients, conflict-free bias
+// sums, per-graph parameter-gradient partials, then one ordered reduction over graphs): no float
+// atomics, bitwise reproducible; three n x H buffers, or two when LDS is short.
 //
 // Numerics: k-ascending fmaf chains in the transforms, edge-order separately rounded
 // multiply/add in the gather-reduce (same as the layered kernels).
