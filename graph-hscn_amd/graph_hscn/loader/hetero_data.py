@@ -113,20 +113,23 @@ def hetero_batch_on_device(batch, clusters: torch.Tensor, num_clusters: int):
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     _hip.call("hscn_build_hetero_count", _hip.ptr(x), int(x.dtype == torch.int64), _hip.ptr(clusters), _hip.ptr(nptr),
               B, F, K, _hip.ptr(U), _hip.ptr(lvl), _hip.ptr(means), _hip.ptr(flag), _hip.stream())
-    U64 = U.to(torch.int64)
-    vptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
-    evptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
-    vptr[1:] = torch.cumsum(U64, 0)
-    evptr[1:] = torch.cumsum(U64 * (U64 + 1) // 2, 0)
-    tot = torch.stack([vptr[-1], evptr[-1], flag[0].to(torch.int64), U64.max()]).cpu()      # the one host read
-    V, Evv, bad, maxU = (int(t) for t in tot)
+    vptr = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    evptr = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    vptr32 = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    evptr32 = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    totals = torch.empty(4, dtype=torch.int64, device=dev)
+    _hip.call("hscn_build_hetero_scan", _hip.ptr(U), B, _hip.ptr(flag), _hip.ptr(vptr), _hip.ptr(evptr),
+              _hip.ptr(vptr32), _hip.ptr(evptr32), _hip.ptr(totals), _hip.stream())
+    V, Evv, bad, maxU = (int(t) for t in totals.cpu())                                       # the one host read
     if bad:
         raise IndexError("cluster ids must lie in [0, num_clusters)")
     vx = torch.empty(V, F, dtype=torch.float32, device=dev)
     ei_lv = torch.empty(2, N, dtype=torch.int64, device=dev)
     ei_vv = torch.empty(2, Evv, dtype=torch.int64, device=dev)
+    vbatch = torch.empty(V, dtype=torch.int64, device=dev)
     _hip.call("hscn_build_hetero_emit", _hip.ptr(U), _hip.ptr(vptr), _hip.ptr(evptr), _hip.ptr(nptr), _hip.ptr(lvl),
-              _hip.ptr(means), B, F, K, N, Evv, _hip.ptr(vx), _hip.ptr(ei_lv), _hip.ptr(ei_vv), _hip.stream())
+              _hip.ptr(means), B, F, K, N, Evv, _hip.ptr(vx), _hip.ptr(ei_lv), _hip.ptr(ei_vv), _hip.ptr(vbatch),
+              _hip.stream())
     hb = HeteroBatch()
     hb.num_graphs = B
     loc, vir = hb["local"], hb["virtual"]
@@ -140,15 +143,15 @@ def hetero_batch_on_device(batch, clusters: torch.Tensor, num_clusters: int):
     loc.num_nodes = N
     vir.x = vx
     vir.ptr = vptr
-    vir.ptr32 = vptr.to(torch.int32)
-    vir.batch = torch.repeat_interleave(torch.arange(B, device=dev), U64)
+    vir.ptr32 = vptr32
+    vir.batch = vbatch
     vir.max_nodes = maxU
     vir.num_nodes = V
     hb[LL].edge_index = batch.edge_index
     hb[LL].ptr32 = batch.eptr32 if batch.eptr32.device == dev else batch.eptr32.to(dev)
     hb[LL].max_edges = int(batch.max_edges)
     hb[VV].edge_index = ei_vv
-    hb[VV].ptr32 = evptr.to(torch.int32)
+    hb[VV].ptr32 = evptr32
     hb[VV].max_edges = maxU * (maxU + 1) // 2
     hb[LV].edge_index = ei_lv
     hb[LV].ptr32 = nptr

@@ -237,17 +237,23 @@ int hscn_assign_argmax(const float* S, int64_t* ids, int64_t num_nodes, int K, v
  * A batch of graphs (node ranges nptr) with raw cluster ids per node (K <= 64):
  *   count: U[g] = distinct ids, lvl[i] = remapped id of node i (np.unique order),
  *          means[g,v,:] = float32(float64 mean, node order) of remapped cluster (v+1) mod U[g]
- *   (host: vptr = cumsum(U), evptr = cumsum(U(U+1)/2) -- the outputs have data-dependent sizes)
+ *   scan : vptr = exclusive cumsum(U), evptr = exclusive cumsum(U(U+1)/2) as int64 [B+1] (PyG ptr) and
+ *          int32 [B+1] (resident kernels), totals [4] = {V, E_vv, flag word, max U}: the one thing the host
+ *          reads back, because the outputs have data-dependent sizes
  *   emit : virtual_x [V,F]; ei_lv [2,N] = {node, vptr[g] + lvl}; ei_vv [2,Evv] = {(i -> j): i+j <= U-1}
- *          in the reference's order, offset by vptr.
+ *          in the reference's order, offset by vptr; vbatch [V] (or NULL) = graph id of every virtual node.
  * x is int64 (atom features) or fp32; flag bit 8: a cluster id outside [0,K).
  * ------------------------------------------------------------------------- */
 int hscn_build_hetero_count(const void* x, int x_is_int64, const int64_t* clusters, const int32_t* nptr,
                             int64_t B, int F, int K, int32_t* U /*[B]*/, int32_t* lvl /*[N]*/,
                             float* means /*[B,K,F]*/, int32_t* flag, void* stream);
+int hscn_build_hetero_scan(const int32_t* U, int64_t B, const int32_t* flag /*or NULL*/, int64_t* vptr /*[B+1]*/,
+                           int64_t* evptr /*[B+1]*/, int32_t* vptr32 /*[B+1]*/, int32_t* evptr32 /*[B+1]*/,
+                           int64_t* totals /*[4]*/, void* stream);
 int hscn_build_hetero_emit(const int32_t* U, const int64_t* vptr /*[B+1]*/, const int64_t* evptr /*[B+1]*/,
                            const int32_t* nptr, const int32_t* lvl, const float* means, int64_t B, int F, int K,
-                           int64_t N, int64_t Evv, float* virtual_x, int64_t* ei_lv, int64_t* ei_vv, void* stream);
+                           int64_t N, int64_t Evv, float* virtual_x, int64_t* ei_lv, int64_t* ei_vv,
+                           int64_t* vbatch /*[V] or NULL*/, void* stream);
 
 /* a5  to_dense_adj (reference model/hscn.py:61): adj must be
  * zero-filled by the caller's stream order; adj[row_e*n + col_e] += 1. */
