@@ -124,7 +124,12 @@ def ptr(t: Optional[torch.Tensor]):
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current HIP stream of the current device (the private getter is ~20x cheaper than
+    building a ``torch.cuda.Stream`` object; the eager path is host-bound)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream
 
 
 def check(rc: int, name: str) -> None:

@@ -175,11 +175,7 @@ class HSCN(nn.Module):
         name = _act_name(self.activation)
         ok = (name in ACT_DICT and set(edge_index_dict) == {LL, VV, LV} and "local" in x_dict
               and "virtual" in x_dict and x_dict["local"].is_cuda)
-        if ok:
-            for conv in self.convs:
-                c = conv.convs
-                ok = ok and isinstance(c["__".join(LL)], GCNConv) and isinstance(c["__".join(VV)], GCNConv) \
-                    and isinstance(c["__".join(LV)], GATConv)
+        ok = ok and self._resident_params() is not None
         meta = _engine.meta_from_batch(batch, x_dict["local"].device) if ok else None
         H, C = self.lin_1.out_channels, self.lin_2.out_channels
         if meta is None or not _engine.supported(x_dict["local"].size(1), H, len(self.convs), C, meta):
@@ -190,13 +186,30 @@ class HSCN(nn.Module):
             return None
         return meta, name
 
-    def _forward_resident(self, x_dict, edge_index_dict, meta, act_name) -> Tensor:
+    def _resident_params(self):
+        """The parameter order the resident launches take, or None when the relations are not the
+        GAT / GCN / GCN combination; looked up once (the eager path is host-bound), rebuilt when the module
+        tree changes (load_state_dict keeps the Parameter objects, assigning new modules does not)."""
+        key = tuple(id(m) for conv in self.convs for m in conv.convs.values()) + (id(self.lin_1.weight), id(self.lin_2.weight))
+        cached = getattr(self, "_resident_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         params = []
         for conv in self.convs:
-            ll, vv, lv = (conv.convs["__".join(k)] for k in (LL, VV, LV))
+            c = conv.convs
+            ll, vv, lv = (c["__".join(k)] for k in (LL, VV, LV))
+            if not (isinstance(ll, GCNConv) and isinstance(vv, GCNConv) and isinstance(lv, GATConv)):
+                params = None
+                break
             params += [ll.lin.weight, ll.bias, vv.lin.weight, vv.bias, lv.lin_src.weight, lv.lin_dst.weight,
                        lv.att_src, lv.att_dst, lv.bias]
-        params += [self.lin_1.weight, self.lin_1.bias, self.lin_2.weight, self.lin_2.bias]
+        if params is not None:
+            params += [self.lin_1.weight, self.lin_1.bias, self.lin_2.weight, self.lin_2.bias]
+        object.__setattr__(self, "_resident_cache", (key, params))
+        return params
+
+    def _forward_resident(self, x_dict, edge_index_dict, meta, act_name) -> Tensor:
+        params = self._resident_params()
         slope = self.convs[0].convs["__".join(LV)].negative_slope
         cfg = (_engine.ACT[act_name], slope, self.compute_virtual, self.keep_virtual, self.overlap_virtual)
         out = _engine.HSCNResidentFn.apply(x_dict["local"], x_dict["virtual"], edge_index_dict[LL],
