@@ -1,0 +1,175 @@
+"""hipGraph replay of the training step across DIFFERENT batches.
+
+A captured step replays only if every pointer and every host-side size it was captured with stays
+valid.  The graph-resident kernels read the per-graph node / edge ranges from device arrays, so the
+only host constants are capacities: ``StaticHeteroBatch`` owns device buffers sized for the largest
+batch of a loader (nodes, edges per relation, virtual nodes; per-graph maxima that size the LDS), each
+step's batch is copied INTO them (``load``), and the captured launches run on whatever the buffers
+hold.  ``CapturedStep`` captures ``zero grads -> HSCN.forward -> criterion -> backward`` once; afterwards
+a training iteration is ``static.load(batch); step.replay(); optimizer.step()``.
+
+The reference loop (train/train.py:73-95) issues ~150 small launches per step from Python; the eager
+path here issues 4 but is still host-bound -- replay is what lets the GPU, not
+the interpreter, set the pace of an epoch.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+from torch import Tensor
+
+from .data import HeteroBatch
+from .loss import criterion
+
+LL = ("local", "to", "local")
+VV = ("virtual", "to", "virtual")
+LV = ("local", "to", "virtual")
+
+
+class StaticHeteroBatch:
+    """Fixed-capacity device buffers with the ``HeteroBatch`` protocol (``.batch`` is the object to hand
+    to the model).  Only for the graph-resident engine: edge lists are valid inside the per-graph ranges
+    of ``ptr32`` only, the tail of every buffer is stale data of earlier, larger batches.
+
+    All fields are views of ONE flat byte buffer, so a batch that was ``pack``-ed ahead of time (on the
+    device or in pinned host memory) is loaded by a single copy."""
+
+    def __init__(self, batches: Iterable[HeteroBatch], device, num_classes: Optional[int] = None):
+        batches = list(batches)
+        if not batches:
+            raise ValueError("need at least one batch to size the buffers")
+        B = {int(b.num_graphs) for b in batches}
+        if len(B) != 1:
+            raise ValueError("all batches must hold the same number of graphs (drop or pad the last one)")
+        self.num_graphs = B.pop()
+        self.device = torch.device(device)
+        cap = lambda f: max(int(f(b)) for b in batches)
+        self.N = cap(lambda b: b["local"].num_nodes)
+        self.V = cap(lambda b: b["virtual"].num_nodes)
+        self.E = {et: max(cap(lambda b, et=et: b[et].edge_index.size(1)), 1) for et in (LL, VV, LV)}
+        self.max_nodes = {"local": cap(lambda b: b["local"].max_nodes), "virtual": cap(lambda b: b["virtual"].max_nodes)}
+        self.max_edges = {et: cap(lambda b, et=et: b[et].max_edges) for et in (LL, VV, LV)}
+        F = int(batches[0]["local"].x.size(1))
+        y0 = batches[0]["local"].y if "y" in batches[0]["local"] else None
+        G = self.num_graphs
+        fields = [("x_local", torch.float32, (self.N, F)), ("x_virtual", torch.float32, (self.V, F))]
+        for nt, n in (("local", self.N), ("virtual", self.V)):
+            fields += [(f"ptr_{nt}", torch.int64, (G + 1,)), (f"ptr32_{nt}", torch.int32, (G + 1,)),
+                       (f"batch_{nt}", torch.int64, (n,))]
+        if y0 is not None:
+            C = int(y0.size(1)) if num_classes is None else int(num_classes)
+            fields.append(("y", torch.float32, (G, C)))
+        for i, et in enumerate((LL, VV, LV)):
+            fields += [(f"ei_{i}", torch.int64, (2, self.E[et])), (f"eptr_{i}", torch.int32, (G + 1,))]
+        self._layout, off = [], 0
+        for name, dt, shape in fields:
+            nbytes = torch.empty((), dtype=dt).element_size()
+            for d in shape:
+                nbytes *= d
+            self._layout.append((name, dt, shape, off, nbytes))
+            off += (nbytes + 15) // 16 * 16
+        self.nbytes = off
+        self.flat = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.batch = self._view(self.flat)
+
+    def _view(self, flat: Tensor) -> HeteroBatch:
+        t = {name: flat[off: off + nb].view(dt).view(shape) for name, dt, shape, off, nb in self._layout}
+        hb = HeteroBatch()
+        hb.num_graphs = self.num_graphs
+        for nt, n in (("local", self.N), ("virtual", self.V)):
+            st = hb[nt]
+            st.x = t[f"x_{nt}"]
+            st.ptr, st.ptr32, st.batch = t[f"ptr_{nt}"], t[f"ptr32_{nt}"], t[f"batch_{nt}"]
+            st.num_nodes = n
+            st.max_nodes = self.max_nodes[nt]
+        if "y" in t:
+            hb["local"].y = t["y"]
+        for i, et in enumerate((LL, VV, LV)):
+            hb[et].edge_index = t[f"ei_{i}"]
+            hb[et].ptr32 = t[f"eptr_{i}"]
+            hb[et].max_edges = self.max_edges[et]
+        return hb
+
+    def _fill(self, dst: HeteroBatch, src: HeteroBatch) -> None:
+        if int(src.num_graphs) != self.num_graphs:
+            raise ValueError("batch holds a different number of graphs than the static buffers")
+        for nt, capn in (("local", self.N), ("virtual", self.V)):
+            s, d = src[nt], dst[nt]
+            n = int(s.num_nodes)
+            if n > capn or int(s.max_nodes) > self.max_nodes[nt]:
+                raise ValueError(f"batch exceeds the static capacity of '{nt}' nodes")
+            d.x[:n].copy_(s.x, non_blocking=True)
+            d.batch[:n].copy_(s.batch, non_blocking=True)
+            d.ptr.copy_(s.ptr, non_blocking=True)
+            d.ptr32.copy_(s.ptr32, non_blocking=True)
+        if "y" in src["local"] and "y" in dst["local"]:
+            dst["local"].y.copy_(src["local"].y, non_blocking=True)
+        for et in (LL, VV, LV):
+            s, d = src[et], dst[et]
+            e = int(s.edge_index.size(1))
+            if e > self.E[et] or int(s.max_edges) > self.max_edges[et]:
+                raise ValueError(f"batch exceeds the static capacity of relation {et}")
+            d.edge_index[:, :e].copy_(s.edge_index, non_blocking=True)
+            d.ptr32.copy_(s.ptr32, non_blocking=True)
+
+    def pack(self, src: HeteroBatch, device=None, pin_memory: bool = False) -> Tensor:
+        """``src`` laid out like the static buffers, as one flat byte tensor (on ``device``, default: the
+        static buffers' device; or in pinned host memory): what ``load`` takes with a single copy."""
+        dev = torch.device(device) if device is not None else self.device
+        flat = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev, pin_memory=(pin_memory and dev.type == "cpu"))
+        self._fill(self._view(flat), src)
+        return flat
+
+    def load(self, src) -> HeteroBatch:
+        """Make the static buffers hold ``src``: a packed byte tensor (one copy) or a ``HeteroBatch`` on the
+        host or the device (one copy per field).  Asynchronous on the current stream."""
+        if isinstance(src, Tensor):
+            if src.dtype != torch.uint8 or src.numel() != self.nbytes:
+                raise ValueError("not a batch packed by this StaticHeteroBatch")
+            self.flat.copy_(src, non_blocking=True)
+        else:
+            self._fill(self.batch, src)
+        return self.batch
+
+
+class CapturedStep:
+    """``zero grads -> model(batch) -> criterion -> backward`` captured once on ``static.batch``.
+    ``replay()`` runs it on whatever was last loaded; ``loss`` / ``pred`` / ``score`` are the captured
+    output tensors (refreshed by every replay), parameter gradients live in the graph's memory pool.
+
+    Drop the outputs of earlier EAGER steps of the same model (``loss``, ``pred``) before constructing this:
+    they keep the parameters' gradient-accumulation nodes alive, bound to the stream those steps ran on,
+    and autograd would then tie the capture to that (non-capturing) stream."""
+
+    def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3):
+        self.model, self.static, self.loss_fn = model, static, loss_fn
+        hb = static.batch
+        if "y" not in hb["local"]:
+            raise ValueError("the static batch carries no targets")
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            pred = model(hb.x_dict, hb.edge_index_dict, hb)
+            loss, score = criterion(loss_fn, pred, hb["local"].y)
+            loss.backward()
+            return pred.detach(), loss.detach(), score
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if getattr(model, "last_engine", None) != "resident":
+            raise RuntimeError("CapturedStep needs the graph-resident engine (the layered operators size their "
+                               "work by tensor shapes, which a static-capacity batch does not carry)")
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.pred, self.loss, self.score = step()
+
+    def replay(self) -> Tensor:
+        self.graph.replay()
+        return self.loss

@@ -85,3 +85,53 @@ def test_loss_gradient_scalar_is_applied_by_whoever_consumes_it():
             assert got.keys() == ref.keys()
             for n in ref:
                 assert torch.allclose(got[n], ref[n], atol=1e-6, rtol=1e-4), (eng, root, n)
+
+
+def test_captured_step_replays_on_different_batches():
+    """graph_hscn.replay: one captured training step (static-capacity buffers) replayed on three different
+    batches == the eager step on each of them, bit for bit (prediction, loss, gradients)."""
+    import numpy as np
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.data import HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.loss import criterion
+    from graph_hscn.model.hscn import HSCN
+    from graph_hscn.replay import CapturedStep, StaticHeteroBatch
+    dev = torch.device("cuda:0")
+    B, K, C = 10, 16, 10
+    rng = np.random.default_rng(0)
+    batches = []
+    for seed in (1, 2, 3):
+        graphs = make_dataset("peptides_func", B, seed=seed)
+        for g in graphs:
+            g.y = torch.from_numpy((rng.random((1, C)) < 0.3).astype(np.float32))
+        batches.append(HeteroBatch.from_data_list(
+            [hetero_from_clusters(g, rng.integers(0, K, g.num_nodes), K) for g in graphs]))
+    torch.manual_seed(0)
+    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, C, 3).to(dev)
+    model.engine = "resident"
+    ref = []
+    for hb in batches:
+        d = hb.to(dev)
+        model.zero_grad(set_to_none=True)
+        pred = model(d.x_dict, d.edge_index_dict, d)
+        loss, _ = criterion("cross_entropy", pred, d["local"].y)
+        loss.backward()
+        ref.append((pred.detach().clone(), loss.detach().clone(),
+                    {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    del pred, loss, d      # (tensors of an eager step keep autograd nodes tied to the stream they ran on)
+    static = StaticHeteroBatch(batches, dev)
+    static.load(batches[0])
+    step = CapturedStep(model, static, "cross_entropy")
+    packed = [static.pack(hb) for hb in batches]          # laid out like the static buffers: one copy per load
+    for k, i in enumerate((1, 2, 0, 2, 1)):
+        static.load(packed[i] if k % 2 else batches[i])
+        loss = step.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(step.pred, ref[i][0])
+        assert torch.equal(loss, ref[i][1])
+        for n, p in model.named_parameters():
+            if n in ref[i][2]:
+                assert torch.equal(p.grad, ref[i][2][n]), (i, n)
+    static.batch._resident_meta.check()
