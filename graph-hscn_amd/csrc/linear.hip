@@ -81,16 +81,16 @@ __global__ void k_rowdot(const float* __restrict__ y, const float* __restrict__ 
 }
 
 // ---- weight / bias gradient: partial[g][p] over row chunk g, pair p = o*(I+1)+i ----
-constexpr int BW_T = 32;       // rows per LDS tile
+constexpr int BW_T = 32;       // rows per LDS tile (fewer when in_f is wide: the tile must fit 64 KB)
 constexpr int BW_PPT = 16;     // pairs per thread per pass
 constexpr int BW_PAIRS = LIN_THREADS * BW_PPT;
 
 __global__ void __launch_bounds__(LIN_THREADS)
 k_linear_bwd_w_partial(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ partial,
-                       int64_t rows, int I, int O, int64_t rows_per_chunk, int P) {
+                       int64_t rows, int I, int O, int64_t rows_per_chunk, int P, int T) {
   extern __shared__ __align__(16) float lds[];
-  float* gy_t = lds;                       // [BW_T][O]
-  float* x_t = lds + (size_t)BW_T * O;     // [BW_T][I+1]  (last column = 1 for the bias)
+  float* gy_t = lds;                       // [T][O]
+  float* x_t = lds + (size_t)T * O;        // [T][I+1]  (last column = 1 for the bias)
   const int I1 = I + 1;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
   int64_t r_end = r_begin + rows_per_chunk;
@@ -104,8 +104,8 @@ k_linear_bwd_w_partial(const float* __restrict__ gy, const float* __restrict__ x
     if (p < P) { po[k] = p / I1; pi[k] = p - po[k] * I1; } else { po[k] = -1; pi[k] = 0; }
     acc[k] = 0.f;
   }
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += BW_T) {
-    int nt = (int)((r_end - r0) < BW_T ? (r_end - r0) : BW_T);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += T) {
+    int nt = (int)((r_end - r0) < T ? (r_end - r0) : T);
     __syncthreads();
     for (int idx = threadIdx.x; idx < nt * O; idx += LIN_THREADS) gy_t[idx] = gy[r0 * O + idx];
     for (int idx = threadIdx.x; idx < nt * I1; idx += LIN_THREADS) {
@@ -220,10 +220,12 @@ int hscn_linear_bwd_w(const float* gy, const float* x, float* gW, float* gb, int
   const int P = O * (I + 1);
   const int G = chunks_for(rows);
   const int64_t rpc = (rows + G - 1) / G;
-  size_t lds = (size_t)BW_T * (O + I + 1) * 4;
+  int T = BW_T;
+  while (T > 1 && (size_t)T * (O + I + 1) * 4 > 64 * 1024) T >>= 1;
+  size_t lds = (size_t)T * (O + I + 1) * 4;
   if (lds > 64 * 1024) return HSCN_E_UNSUPPORTED;
   dim3 grid(G, (P + BW_PAIRS - 1) / BW_PAIRS);
-  k_linear_bwd_w_partial<<<grid, LIN_THREADS, lds, st>>>(gy, x, (float*)workspace, rows, I, O, rpc, P);
+  k_linear_bwd_w_partial<<<grid, LIN_THREADS, lds, st>>>(gy, x, (float*)workspace, rows, I, O, rpc, P, T);
   k_linear_bwd_w_reduce<<<hscn_blocks(P, 256), 256, 0, st>>>((const float*)workspace, gW, gb, G, I, O, P,
                                                              accumulate);
   HSCN_RETURN_IF_LAUNCH_FAILED();

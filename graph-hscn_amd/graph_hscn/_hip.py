@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 from typing import Optional
 
 import torch
@@ -35,6 +35,7 @@ _SIGNATURES = {
     "hscn_linear_bwd_w": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P, c_size_t, P]),
     "hscn_act_fwd": (c_int, [P, P, c_int64, c_int, P]),
     "hscn_act_bwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hscn_dropout": (c_int, [P, P, c_int64, c_float, c_uint64, P]),
     "hscn_spmm_csr_gcn": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     "hscn_spmm_csr_weighted": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
     "hscn_gat_segment_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, c_int, P]),

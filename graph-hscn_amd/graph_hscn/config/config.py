@@ -57,6 +57,29 @@ class DataConfig:  # config.py:32-46
         self.task_level = "graph" if "peptides" in self.dataset_name else (self.task_level or "graph")
 
 
+DROPOUT = 0.2  # defaults.py:6
+USE_BATCH_NORM = False
+USE_LAYER_NORM = False
+
+
+@dataclass
+class MPNNConfig:  # config.py:49-73
+    conv_type: str
+    activation: str
+    hidden_channels: int = HIDDEN_CHANNELS
+    num_layers: int = NUM_LAYERS
+    dropout: float = DROPOUT
+    use_batch_norm: bool = USE_BATCH_NORM
+    use_layer_norm: bool = USE_LAYER_NORM
+
+    def __post_init__(self):
+        if self.dropout and not (0.0 <= self.dropout <= 1.0):
+            raise ValueError(f"{self.dropout} must be between 0.0 and 1.0.")
+        for v in (self.num_layers, self.hidden_channels):
+            if v < 0:
+                raise ValueError(f"{v} must be non-negative.")
+
+
 @dataclass
 class HSCNConfig:  # config.py:76-93 (+ mp_units, read at main.py:102 but absent there)
     activation: str

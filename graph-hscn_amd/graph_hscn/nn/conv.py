@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from .._hip import ACT
-from ..structure import Relation, relation_of
+from ..structure import Relation, relation_of, self_loop_relation_of
 from . import functional as Fh
 
 
@@ -89,21 +89,27 @@ class GraphConv(nn.Module):
 
 
 class GCNConv(nn.Module):
-    """PyG GCNConv restricted to what build_conv_relation constructs
-    (model/hscn.py:117-125): ``add_self_loops=False``, ``normalize=True``,
-    unit edge weights."""
+    """PyG GCNConv, ``normalize=True``, unit edge weights.
+    ``add_self_loops=False`` is what build_conv_relation constructs (model/hscn.py:117-125);
+    the default ``add_self_loops=True`` is what the MPNN baseline constructs (model/mpnn.py:28-32):
+    the same kernels over the edge list with one loop per node appended, whose in-degree is
+    gcn_norm's degree."""
 
     def __init__(self, in_channels: int, out_channels: int, add_self_loops: bool = True,
                  cached: bool = False, bias: bool = True):
         super().__init__()
-        if add_self_loops:
-            raise NotImplementedError("the hot path builds GCNConv with add_self_loops=False (hscn.py:123-125)")
+        self.add_self_loops = bool(add_self_loops)
         self.lin = Linear(in_channels, out_channels, bias=False, weight_initializer="glorot")
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
     def forward(self, x: Tensor, edge_index: Union[Tensor, Relation], act: str = "identity") -> Tensor:
         self.lin.materialize(x.size(-1), x)
-        rel = _relation(edge_index, x.size(0), x.size(0))
+        if isinstance(edge_index, Relation):
+            rel = edge_index                      # the caller built the structure (loops included if wanted)
+        elif self.add_self_loops:
+            rel = self_loop_relation_of(edge_index, x.size(0))
+        else:
+            rel = relation_of(edge_index, x.size(0), x.size(0))
         return Fh.GCNConvFn.apply(x, self.lin.weight, self.bias, rel, ACT[act])
 
 

@@ -114,6 +114,47 @@ class Activation:
 
 
 # --------------------------------------------------------------------------- #
+# Dropout (MPNN baseline, reference model/mpnn.py:58)
+# --------------------------------------------------------------------------- #
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, p: float, seed: int):
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("hscn_dropout", ptr(x), ptr(y), x.numel(), float(p), int(seed), stream())
+        ctx.p, ctx.seed = float(p), int(seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = _c(g)
+        gx = torch.empty_like(g)
+        call("hscn_dropout", ptr(g), ptr(gx), g.numel(), ctx.p, ctx.seed, stream())   # same seed: same mask
+        return gx, None, None
+
+
+_dropout_calls = 0
+
+
+def dropout(x: Tensor, p: float = 0.5, training: bool = True, seed: Optional[int] = None) -> Tensor:
+    """``F.dropout`` semantics (inverted scaling; identity when not training or p == 0).  The mask comes
+    from the library's counter-based generator, keyed by ``seed`` (default: ``torch.initial_seed()`` mixed
+    with a per-call counter, so ``torch.manual_seed`` makes a run repeatable); it is NOT the mask torch's
+    own generator would draw.  The default seed is a host value: a captured hipGraph replays one mask."""
+    global _dropout_calls
+    if p < 0.0 or p > 1.0:
+        raise ValueError(f"dropout probability has to be between 0 and 1, but got {p}")
+    if not training or p == 0.0:
+        return x
+    if p == 1.0:
+        return x * 0.0
+    if seed is None:
+        _dropout_calls += 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _dropout_calls) & 0xFFFFFFFFFFFFFFFF
+    return DropoutFn.apply(x, p, seed)
+
+
+# --------------------------------------------------------------------------- #
 # Linear
 # --------------------------------------------------------------------------- #
 class LinearFn(Function):

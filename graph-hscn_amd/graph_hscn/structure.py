@@ -126,7 +126,35 @@ def relation_of(edge_index: Tensor, num_src: int, num_dst: int, cache: bool = Tr
     return rel
 
 
+def with_self_loops(edge_index: Tensor, num_nodes: int) -> Tensor:
+    """PyG ``add_remaining_self_loops`` for unit weights: existing self loops are taken out,
+    one loop per node is appended after the remaining edges (so a target-keyed stable CSR ends every row
+    with its loop, the order the reference's scatter-add sums in).  Index plumbing on the device."""
+    keep = edge_index[0] != edge_index[1]
+    loops = torch.arange(int(num_nodes), dtype=torch.int64, device=edge_index.device)
+    return torch.cat([edge_index[:, keep], loops.unsqueeze(0).expand(2, -1)], 1).contiguous()
+
+
+_LOOP_CACHE: "OrderedDict[Tuple, Tuple[Tensor, Relation]]" = OrderedDict()
+
+
+def self_loop_relation_of(edge_index: Tensor, num_nodes: int) -> Relation:
+    """Relation over ``edge_index`` + self loops (what GCNConv(add_self_loops=True) normalises and
+    propagates over), cached per tensor like ``relation_of``."""
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device), int(num_nodes))
+    hit = _LOOP_CACHE.get(key)
+    if hit is not None and hit[0] is edge_index:
+        _LOOP_CACHE.move_to_end(key)
+        return hit[1]
+    rel = Relation(with_self_loops(edge_index, num_nodes), num_nodes, num_nodes)
+    _LOOP_CACHE[key] = (edge_index, rel)
+    while len(_LOOP_CACHE) > _CACHE_MAX:
+        _LOOP_CACHE.popitem(last=False)
+    return rel
+
+
 def clear_cache() -> None:
+    _LOOP_CACHE.clear()
     _CACHE.clear()
 
 

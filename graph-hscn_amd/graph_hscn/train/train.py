@@ -25,6 +25,8 @@ def _run_batch(model, batch, device):
     if isinstance(model, HSCN):
         batch = batch.to(device)
         return model(batch.x_dict, batch.edge_index_dict, batch), batch["local"].y
+    # train.py:78-80 leaves the batch where the loader put it; the HIP operators take device tensors only
+    batch = batch.to(device)
     batch.x = batch.x.float()
     return model(batch), batch.y
 

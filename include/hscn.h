@@ -116,6 +116,13 @@ int hscn_act_fwd(const float* x, float* y, int64_t count, int act, void* stream)
  * elu: y>0 ? 1 : y+1; tanh: 1-y^2).  g may alias gy. */
 int hscn_act_bwd(const float* gy, const float* y, float* g, int64_t count, int act, void* stream);
 
+/* Inverted dropout (reference model/mpnn.py:58, F.dropout(x, p, training) of the MPNN baseline):
+ * y[i] = keep(seed, i) ? x[i] / (1 - p) : 0, keep drawn per element from Philox-4x32-10 keyed by
+ * `seed` with the element number as counter (P(keep) = 1 - p).  The mask is a pure function of
+ * (seed, i): the backward is the same entry on the incoming gradient with the same seed.
+ * 0 <= p < 1; y may alias x. */
+int hscn_dropout(const float* x, float* y, int64_t count, float p, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * a12  GCNConv propagate, unit weights, no self loops
  * (reference model/hscn.py:88-93):

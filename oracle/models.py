@@ -5,7 +5,8 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED.
 Follows /root/reference/graph_hscn/model/hscn.py:
   SCN   :19-64   (GraphConv stack -> Linear -> to_dense_adj -> dense_mincut_pool)
   HSCN  :67-114  (L x HeteroConv{lv: GAT, ll: GCN, vv: GCN} -> ReLU -> mean pool -> 2 Linear)
-and the stage-A driver /root/reference/graph_hscn/train/train_clustering.py:36-69.
+and the stage-A driver /root/reference/graph_hscn/train/train_clustering.py:36-69;
+  MPNN  /root/reference/graph_hscn/model/mpnn.py:13-62 (the GCN baseline of BASELINE config 1).
 ``state_dict`` keys follow PyG naming so weights can
 be copied 1:1 into the product modules.
 """
@@ -123,6 +124,39 @@ class HSCN(nn.Module):
         x = P.global_mean_pool(x_dict["local"], batch_local, num_graphs)
         x = self.activation(self.lin_1(x))
         return self.lin_2(x)
+
+
+class MPNN(nn.Module):
+    """model/mpnn.py:13-62 with ``conv = GCNConv`` (config/config.py:19-23, configs/GCN/peptides_func_GCN.yaml:6):
+    GCNConv(add_self_loops=True) stack, ``F.relu`` then the configured activation then dropout after every
+    hidden layer, ``scatter_mean`` over the batch vector at the end.  Normalisation layers are not restated
+    (``use_batch_norm`` alone is an AttributeError in the reference, mpnn.py:35-38,54)."""
+
+    def __init__(self, activation: Callable, num_features: int, hidden_channels: int, num_classes: int,
+                 num_layers: int, dropout: float = 0.0):
+        super().__init__()
+        self.num_layers = num_layers
+        self.conv_layers = nn.ModuleList()
+        self.conv_layers.append(P.GCNConv(num_features, hidden_channels))
+        for _ in range(num_layers - 2):
+            self.conv_layers.append(P.GCNConv(hidden_channels, hidden_channels))
+        self.conv_layers.append(P.GCNConv(hidden_channels, num_classes))
+        self.activation = activation
+        self.dropout = dropout
+
+    def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, num_graphs: Optional[int] = None,
+                masks: Optional[List[Tensor]] = None) -> Tensor:
+        """``masks`` (one 0/1 tensor per hidden layer) replaces F.dropout's own draw so that a product run
+        with a known mask can be compared element for element."""
+        for i in range(self.num_layers - 1):
+            x = F.relu(self.conv_layers[i](x, edge_index))
+            x = self.activation(x)
+            if masks is not None:
+                x = x * masks[i] * (1.0 / (1.0 - self.dropout))
+            else:
+                x = F.dropout(x, p=self.dropout, training=self.training)
+        x = self.conv_layers[-1](x, edge_index)
+        return P.global_mean_pool(x, batch, num_graphs)
 
 
 def criterion(loss_fn: str, pred: Tensor, true: Tensor):

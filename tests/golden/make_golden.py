@@ -73,7 +73,37 @@ def hscn_case(seed=1, B=4, K=8, H=16, L=3, C=10):
     np.savez_compressed(os.path.join(HERE, "hscn_peptides_b4.npz"), **out)
 
 
+def mpnn_case(seed=2, B=4, H=16, L=3, C=10):
+    """The GCN baseline of BASELINE config 1 (model/mpnn.py) in eval mode on a 4-graph Peptides batch."""
+    torch.manual_seed(seed)
+    graphs = make_dataset("peptides_func", B, seed=seed + 30)
+    ns = [g.num_nodes for g in graphs]
+    off = np.concatenate([[0], np.cumsum(ns)])
+    x = torch.cat([g.x for g in graphs]).float()
+    ei = torch.cat([g.edge_index + int(off[i]) for i, g in enumerate(graphs)], 1)
+    batch = torch.repeat_interleave(torch.arange(B), torch.as_tensor(ns))
+    y = torch.cat([g.y.view(1, -1) for g in graphs]).float()
+    m = OM.MPNN(OM.ACT["relu"], 9, H, C, L, dropout=0.2).eval()
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("bias"):
+                p.normal_(0, 0.1)
+    pred = m(x, ei, batch, B)
+    loss, _ = OM.criterion("cross_entropy", pred, y)
+    loss.backward()
+    out = dict(num_nodes=np.array(ns), x=x.numpy(), edge_index=ei.numpy(), batch=batch.numpy(), y=y.numpy(),
+               pred=pred.detach().numpy(), loss=loss.detach().numpy())
+    out.update(flat_state(m))
+    out.update({f"g::{k}": p.grad.numpy() for k, p in m.named_parameters()})
+    np.savez_compressed(os.path.join(HERE, "mpnn_gcn_peptides_b4.npz"), **out)
+
+
 if __name__ == "__main__":
-    scn_case()
-    hscn_case()
+    only = sys.argv[1:]                     # e.g. `make_golden.py mpnn` rewrites that file alone
+    if not only or "scn" in only:
+        scn_case()
+    if not only or "hscn" in only:
+        hscn_case()
+    if not only or "mpnn" in only:
+        mpnn_case()
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])

@@ -57,6 +57,35 @@ def test_oracle_reproduces_hscn_golden_and_transform():
     np.testing.assert_allclose(pred.detach().numpy(), z["pred"], atol=1e-6, rtol=1e-5)
 
 
+def test_oracle_reproduces_mpnn_golden():
+    z = _load("mpnn_gcn_peptides_b4.npz")
+    m = OM.MPNN(OM.ACT["relu"], 9, 16, 10, 3, dropout=0.2).eval()
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("w::")})
+    pred = m(torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"]), torch.from_numpy(z["batch"]), 4)
+    np.testing.assert_allclose(pred.detach().numpy(), z["pred"], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_mpnn_matches_golden():
+    from graph_hscn.config.config import ACT_DICT, CONV_DICT
+    from graph_hscn.data import Batch
+    from graph_hscn.loss import criterion
+    from graph_hscn.model.mpnn import MPNN
+    z = _load("mpnn_gcn_peptides_b4.npz")
+    b = Batch(x=torch.from_numpy(z["x"]), edge_index=torch.from_numpy(z["edge_index"]), y=torch.from_numpy(z["y"]))
+    b.batch, b.num_graphs = torch.from_numpy(z["batch"]), 4
+    b = b.to("cuda")
+    m = MPNN(CONV_DICT["gcn"], ACT_DICT["relu"], 9, 16, 10, 3, dropout=0.2).to("cuda").eval()
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("w::")})
+    pred = m(b)
+    loss, _ = criterion("cross_entropy", pred, b.y)
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), z["pred"], atol=1e-5, rtol=1e-5)
+    assert abs(loss.item() - float(z["loss"])) < 1e-6
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), z[f"g::{k}"], atol=1e-5, rtol=1e-3)
+
+
 @pytest.mark.gpu
 def test_hip_scn_matches_golden():
     from graph_hscn import _hip

@@ -163,3 +163,24 @@ def test_epoch_metrics_equal_sklearn():
     p[3, 3] = float("nan")
     with pytest.raises(Exception):
         eval_mae(t, p)
+
+
+def test_mpnn_config_and_factory():
+    """config/config.py:49-73 validation; model/mpnn.py:65-78 factory; parameter names of PyG's GCNConv."""
+    from graph_hscn.config.config import MPNNConfig
+    from graph_hscn.model.mpnn import MPNN, build_mpnn
+    from oracle import models as OM
+    cfg = MPNNConfig("GCN", "relu")
+    assert (cfg.hidden_channels, cfg.num_layers, cfg.dropout) == (16, 3, 0.2)
+    with pytest.raises(ValueError):
+        MPNNConfig("gcn", "relu", dropout=1.5)
+    with pytest.raises(ValueError):
+        MPNNConfig("gcn", "relu", num_layers=-1)
+    m = build_mpnn(cfg, 9, 10)
+    assert isinstance(m, MPNN) and len(m.conv_layers) == 3 and m.dropout == 0.2
+    assert sorted(m.state_dict()) == sorted(OM.MPNN(OM.ACT["relu"], 9, 16, 10, 3).state_dict())
+    assert [tuple(c.lin.weight.shape) for c in m.conv_layers] == [(16, 9), (16, 16), (10, 16)]
+    with pytest.raises(NotImplementedError):
+        build_mpnn(MPNNConfig("gcn", "relu", use_layer_norm=True), 9, 10)
+    with pytest.raises(KeyError):
+        build_mpnn(MPNNConfig("gin", "relu"), 9, 10)          # GINConv(dim, dim) is a TypeError in PyG
