@@ -400,7 +400,7 @@ def main():
             def a_step():
                 for p in scn.parameters():
                     p.grad = None
-                scn.forward_graphs(bigd, with_total=True)[3].backward()   # mc + o, as train_clustering does it
+                scn.forward_graphs(bigd, with_total=True)[3].backward(root_grad)   # mc + o, as train_clustering does it
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

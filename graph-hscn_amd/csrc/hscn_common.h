@@ -44,6 +44,22 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act) {
   }
 }
 
+// One element of the loss tail (reference graph_hscn/loss.py:6-19): kind 0 = BCE with logits
+// max(x,0) - x*y + log1p(exp(-|x|)), kind 1 = L1; l = loss term, sg = sigmoid(x) (the score of both
+// branches), g = d(mean loss)/dx with inv = 1/count.  Shared by k_criterion and the graph-resident
+// backward, which must agree bit for bit.
+__device__ __forceinline__ void criterion_elem(int kind, float x, float y, float inv, float& l, float& sg, float& g) {
+  sg = 1.0f / (1.0f + expf(-x));
+  if (kind == 0) {
+    l = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    g = (sg - y) * inv;
+  } else {
+    const float d = x - y;
+    l = fabsf(d);
+    g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv;
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

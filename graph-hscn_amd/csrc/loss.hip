@@ -27,17 +27,8 @@ __global__ void __launch_bounds__(1024) k_criterion(const float* __restrict__ pr
     for (int u = 0; u < 4; ++u) {
       const int64_t i = base + u * 1024 + threadIdx.x;
       if (i >= count) continue;
-      const float x = xs[u], y = ys[u];
-      const float sg = 1.0f / (1.0f + expf(-x));
-      float l, g;
-      if (kind == 0) {  // BCE with logits: max(x,0) - x*y + log1p(exp(-|x|))
-        l = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
-        g = (sg - y) * inv;
-      } else {          // L1
-        const float d = x - y;
-        l = fabsf(d);
-        g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv;
-      }
+      float l, sg, g;
+      criterion_elem(kind, xs[u], ys[u], inv, l, sg, g);
       s += l;
       if (score) score[i] = sg;
       grad[i] = g;

@@ -60,6 +60,7 @@ struct FwdArgs {
   LayerP layer[MAXL];
   const float *W1, *b1, *W2, *b2;
   float *acts, *pooled, *z, *pred, *xv_out;
+  float* score;  // optional [B][C]: sigmoid(pred), the score output of the loss tail (loss.py:9-10,17-19)
   int32_t *csr_rowptr_t, *csr_col_t;  // exported source-keyed ll CSR (graph g: rowptr at n0+g, col at e0)
   float* dinv_out;                     // exported in-degree^-1/2 of the ll relation
   int32_t* flag;
@@ -83,6 +84,12 @@ struct BwdArgs {
   const float *W1, *W2;
   const float *acts, *pooled, *z, *g_pred;
   const float* g_scale;  // optional device scalar: the upstream gradient is g_scale[0] * g_pred
+  // loss tail riding on this launch (target != NULL): the upstream gradient row is computed here from
+  // (pred, target) instead of being read from g_pred, and the graph's summed loss terms go to column
+  // `Pn` of its partials row (partials rows are then P = Pn + 1 wide)
+  const float *pred, *target;
+  int loss_kind, Pn;
+  float inv_count;
   const int32_t *csr_rowptr_t, *csr_col_t;  // from the forward launch
   const float* dinv_in;
   float* partials;  // [B][P]
@@ -983,7 +990,9 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         a2 = fmaf(z4.z, w4.z, a2);
         a2 = fmaf(z4.w, w4.w, a2);
       }
-      A.pred[(size_t)g * A.C + c] = a2 + b2l[c];
+      const float pc = a2 + b2l[c];
+      A.pred[(size_t)g * A.C + c] = pc;
+      if (A.score) A.score[(size_t)g * A.C + c] = 1.0f / (1.0f + expf(-pc));   // = criterion_elem's sg
     }
   }
   STAMP(63);
@@ -1022,7 +1031,7 @@ __host__ __device__ inline BwdLayout bwd_layout(int H, int C, int max_n, int max
   Y.red = take((size_t)(RT_MAX / 64) * 256);  // weight gradient: one 16 x 16 partial tile per wave
   Y.bred = take((size_t)(RT_MAX / 64) * H);    // bias gradient: one H-vector per wave
   Y.wl = take((size_t)H * H);
-  Y.headw = take((size_t)H * H + (size_t)C * H + C);  // W1 | W2 | g_pred row
+  Y.headw = take((size_t)H * H + (size_t)C * H + 2 * (size_t)C);  // W1 | W2 | g_pred row | loss terms
   Y.rowptr_t = take(max_n + 1);
   Y.col_t = take(max_ell);
   Y.total = o;
@@ -1071,14 +1080,19 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
   // stores below: source-keyed CSR + degree norm (exported by the forward launch), the last layer's
   // output, head weights, upstream gradient
   int cr[EPT], rr[RPT];
-  float yr[XPT], dr[RPT], hw0, hw1, zv, pv;
+  float yr[XPT], dr[RPT], hw0, hw1, ty0 = 0.f, ty1 = 0.f, zv, pv;
   const int HT = H * H + A.C * H + A.C;
   auto haddr = [&](int idx) -> const float* {
     if (idx < H * H) return A.W1 + idx;
     idx -= H * H;
     if (idx < A.C * H) return A.W2 + idx;
     idx -= A.C * H;
-    return A.g_pred + (size_t)g * A.C + (idx < A.C ? idx : 0);
+    return (A.target ? A.pred : A.g_pred) + (size_t)g * A.C + (idx < A.C ? idx : 0);
+  };
+  // with a loss tail the last C words are computed from (pred, target): the target word travels with its pred word
+  auto taddr = [&](int idx) -> const float* {
+    idx -= HT - A.C;
+    return A.target + (size_t)g * A.C + ((idx >= 0 && idx < A.C) ? idx : 0);
   };
   const int32_t* rpt = A.csr_rowptr_t + (size_t)n0 + g;
   const int32_t* cpt = A.csr_col_t + (size_t)e0;
@@ -1102,10 +1116,23 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
   const float gs = A.g_scale ? A.g_scale[0] : 1.f;
   const bool scaled = A.g_scale != nullptr;
   // (the last C words are the upstream gradient row: the loss node's scalar factor is applied here)
-  auto hval = [&](int idx, float v) { return (scaled && idx >= HT - A.C) ? gs * v : v; };
+  const bool tail = A.target != nullptr;
+  auto hval = [&](int idx, float v, float ty) {
+    if (idx < HT - A.C) return v;
+    if (tail) {   // v = pred, ty = target  ->  loss term (kept for the column sum) and d(mean loss)/dpred
+      float l, sg;
+      criterion_elem(A.loss_kind, v, ty, A.inv_count, l, sg, v);
+      headw[idx + A.C] = l;
+    }
+    return scaled ? gs * v : v;
+  };
   hw0 = *haddr((int)threadIdx.x < HT ? (int)threadIdx.x : 0);
   hw1 = *haddr((int)threadIdx.x + RT < HT ? (int)threadIdx.x + RT : 0);
-  for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = hval(idx, *haddr(idx));
+  if (tail) {
+    ty0 = *taddr((int)threadIdx.x < HT ? (int)threadIdx.x : 0);
+    ty1 = *taddr((int)threadIdx.x + RT < HT ? (int)threadIdx.x + RT : 0);
+  }
+  for (int idx = threadIdx.x + 2 * RT; idx < HT; idx += RT) headw[idx] = hval(idx, *haddr(idx), tail ? *taddr(idx) : 0.f);
   zv = A.z[(size_t)g * H + (threadIdx.x < H ? threadIdx.x : 0)];
   pv = A.pooled[(size_t)g * H + (threadIdx.x < H ? threadIdx.x : 0)];
   // ---- park in LDS ----------------------------------------------------------------------------
@@ -1130,8 +1157,8 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     if (idx < n * H) X[idx] = yr[i];
   }
   for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) X[idx] = yL[idx];
-  if ((int)threadIdx.x < HT) headw[threadIdx.x] = hval((int)threadIdx.x, hw0);
-  if ((int)threadIdx.x + RT < HT) headw[threadIdx.x + RT] = hval((int)threadIdx.x + RT, hw1);
+  if ((int)threadIdx.x < HT) headw[threadIdx.x] = hval((int)threadIdx.x, hw0, ty0);
+  if ((int)threadIdx.x + RT < HT) headw[threadIdx.x + RT] = hval((int)threadIdx.x + RT, hw1, ty1);
   if (threadIdx.x < H) {
     zz[threadIdx.x] = zv;
     pol[threadIdx.x] = pv;
@@ -1157,6 +1184,11 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
     part[oW2 + idx] = gpl[c] * zz[k];
   }
   for (int c = threadIdx.x; c < A.C; c += RT) part[ob2 + c] = gpl[c];
+  if (tail && threadIdx.x == RT - 64) {   // the graph's loss terms, summed in class order (a wave off the head's critical path)
+    float sl = 0.f;
+    for (int c = 0; c < A.C; ++c) sl += headw[HT + c];
+    part[A.Pn] = sl;
+  }
   for (int idx = threadIdx.x; idx < H * H; idx += RT) {
     const int o = idx / H, k = idx - o * H;
     part[oW1 + idx] = gz[o] * pol[k];
@@ -1547,6 +1579,7 @@ int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, cons
   }
   A.W1 = W1; A.b1 = b1; A.W2 = W2; A.b2 = b2;
   A.acts = acts; A.pooled = pooled; A.z = z; A.pred = pred; A.xv_out = xv_out; A.flag = flag;
+  A.score = nullptr;
   if ((csr_rowptr_t == nullptr) != (csr_col_t == nullptr) || (csr_rowptr_t == nullptr) != (dinv_out == nullptr))
     return HSCN_E_BADARG;
   A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_out = dinv_out;
@@ -1622,7 +1655,7 @@ int fill_bwd_args(BwdArgs& A, const float* x_local, const int64_t* ei_ll, int64_
                   const float* pooled, const float* z, const float* g_pred, const float* g_scale,
                   const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
                   float* partials, float* grads, int32_t* flag) {
-  if (!x_local || !lptr || !eptr_ll || !W_ll_host || !W1 || !W2 || !acts || !pooled || !z || !g_pred ||
+  if (!x_local || !lptr || !eptr_ll || !W_ll_host || !W1 || !W2 || !acts || !pooled || !z ||
       !partials || !grads || !csr_rowptr_t || !dinv || (E_ll > 0 && !csr_col_t))
     return HSCN_E_BADARG;
   A.x_local = x_local; A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
@@ -1635,6 +1668,17 @@ int fill_bwd_args(BwdArgs& A, const float* x_local, const int64_t* ei_ll, int64_
   A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_in = dinv;
   A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_ell = max_ell; A.P = (int)hscn_resident_param_count(F, H, L, C);
+  A.pred = nullptr; A.target = nullptr; A.loss_kind = 0; A.Pn = A.P; A.inv_count = 0.f;
+  return 0;
+}
+
+// upstream gradient: either given (g_pred) or computed by the launch from the loss tail
+int attach_tail(BwdArgs& A, const hscn_loss_tail* tail, int64_t B) {
+  if (!tail) return A.g_pred ? 0 : HSCN_E_BADARG;
+  if (!tail->pred || !tail->target || (tail->kind != 0 && tail->kind != 1)) return HSCN_E_BADARG;
+  A.pred = tail->pred; A.target = tail->target; A.loss_kind = tail->kind;
+  A.inv_count = 1.0f / (float)(B * (int64_t)A.C);   // k_criterion's 1 / count
+  A.P = A.Pn + 1;                                     // partials rows and grads carry the loss column
   return 0;
 }
 
@@ -1669,8 +1713,8 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
                       int head_act, float slope, const void* const* layer_params_host /* L x 9 */,
                       const float* W1, const float* b1, const float* W2, const float* b2, int max_n, int max_v,
                       int max_ell, int max_evv, int compute_virtual, float* acts, float* pooled, float* z,
-                      float* pred, float* xv_out, int32_t* csr_rowptr_t, int32_t* csr_col_t, float* dinv_out,
-                      int32_t* flag, void* stream_) {
+                      float* pred, float* score, float* xv_out, int32_t* csr_rowptr_t, int32_t* csr_col_t,
+                      float* dinv_out, int32_t* flag, void* stream_) {
   if (B < 0 || N < 0 || V < 0) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, max_v, max_ell, max_evv)) return HSCN_E_UNSUPPORTED;
@@ -1680,6 +1724,7 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
                              b2, max_n, max_v, max_ell, max_evv, compute_virtual, acts, pooled, z, pred, xv_out,
                              csr_rowptr_t, csr_col_t, dinv_out, flag))
     return rc;
+  A.score = score;
   hipStream_t st = hscn_stream(stream_);
   switch (H) {
     case 16: return launch_fwd<16>(A, B, st);
@@ -1694,7 +1739,8 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
                       const void* const* W_ll_host /* L */, const float* W1, const float* W2, const float* acts,
                       const float* pooled, const float* z, const float* g_pred, const float* g_scale,
                       const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv, int max_n,
-                      int max_ell, float* partials /*[B][P]*/, float* grads /*[P]*/, int32_t* flag, void* stream_) {
+                      int max_ell, float* partials /*[B][P]*/, float* grads /*[P]*/, int32_t* flag,
+                      const hscn_loss_tail* tail, void* stream_) {
   if (B < 0 || N < 0) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, 0, max_ell, 0)) return HSCN_E_UNSUPPORTED;
@@ -1703,6 +1749,7 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
                               acts, pooled, z, g_pred, g_scale, csr_rowptr_t, csr_col_t, dinv, max_n, max_ell,
                               partials, grads, flag))
     return rc0;
+  if (int rct = attach_tail(A, tail, B)) return rct;
   hipStream_t st = hscn_stream(stream_);
   int rc = HSCN_E_UNSUPPORTED;
   switch (H) {
@@ -1711,7 +1758,7 @@ int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, 
     case 64: rc = launch_bwd<64>(A, B, st); break;
   }
   if (rc) return rc;
-  k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P);
+  k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P, A.target ? A.Pn : -1, A.inv_count);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -1722,7 +1769,8 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const float* acts, const float* pooled, const float* z, const float* g_pred,
                                    const float* g_scale, const int32_t* csr_rowptr_t, const int32_t* csr_col_t,
                                    const float* dinv, int max_n, int max_ell, float* partials, float* grads,
-                                   int32_t* flag, const hscn_virtual_job* job, void* stream_) {
+                                   int32_t* flag, const hscn_loss_tail* tail, const hscn_virtual_job* job,
+                                   void* stream_) {
   if (B < 0 || N < 0 || !job) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!hscn_resident_supported(F, H, L, C, max_n, job->max_v, max_ell, job->max_evv)) return HSCN_E_UNSUPPORTED;
@@ -1731,6 +1779,7 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                               W2, acts, pooled, z, g_pred, g_scale, csr_rowptr_t, csr_col_t, dinv, max_n,
                               max_ell, partials, grads, flag))
     return rc0;
+  if (int rct = attach_tail(Ab, tail, B)) return rct;
   FwdArgs Af;
   if (int rc1 = fill_fwd_args(Af, x_local, job->x_virtual, nullptr, 0, job->ei_vv, job->E_vv, job->ei_lv,
                               job->E_lv, lptr, job->vptr, eptr_ll, job->eptr_vv, job->eptr_lv, N, job->V, F, H, L,
@@ -1751,7 +1800,7 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
     case 64: rc = launch_bwd_virtual<64>(Ab, Af, B, st); break;
   }
   if (rc) return rc;
-  k_param_reduce<<<hscn_blocks(Ab.P, 32), 256, 0, st>>>(partials, grads, (int)B, Ab.P);
+  k_param_reduce<<<hscn_blocks(Ab.P, 32), 256, 0, st>>>(partials, grads, (int)B, Ab.P, Ab.target ? Ab.Pn : -1, Ab.inv_count);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -1760,9 +1809,9 @@ int hscn_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
                                    int head_act, const void* const* layer_params_host, const float* W1,
                                    const float* b1, const float* W2, const float* b2, int max_n, int max_ell,
-                                   float* acts, float* pooled, float* z, float* pred, int32_t* csr_rowptr_t,
-                                   int32_t* csr_col_t, float* dinv_out, int32_t* flag, const hscn_virtual_job* job,
-                                   void* stream_) {
+                                   float* acts, float* pooled, float* z, float* pred, float* score,
+                                   int32_t* csr_rowptr_t, int32_t* csr_col_t, float* dinv_out, int32_t* flag,
+                                   const hscn_virtual_job* job, void* stream_) {
   if (B < 0 || N < 0 || !job) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (L < 2 || !job_has_state(job)) return HSCN_E_BADARG;
@@ -1774,6 +1823,7 @@ int hscn_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                               max_ell, job->max_evv, 0, acts, pooled, z, pred, nullptr, csr_rowptr_t, csr_col_t,
                               dinv_out, flag))
     return rc0;
+  Al.score = score;
   // virtual part 1: `acts` is not read by layer 0 (it takes the input features) but must be valid
   if (int rc1 = fill_fwd_args(Av, x_local, job->x_virtual, nullptr, 0, job->ei_vv, job->E_vv, job->ei_lv,
                               job->E_lv, lptr, job->vptr, eptr_ll, job->eptr_vv, job->eptr_lv, N, job->V, F, H, L,

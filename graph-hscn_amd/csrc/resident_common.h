@@ -245,8 +245,10 @@ __device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float
 
 // out[p] = sum_g partials[g][p]: a block owns 32 parameters x 8 contiguous graph slices (coalesced
 // over p), each slice summed in graph order, slices folded in slice order -> fixed summation tree
+// (column p_scaled, if any, is multiplied by `scale`: the loss column of a step whose loss tail rode
+// on the backward launch -- sum of the per-graph loss terms times 1/count)
 __global__ void __launch_bounds__(256) k_param_reduce(const float* __restrict__ partials, float* __restrict__ out,
-                                                      int B, int P) {
+                                                      int B, int P, int p_scaled, float scale) {
   __shared__ float red[8][32];
   const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int p = blockIdx.x * 32 + pl;
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(256) k_param_reduce(const float* __restrict__ 
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) t += red[q][pl];
-    out[p] = t;
+    out[p] = p == p_scaled ? t * scale : t;
   }
 }
 

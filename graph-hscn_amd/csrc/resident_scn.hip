@@ -862,7 +862,7 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
   hipStream_t st = hscn_stream(stream_);
   int rc = H == 16 ? launch_scn<16>(A, 1, st) : launch_scn<32>(A, 1, st);
   if (rc) return rc;
-  k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P);
+  k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P, -1, 0.f);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

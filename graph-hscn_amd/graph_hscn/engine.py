@@ -95,6 +95,11 @@ class _VirtualJob(ctypes.Structure):
                 ("st_dinv_v", ctypes.c_void_p), ("st_xv", ctypes.c_void_p)]
 
 
+class _LossTail(ctypes.Structure):
+    """include/hscn.h: hscn_loss_tail."""
+    _fields_ = [("pred", ctypes.c_void_p), ("target", ctypes.c_void_p), ("kind", ctypes.c_int32)]
+
+
 # final virtual features of the last step whose virtual branch rode on the backward launch (tests)
 last_deferred_virtual: Optional[Tensor] = None
 
@@ -144,6 +149,8 @@ class HSCNResidentFn(Function):
         pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
         z = torch.empty(B, H, dtype=torch.float32, device=dev)
         pred = torch.empty(B, C, dtype=torch.float32, device=dev)
+        # sigmoid(pred) costs the head ten more stores; with it the loss tail can ride on the backward launch
+        score = torch.empty(B, C, dtype=torch.float32, device=dev) if need_bwd else None
         xv_out = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev) if (compute_virtual and keep_virtual) else None
         # source-keyed CSR + degree norm: built in LDS by the forward launch, reused by the backward launch
         E_ll = ei_ll.size(1)
@@ -162,8 +169,8 @@ class HSCNResidentFn(Function):
                               meta.max_evv, float(slope), *[ptr(t) for t in state])
             call("hscn_resident_fwd_with_virtual", ptr(x_local), ptr(ei_ll), E_ll, ptr(meta.lptr), ptr(meta.eptr_ll),
                  N, B, F, H, L, C, head_act, table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_ell,
-                 ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(meta.flag),
-                 ctypes.byref(job), stream())
+                 ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(score), ptr(csr_rp), ptr(csr_col), ptr(dinv),
+                 ptr(meta.flag), ctypes.byref(job), stream())
             # what the backward launch needs to run the rest of the virtual branch beside itself
             ctx.virtual = (x_virtual, ei_vv, ei_lv, params[: 9 * L], table, float(slope), state)
         else:
@@ -171,17 +178,15 @@ class HSCNResidentFn(Function):
                  ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll),
                  ptr(meta.eptr_vv), ptr(meta.eptr_lv), N, V, B, F, H, L, C, head_act, float(slope), table,
                  ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_v, meta.max_ell, meta.max_evv,
-                 int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(xv_out), ptr(csr_rp),
-                 ptr(csr_col), ptr(dinv), ptr(meta.flag), stream())
+                 int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(score), ptr(xv_out),
+                 ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(meta.flag), stream())
         ctx.meta, ctx.head_act, ctx.dims = meta, head_act, (N, F, H, L, C, B)
         ctx.csr = (csr_rp, csr_col, dinv)
         ctx.save_for_backward(x_local, ei_ll, acts, pooled, z, W1, W2, *[params[9 * l] for l in range(L)])
         ret_xv = xv_out if keep_virtual else None
-        ctx.mark_non_differentiable(*([ret_xv] if ret_xv is not None else []))
+        ctx.mark_non_differentiable(*[t for t in (ret_xv, score) if t is not None])
         ctx.set_materialize_grads(False)
-        if ret_xv is None:
-            return pred
-        return pred, ret_xv
+        return pred, ret_xv, score
 
     @staticmethod
     def backward(ctx, g_pred, *_):
@@ -192,19 +197,29 @@ class HSCNResidentFn(Function):
         N, F, H, L, C, B = ctx.dims
         dev = x_local.device
         P = int(_hip.lib().hscn_resident_param_count(F, H, L, C))
-        partials = torch.empty(B, P, dtype=torch.float32, device=dev)
-        grads = torch.empty(P, dtype=torch.float32, device=dev)
-        # the loss node hands its gradient over as (unscaled, scalar): the launch applies the scalar
-        from .loss import LazyScaled
-        g_scale = None
-        if isinstance(g_pred, LazyScaled):
+        # the loss node hands its gradient over unevaluated: either (unscaled gradient, scalar) -- the launch
+        # applies the scalar -- or (pred, target, kind, scalar) -- the launch evaluates the loss tail itself
+        # and returns the loss value as one more reduced column
+        from .loss import LazyCriterionGrad, LazyScaled
+        g_scale, tail, tail_ref = None, None, None
+        if isinstance(g_pred, LazyCriterionGrad) and g_pred.pred.shape == (B, C):
+            tail_ref = g_pred
+            tail = _LossTail(ptr(g_pred.pred), ptr(g_pred.target), int(g_pred.kind))
+            g_scale, g_pred = g_pred.scale, None
+        elif isinstance(g_pred, LazyScaled):
             g_pred, g_scale = g_pred.grad_unscaled, g_pred.scale
-        g_pred = g_pred.contiguous()
+        if g_pred is not None:
+            g_pred = g_pred.contiguous()
+        Pw = P + (1 if tail is not None else 0)
+        partials = torch.empty(B, Pw, dtype=torch.float32, device=dev)
+        grads = torch.empty(Pw, dtype=torch.float32, device=dev)
         table = _ptr_table(list(W_ll))
         args = (ptr(x_local), ptr(ei_ll), ei_ll.size(1), ptr(meta.lptr), ptr(meta.eptr_ll), N, B,
                 F, H, L, C, ctx.head_act, table, ptr(W1), ptr(W2), ptr(acts), ptr(pooled), ptr(z), ptr(g_pred),
                 ptr(g_scale), ptr(ctx.csr[0]), ptr(ctx.csr[1]), ptr(ctx.csr[2]), meta.max_n, meta.max_ell, ptr(partials),
-                ptr(grads), ptr(meta.flag))
+                ptr(grads), ptr(meta.flag), ctypes.byref(tail) if tail is not None else None)
+        if tail_ref is not None:
+            tail_ref.state.fill(grads[P:P + 1].view(()))      # the loss value, once this launch has run
         if ctx.virtual is not None:
             global last_deferred_virtual
             x_virtual, ei_vv, ei_lv, _keep, vtable, slope, state = ctx.virtual

@@ -1,7 +1,9 @@
 """Loss selection of the training loop (reference graph_hscn/loss.py:6-19).
 
 On the device the multilabel BCE-with-logits and L1 branches are one fused HIP
-launch (loss + sigmoid score + dL/dpred, csrc/loss.hip); the multiclass branch
+launch (loss + sigmoid score + dL/dpred, csrc/loss.hip) -- or none at all: a prediction
+of the graph-resident HSCN forward arrives with its score, and the loss and its gradient
+are evaluated inside the backward launch of the same step (``LazyLoss``); the multiclass branch
 (``true.ndim == 1``) and CPU tensors use the plain torch ops the reference
 uses.  Quirk kept: the L1 branch scores with ``sigmoid(pred)`` (loss.py:17-19)."""
 import torch
@@ -43,20 +45,138 @@ class LazyScaled(torch.Tensor):
         return f"LazyScaled(shape={tuple(self.shape)})"
 
 
+def _run_criterion(pred, true, kind, want_score=True):
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    score = torch.empty_like(pred) if want_score else None
+    grad = torch.empty_like(pred)
+    call("hscn_criterion_fwd", ptr(pred), ptr(true), pred.numel(), kind, ptr(loss), ptr(score), ptr(grad), stream())
+    return loss.view(()), score, grad
+
+
+class _LossState:
+    """A loss whose evaluation was left to the backward launch of the graph-resident HSCN step
+    (include/hscn.h: hscn_loss_tail).  ``value`` appears when that launch has been issued (``fill``); a
+    read before that -- ``loss.item()`` ahead of ``backward()``, or no backward at all -- evaluates the
+    loss with a launch of its own and keeps its gradient for the backward."""
+    __slots__ = ("pred", "target", "kind", "value", "grad")
+
+    def __init__(self, pred, target, kind):
+        self.pred, self.target, self.kind = pred, target, kind
+        self.value = self.grad = None
+
+    def fill(self, value):
+        self.value = value
+
+    def get(self):
+        if self.value is None:
+            self.value, _, self.grad = _run_criterion(self.pred, self.target, self.kind, want_score=False)
+        return self.value
+
+
+_ONES = {}
+
+
+def root_grad(device):
+    """Cached scalar 1 on ``device``: ``loss.backward(root_grad(dev))`` spares the fill launch of the
+    implicit ``ones_like(loss)`` (4.5 us per step on a 50 us step)."""
+    return _one(torch.device(device))
+
+
+def _one(device):
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+class LazyLoss(torch.Tensor):
+    """0-dim loss backed by a ``_LossState``: any use as a value dispatches through ``state.get()``;
+    ``detach`` / ``alias`` stay lazy (a training loop may collect ``loss.detach()`` before ``backward()``),
+    and ``ones_like`` -- the implicit root gradient of ``loss.backward()`` -- does not need the value."""
+
+    @staticmethod
+    def __new__(cls, state, device):
+        r = torch.Tensor._make_wrapper_subclass(cls, (), dtype=torch.float32, device=device, requires_grad=False)
+        r.state = state
+        return r
+
+    def materialize(self) -> torch.Tensor:
+        return self.state.get()
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        if func in (torch.ops.aten.detach.default, torch.ops.aten.alias.default):
+            return LazyLoss(args[0].state, args[0].device)
+        if func is torch.ops.aten.ones_like.default:
+            return _one(args[0].device)
+        un = lambda t: t.state.get() if isinstance(t, LazyLoss) else t
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+    def __repr__(self):
+        return f"LazyLoss({'pending' if self.state.value is None else float(self.state.value)})"
+
+
+class LazyCriterionGrad(torch.Tensor):
+    """``scale[0] * d criterion(pred, target) / d pred`` not yet evaluated: the graph-resident HSCN backward
+    takes (pred, target, kind, scale) and evaluates it inside its launch; anything else gets the dense
+    tensor through ``materialize``."""
+
+    @staticmethod
+    def __new__(cls, pred, target, kind, scale, state):
+        r = torch.Tensor._make_wrapper_subclass(cls, pred.shape, dtype=pred.dtype, device=pred.device,
+                                                requires_grad=False)
+        r.pred, r.target, r.kind, r.scale, r.state = pred, target, kind, scale, state
+        r._dense = None
+        return r
+
+    def materialize(self) -> torch.Tensor:
+        if self._dense is None:
+            self.state.get()
+            out = torch.empty_like(self.state.grad)
+            call("hscn_scale", ptr(self.scale), ptr(self.state.grad), ptr(out), out.numel(), stream())
+            self._dense = out
+        return self._dense
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        un = lambda t: t.materialize() if isinstance(t, LazyCriterionGrad) else t
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+    def __repr__(self):
+        return f"LazyCriterionGrad(shape={tuple(self.shape)})"
+
+
+class _TailCriterionFn(Function):
+    """criterion on a prediction of the graph-resident HSCN forward (which already wrote the score):
+    no launch here; the backward launch of the step evaluates the loss tail (csrc/resident.hip)."""
+
+    @staticmethod
+    def forward(ctx, pred, true, kind):
+        ctx.state = _LossState(pred, true, kind)
+        ctx.set_materialize_grads(False)
+        return LazyLoss(ctx.state, pred.device)
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        if g_loss is None:
+            return None, None, None
+        st = ctx.state
+        scale = g_loss.reshape(1).contiguous()
+        if st.grad is not None:                  # the loss was read before the backward: its gradient exists
+            return LazyScaled(st.grad, scale), None, None
+        return LazyCriterionGrad(st.pred, st.target, st.kind, scale, st), None, None
+
+
 class _CriterionFn(Function):
     @staticmethod
     def forward(ctx, pred, true, kind):
-        pred = pred.contiguous()
-        true = true.contiguous()
-        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-        score = torch.empty_like(pred)
-        grad = torch.empty_like(pred)
-        call("hscn_criterion_fwd", ptr(pred), ptr(true), pred.numel(), kind, ptr(loss), ptr(score), ptr(grad),
-             stream())
+        loss, score, grad = _run_criterion(pred.contiguous(), true.contiguous(), kind)
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(score)
         ctx.set_materialize_grads(False)  # no zero tensor (a fill launch) for the score output
-        return loss.view(()), score
+        return loss, score
 
     @staticmethod
     def backward(ctx, g_loss, _g_score):
@@ -69,7 +189,14 @@ class _CriterionFn(Function):
 def criterion(loss_fn: str, pred: torch.Tensor, true: torch.Tensor):
     multiclass = loss_fn == "cross_entropy" and pred.ndim > 1 and true.ndim == 1
     if pred.is_cuda and not multiclass and pred.dtype == torch.float32 and pred.shape == true.shape:
-        return _CriterionFn.apply(pred, true.float(), 0 if loss_fn == "cross_entropy" else 1)
+        kind = 0 if loss_fn == "cross_entropy" else 1
+        true = true.float()
+        score = getattr(pred, "_hscn_score", None)
+        if (score is not None and pred.requires_grad and torch.is_grad_enabled() and pred.dim() == 2
+                and true.is_contiguous() and pred.is_contiguous() and true.device == pred.device):
+            _one(pred.device)          # the root gradient of loss.backward(), created outside any capture
+            return _TailCriterionFn.apply(pred, true, kind), score
+        return _CriterionFn.apply(pred, true, kind)
     if loss_fn == "cross_entropy":
         if multiclass:
             pred = F.log_softmax(pred, dim=-1)

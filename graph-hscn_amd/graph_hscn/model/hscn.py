@@ -214,8 +214,13 @@ class HSCN(nn.Module):
         cfg = (_engine.ACT[act_name], slope, self.compute_virtual, self.keep_virtual, self.overlap_virtual)
         out = _engine.HSCNResidentFn.apply(x_dict["local"], x_dict["virtual"], edge_index_dict[LL],
                                            edge_index_dict[VV], edge_index_dict[LV], meta, cfg, *params)
-        if isinstance(out, tuple):
-            out, self.last_virtual = out
+        out, xv, score = out
+        if xv is not None:
+            self.last_virtual = xv
+        if score is not None:
+            # loss.criterion recognises a prediction that comes with its score and lets the loss tail ride on
+            # the backward launch (no launch of its own)
+            out._hscn_score = score
         return out
 
     def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[Tuple[str, str, str], Tensor],

@@ -20,6 +20,7 @@ import torch
 from .. import _hip
 from ..config.config import OPTIM_DICT
 from ..data import Batch
+from ..loss import root_grad
 from ..model.hscn import SCN
 from ..nn.pool import gcn_norm
 
@@ -65,7 +66,7 @@ def train_clustering(logger, dataset, model: SCN, model_cfg, optim_cfg, training
             # train_clustering.py:48  loss = mc_loss + o_loss (the fused launch already holds the sum;
             # on the layered path the 4th slot is the dense adjacency placeholder, not a loss)
             loss = total if model.last_engine == "resident" and total is not None else mc_loss + o_loss
-            loss.backward()
+            loss.backward(root_grad(loss.device))      # no ones_like fill launch
             optimizer.step()
     cluster_all_lst: List[np.ndarray] = []
     if logger is not None:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 2
+#define HSCN_ABI_VERSION 3
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -305,10 +305,22 @@ int hscn_scale(const float* g /*[1]*/, const float* x, float* y, int64_t count, 
  *     max_n / max_v / max_ell / max_evv (the LDS budget the launch was sized for)
  *   g_scale: optional device scalar; the upstream gradient is g_scale[0] * g_pred (the factor
  *     the loss node would otherwise apply with a launch of its own, hscn_scale); NULL = 1
+ *   score (forward, optional [B,C]): sigmoid(pred), the score loss.py:9-10,17-19 returns beside the loss
+ *   tail (backward, optional): the loss tail of the step (loss.py:6-19 on this prediction, mean over
+ *     B*C elements) rides on the backward launch: workgroup g derives its upstream gradient row
+ *     g_scale[0] * d(mean loss)/dpred[g,:] from (tail->pred, tail->target) itself -- g_pred is ignored
+ *     and may be NULL -- and adds the graph's loss terms as one more column of its partials row;
+ *     `partials` is then [B, P+1], `grads` [P+1], and grads[P] receives the mean loss.  Same
+ *     per-element arithmetic as hscn_criterion_fwd (gradients bit-identical to the three-call route).
  * hscn_resident_bwd returns dL/d{W_ll, b_ll per layer, W1, b1, W2, b2} packed in
  * that order in grads[P] (P = hscn_resident_param_count); the virtual-branch
  * parameters receive no gradient, exactly as in the reference's autograd graph.
  * ------------------------------------------------------------------------- */
+typedef struct hscn_loss_tail {
+  const float* pred;    /* [B,C] what the forward launch of this step wrote */
+  const float* target;  /* [B,C] float32 */
+  int32_t kind;         /* 0 = BCE with logits, 1 = L1 (both mean-reduced) */
+} hscn_loss_tail;
 int hscn_resident_supported(int F, int H, int L, int C, int max_n, int max_v, int max_ell, int max_evv);
 int64_t hscn_resident_param_count(int F, int H, int L, int C);
 int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_t* ei_ll, int64_t E_ll,
@@ -318,14 +330,15 @@ int hscn_resident_fwd(const float* x_local, const float* x_virtual, const int64_
                       int head_act, float slope, const void* const* layer_params_host,
                       const float* W1, const float* b1, const float* W2, const float* b2, int max_n, int max_v,
                       int max_ell, int max_evv, int compute_virtual, float* acts, float* pooled, float* z,
-                      float* pred, float* xv_out, int32_t* csr_rowptr_t /*[N+B]*/, int32_t* csr_col_t /*[E_ll]*/,
-                      float* dinv /*[N]*/, int32_t* flag, void* stream);
+                      float* pred, float* score /*[B,C] or NULL*/, float* xv_out, int32_t* csr_rowptr_t /*[N+B]*/,
+                      int32_t* csr_col_t /*[E_ll]*/, float* dinv /*[N]*/, int32_t* flag, void* stream);
 int hscn_resident_bwd(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                       const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
                       const void* const* W_ll_host, const float* W1, const float* W2, const float* acts,
                       const float* pooled, const float* z, const float* g_pred, const float* g_scale /*[1] or NULL*/,
                       const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv, int max_n,
-                      int max_ell, float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+                      int max_ell, float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag,
+                      const hscn_loss_tail* tail /*or NULL*/, void* stream);
 
 /* hscn_resident_bwd that also carries the virtual branch of the SAME step's forward: one launch
  * of 2B workgroups, even ones run the backward of graph g, odd ones what a compute_virtual = 2
@@ -364,9 +377,9 @@ int hscn_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
                                    int head_act, const void* const* layer_params_host, const float* W1,
                                    const float* b1, const float* W2, const float* b2, int max_n, int max_ell,
-                                   float* acts, float* pooled, float* z, float* pred, int32_t* csr_rowptr_t,
-                                   int32_t* csr_col_t, float* dinv, int32_t* flag, const hscn_virtual_job* job,
-                                   void* stream);
+                                   float* acts, float* pooled, float* z, float* pred, float* score /*or NULL*/,
+                                   int32_t* csr_rowptr_t, int32_t* csr_col_t, float* dinv, int32_t* flag,
+                                   const hscn_virtual_job* job, void* stream);
 int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                                    const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
                                    int head_act, const void* const* W_ll_host, const float* W1, const float* W2,
@@ -374,7 +387,7 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const float* g_scale /*[1] or NULL*/, const int32_t* csr_rowptr_t,
                                    const int32_t* csr_col_t, const float* dinv, int max_n, int max_ell,
                                    float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag,
-                                   const hscn_virtual_job* job, void* stream);
+                                   const hscn_loss_tail* tail /*or NULL*/, const hscn_virtual_job* job, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * a2/a4/a6  stage A, graph-resident engine: the body of the reference's clustering loop

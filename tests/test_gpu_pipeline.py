@@ -48,7 +48,7 @@ def test_loss_gradient_scalar_is_applied_by_whoever_consumes_it():
     from graph_hscn.data import HeteroBatch
     from graph_hscn.loader.hetero_data import hetero_from_clusters
     from graph_hscn.loader.synthetic import make_dataset
-    from graph_hscn.loss import LazyScaled, criterion
+    from graph_hscn.loss import LazyCriterionGrad, LazyScaled, criterion
     from graph_hscn.model.hscn import HSCN
     dev = torch.device("cuda:0")
     graphs = make_dataset("peptides_func", 6, seed=1)
@@ -70,7 +70,8 @@ def test_loss_gradient_scalar_is_applied_by_whoever_consumes_it():
                 loss.backward()
             else:
                 loss.backward(torch.tensor(root, device=dev))
-            assert seen and seen[0] is LazyScaled
+            # (the resident engine's prediction comes with its score: there the whole loss tail is handed over)
+            assert seen and seen[0] is (LazyCriterionGrad if eng == "resident" else LazyScaled)
             res[(eng, root)] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     # reference: plain torch loss on the layered engine
     for root in (None, 0.37):
