@@ -10,7 +10,7 @@ from tests.helpers import DEV, close, hetero_batch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(B=12, K=8, C=10, seed=3, name="peptides_func"):
+def _setup(B=12, K=8, C=10, seed=3, name="peptides_func", H=16):
     from graph_hscn.config.config import ACT_DICT
     from graph_hscn.data import HeteroBatch
     from graph_hscn.loader.hetero_data import hetero_from_clusters
@@ -21,7 +21,7 @@ def _setup(B=12, K=8, C=10, seed=3, name="peptides_func"):
     hb = HeteroBatch.from_data_list([hetero_from_clusters(g, rng.integers(0, K, g.num_nodes), K) for g in graphs])
     from graph_hscn.model.hscn import HSCN
     torch.manual_seed(seed)
-    m = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], hb["local"].x.size(1), 16, C, 3).to(DEV)
+    m = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], hb["local"].x.size(1), H, C, 3).to(DEV)
     m.engine = "resident"
     d = hb.to(DEV)
     y = (torch.rand(B, C, generator=torch.Generator().manual_seed(seed)) < 0.3).float().to(DEV)
@@ -50,9 +50,12 @@ def _step(m, d, y, loss_fn, tail, read_first=False, scale=None):
     return float(held), early, score.clone(), pred.detach().clone(), _grads(m)
 
 
-@pytest.mark.parametrize("loss_fn", ["cross_entropy", "l1"])
-def test_tail_route_equals_three_call_route(loss_fn):
-    m, d, y, _ = _setup()
+@pytest.mark.parametrize("loss_fn,H,C", [("cross_entropy", 16, 10), ("l1", 16, 10), ("cross_entropy", 32, 100),
+                                         ("l1", 64, 3)])
+def test_tail_route_equals_three_call_route(loss_fn, H, C):
+    """(H = 32, C = 100: the head block is larger than two passes of the workgroup, the loss row is parked by
+    the strided tail of the loader)"""
+    m, d, y, _ = _setup(H=H, C=C, B=5 if H == 64 else 12, name="pcqm_contact" if H == 64 else "peptides_func")
     l0, _, s0, p0, g0 = _step(m, d, y, loss_fn, tail=False)
     l1, _, s1, p1, g1 = _step(m, d, y, loss_fn, tail=True)
     assert torch.equal(p0, p1) and torch.equal(s0, s1)            # the forward launch wrote the same score
@@ -71,7 +74,7 @@ def test_tail_route_matches_oracle():
     lo, so = OM.criterion("cross_entropy", out, y.cpu())
     lo.backward()
     l1, _, s1, p1, g1 = _step(m, d, y, "cross_entropy", tail=True)
-    assert abs(l1 - float(lo)) < 1e-6 and close(s1, so) and close(p1, out)
+    assert abs(l1 - float(lo.detach())) < 1e-6 and close(s1, so) and close(p1, out)
     for (n_, po), g in zip(om.named_parameters(), g1):
         if po.grad is None:
             assert g is None, n_
