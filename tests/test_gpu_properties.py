@@ -169,3 +169,34 @@ def test_spmm_linearity_and_checksum_at_the_streaming_shape():
     # every fp32 output carries <= a few ulp of rounding; over N rows of mixed sign that adds up like a random walk
     bound = 8.0 * (N ** 0.5) * 2.0 ** -24 * float(sx.double().pow(2).mean().sqrt())
     assert float((got - want).abs().max()) < bound
+
+
+def test_stage_b_on_the_device_at_full_size(full):
+    """generate_hetero_data's transform for the whole 128-graph batch on the device: identical to the host
+    transform graph by graph, and structurally what loader/hetero_data.py:42-87 defines -- one virtual node
+    per cluster id in use, every local node tied to exactly one of its own graph's virtual nodes, U(U+1)/2
+    virtual-virtual pairs."""
+    from graph_hscn.data import Batch, HeteroBatch
+    from graph_hscn.loader.hetero_data import LL, LV, VV, hetero_batch_on_device
+    _, hs, graphs, ids, ptr = full
+    host = HeteroBatch.from_data_list(hs)
+    dev = hetero_batch_on_device(Batch.from_data_list(graphs).to(DEV), torch.from_numpy(ids).to(DEV), K)
+    for nt in ("local", "virtual"):
+        assert torch.equal(dev[nt].x.cpu(), host[nt].x) and torch.equal(dev[nt].ptr32.cpu(), host[nt].ptr32)
+        assert torch.equal(dev[nt].batch.cpu(), host[nt].batch)
+    for et in (LL, VV, LV):
+        assert torch.equal(dev[et].edge_index.cpu(), host[et].edge_index) and torch.equal(dev[et].ptr32.cpu(), host[et].ptr32)
+    vptr = dev["virtual"].ptr32.cpu().numpy()
+    U = np.array([len(np.unique(ids[ptr[g]:ptr[g + 1]])) for g in range(B)])
+    assert np.array_equal(np.diff(vptr), U)
+    lv = dev[LV].edge_index.cpu().numpy()
+    assert np.array_equal(lv[0], np.arange(ptr[-1]))
+    g_of_node = np.repeat(np.arange(B), np.diff(ptr))
+    assert np.all(lv[1] >= vptr[g_of_node]) and np.all(lv[1] < vptr[g_of_node + 1])
+    assert np.array_equal(np.diff(dev[VV].ptr32.cpu().numpy()), U * (U + 1) // 2)
+    # nodes that share a cluster id share a virtual node, and only they do
+    for g in (0, 31, 127):
+        sl = slice(ptr[g], ptr[g + 1])
+        same_id = ids[sl][:, None] == ids[sl][None, :]
+        same_v = lv[1][sl][:, None] == lv[1][sl][None, :]
+        assert np.array_equal(same_id, same_v)
