@@ -248,6 +248,83 @@ __device__ void lin_mfma(const float* X, const float* Wt, float* Y, int n, const
   }
 }
 
+// ---- one GCN layer in one phase: Y = relu((A_hat X) Wt + b) ------------------------------------------
+// A wave owns 16-row tiles.  Lane (li = row in the tile, lj = quarter of the input features) gathers its
+// quarter of row li of A_hat X straight into the A-operand registers of v_mfma_f32_16x16x4_f32 (k runs
+// over the lane's own contiguous features: the weights are fetched in the matching order), the product with
+// Wt comes off the matrix cores, bias + ReLU ride in the epilogue.  The n x H intermediate X Wt and the
+// workgroup barrier between "transform" and "gather-reduce" do not exist: a layer is one barrier.
+// (A_hat X) Wt instead of the reference's A_hat (X Wt): same value, rounded in another order.
+template <int H>
+__device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, const float* X, const float* Wt,
+                          const float* bias, float* Y, float* __restrict__ gout, int n, const Grp& G) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int TD = H / 16, KS = H / 4;
+  const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int ntile = (n + 15) >> 4;
+  if (G.w >= ntile) return;
+  float b[TD][KS], bia[TD];
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct) {
+    bia[ct] = bias[ct * 16 + li];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[ct][s] = Wt[(KS * lj + s) * H + ct * 16 + li];
+  }
+  for (int rt = G.w; rt < ntile; rt += G.nw) {
+    const int r0 = rt * 16, i = r0 + li;
+    float z[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) z[s] = 0.f;
+    if (i < n) {
+      const int s0 = rowptr[i], t0 = rowptr[i + 1];
+      const float di = dinv[i];
+      const float* xq = X + KS * lj;
+      // four neighbours per trip (molecule-like graphs: one trip per row), clamped slots with weight 0 past the
+      // row's end: index, norm and row reads of a trip are independent, a row costs three LDS round trips
+      for (int p = s0; p < t0; p += 4) {
+        int j[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = col[p + u < t0 ? p + u : t0 - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = p + u < t0 ? dinv[j[u]] * di : 0.f;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xq + j[u] * H + 4 * q);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            z[4 * q + 0] = fmaf(w[u], v[u].x, z[4 * q + 0]);
+            z[4 * q + 1] = fmaf(w[u], v[u].y, z[4 * q + 1]);
+            z[4 * q + 2] = fmaf(w[u], v[u].z, z[4 * q + 2]);
+            z[4 * q + 3] = fmaf(w[u], v[u].w, z[4 * q + 3]);
+          }
+        }
+      }
+    }
+    f32x4 acc[TD];
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int ct = 0; ct < TD; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[s], b[ct][s], acc[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + lj * 4 + r;
+        if (row < n) {
+          const int idx = row * H + ct * 16 + li;
+          const float v = fmaxf(acc[ct][r] + bia[ct], 0.f);
+          Y[idx] = v;
+          if (gout) gout[(size_t)idx] = v;
+        }
+      }
+  }
+}
+
 template <int H>
 struct Blk {  // outputs per lane in lin_blk: W columns (OPT*H floats) must stay in registers at 16 waves/CU
   static constexpr int OPT = H <= 16 ? 2 : 1;
@@ -703,6 +780,11 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     auto reduce_ll = [&](const Grp& G_) {
       agg_gcn_lds<H>(rowptr, col, dinv, dinv, bh, b_ll, xa, n, 1, A.acts + ((size_t)l * A.N + n0) * H, G_);
     };
+    // H <= 32: the whole local layer in one phase, xa -> bh (the two buffers swap roles after the layer)
+    constexpr bool FUSE = H <= 32;
+    auto layer_ll = [&](const Grp& G_) {
+      gcn_fused<H>(rowptr, col, dinv, xa, W, b_ll, bh, A.acts + ((size_t)l * A.N + n0) * H, n, G_);
+    };
     // lv segment softmax + weighted sum, one wave per 64-member chunk of a cluster (clusters are as
     // unbalanced as the assignment makes them: one wave per cluster would serialise the big one).
     // Every chunk wave recomputes the cluster's max / denominator (a few LDS reads), reduces its own
@@ -869,16 +951,16 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         STAMP_T(43 + 4 * l, 0);              // group A done with its phase-2 work
         lds_barrier();
       } else {
-        transforms_ll(GA);
+        if (FUSE) layer_ll(GA); else transforms_ll(GA);
         STAMP_T(41 + 4 * l, 0);
         if (more && DB) ws.store(Wn);
         lds_barrier();
         STAMP(5 + 4 * l);
-        reduce_ll(GA);
+        if (!FUSE) reduce_ll(GA);
         STAMP_T(43 + 4 * l, 0);
         lds_barrier();
       }
-      if (vonly && more) { float* t_ = xa; xa = bh; bh = t_; }
+      if ((vonly && more) || (FUSE && !vonly)) { float* t_ = xa; xa = bh; bh = t_; }
     } else {
       // one n x H transform buffer: the virtual branch first, then the ll path
       if (cv) {
@@ -887,15 +969,20 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         reduce_virtual(ALL);
         lds_barrier();
       }
-      if (!vonly) transforms_ll(ALL);
+      if (!vonly) { if (FUSE) layer_ll(ALL); else transforms_ll(ALL); }
       STAMP_T(41 + 4 * l, 0);
       if (more && DB) ws.store(Wn);
       STAMP_T(40 + 4 * l, 0);
       lds_barrier();
       STAMP(5 + 4 * l);
-      if (vonly) load_next_local(ALL, xa); else reduce_ll(ALL);
-      STAMP_T(43 + 4 * l, 0);
-      lds_barrier();
+      if (vonly || !FUSE) {
+        if (vonly) load_next_local(ALL, xa); else reduce_ll(ALL);
+        STAMP_T(43 + 4 * l, 0);
+        lds_barrier();
+      } else {   // fused local layer: its output sits in bh; in this mode bs shares that buffer and follows it
+        float* t_ = xa; xa = bh; bh = t_;
+        bs = bh;
+      }
     }
     if (more && !DB) {  // single weight buffer: everybody is done with it now
       ws.fetch(A.layer[l + 1], !vonly, cv, H);
