@@ -192,6 +192,8 @@ def criterion(loss_fn: str, pred: torch.Tensor, true: torch.Tensor):
         kind = 0 if loss_fn == "cross_entropy" else 1
         true = true.float()
         score = getattr(pred, "_hscn_score", None)
+        if score is not None:                                   # (score, version of pred it belongs to)
+            score = score[0] if score[1] == pred._version else None
         if (score is not None and pred.requires_grad and torch.is_grad_enabled() and pred.dim() == 2
                 and true.is_contiguous() and pred.is_contiguous() and true.device == pred.device):
             _one(pred.device)          # the root gradient of loss.backward(), created outside any capture

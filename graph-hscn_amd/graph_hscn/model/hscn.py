@@ -220,7 +220,7 @@ class HSCN(nn.Module):
         if score is not None:
             # loss.criterion recognises a prediction that comes with its score and lets the loss tail ride on
             # the backward launch (no launch of its own)
-            out._hscn_score = score
+            out._hscn_score = (score, out._version)
         return out
 
     def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[Tuple[str, str, str], Tensor],

@@ -117,3 +117,16 @@ def test_gradient_accumulation_over_two_batches_and_eval():
     with torch.no_grad():                                            # no backward to ride on: the plain route
         loss, score = criterion("cross_entropy", m(d.x_dict, d.edge_index_dict, d), y)
     assert not isinstance(loss, LazyLoss) and abs(float(loss) - la) < 1e-6
+
+
+def test_a_prediction_changed_in_place_takes_the_plain_route():
+    """The score that travels with the prediction belongs to the values the forward wrote: after an in-place
+    edit the criterion evaluates loss and score itself."""
+    from graph_hscn.loss import LazyLoss, criterion
+    m, d, y, _ = _setup(B=4, seed=4)
+    pred = m(d.x_dict, d.edge_index_dict, d)
+    with torch.no_grad():
+        pred.mul_(0.5)
+    loss, score = criterion("cross_entropy", pred, y)
+    assert not isinstance(loss, LazyLoss)
+    assert close(score, torch.sigmoid(pred.detach()), atol=1e-6)
