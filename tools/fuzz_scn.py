@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised parity run of the graph-resident stage-A step (gcn_norm + SCN forward + MinCUT / orthogonality
+losses + backward, csrc/resident_scn.hip) against the CPU oracle's per-graph loop body
+(train_clustering.py:37-50): random structure (self loops, repeats, hubs, isolated nodes), K, H, activation.
+
+  python tools/fuzz_scn.py [cases] [seed]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-hscn_amd"), os.path.join(ROOT, "tools")]
+import numpy as np
+import torch
+
+from fuzz_resident import close, rand_graph
+from graph_hscn.data import Batch
+from graph_hscn.model.hscn import SCN
+from oracle import models as OM
+
+DEV = "cuda"
+
+
+def run(cases, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = refused = 0
+    for case in range(cases):
+        H = int(rng.choice([16, 16, 32]))
+        K = int(rng.choice([2, 4, 5, 16, 32, 64]))
+        F = int(rng.integers(1, 15))
+        act = str(rng.choice(["relu", "elu", "tanh", "identity"]))
+        B = int(rng.integers(1, 7))
+        graphs = [rand_graph(rng, F, 1, 300 if K <= 16 else 150) for _ in range(B)]
+        torch.manual_seed(case)
+        om = OM.SCN([H], act, F, K)
+        pm = SCN([H], act, F, K).to(DEV)
+        pm.load_state_dict(om.state_dict())
+        big = Batch.from_data_list(graphs)
+        msgs = []
+        if not pm.resident_ok(big):
+            refused += 1
+            if verbose:
+                print(f"REFUSED case {case}: H={H} K={K} F={F} n={[g.num_nodes for g in graphs]}", flush=True)
+            continue
+        S_all, mcs, os_ = [], [], []
+        om.zero_grad()
+        for g in graphs:
+            S_o, mc_o, o_o, *_ = OM.scn_step_single_graph(om, g.x, g.edge_index)
+            ((mc_o + 0.5 * o_o) / B).backward()
+            S_all.append(S_o.detach())
+            mcs.append(float(mc_o))
+            os_.append(float(o_o))
+        S_d, mc_d, o_d = pm.forward_graphs(big)
+        (mc_d + 0.5 * o_d).backward()
+        torch.cuda.synchronize()
+        big._scn_meta.check()
+        S_o = torch.cat(S_all)
+        ok, d = close(S_d, S_o, 1e-5, 1e-5)
+        if not ok:
+            msgs.append(f"S maxdiff {d:.2e}")
+        if abs(float(mc_d) - np.mean(mcs)) > 1e-5 or abs(float(o_d) - np.mean(os_)) > 1e-5:
+            msgs.append(f"losses {float(mc_d)} {float(o_d)} vs {np.mean(mcs)} {np.mean(os_)}")
+        top = S_o.topk(min(2, K), 1).values
+        sure = (top[:, 0] - top[:, -1]) > 1e-5 if K > 1 else torch.ones(S_o.size(0), dtype=torch.bool)
+        ids_d, ids_o = S_d.max(1)[1].cpu(), S_o.max(1)[1]
+        if not torch.equal(ids_d[sure], ids_o[sure]):
+            msgs.append("cluster ids differ where the margin is > 1e-5")
+        for (n_, po), (_, pd) in zip(om.named_parameters(), pm.named_parameters()):
+            ok, d = close(pd.grad, po.grad, 2e-5, 3e-3)
+            if not ok:
+                msgs.append(f"grad {n_} maxdiff {d:.2e} (ref max {float(po.grad.abs().max()):.2e})")
+        bad += bool(msgs)
+        if verbose:
+            print(f"{'BAD' if msgs else 'ok '} case {case}: H={H} K={K} F={F} B={B} act={act} n={[g.num_nodes for g in graphs]} {'; '.join(msgs)}",
+                  flush=True)
+    return bad, refused
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad, refused = run(cases, seed)
+    print(f"{cases - bad - refused}/{cases} cases match the oracle, {refused} refused, {bad} mismatch")
+    sys.exit(1 if bad else 0)
