@@ -1,0 +1,119 @@
+// Collate on the device: a training batch gathered out of a hetero dataset that lives in HBM
+// (reference: PyG DataLoader -> Batch.from_data_list on the host for every step, loader/loader.py:48-60,
+// loader/hetero_data.py:91-106).  The whole Peptides hetero dataset is ~250 MB -- it stays
+// resident; a step's batch is `ids[B]` (a slice of the epoch's permutation, on the device) and ONE launch
+// that copies the chosen graphs' features, edge lists (re-based to batch node numbering), targets and
+// writes the per-graph segment tables, straight into the fixed-capacity buffers a captured step replays on.
+// No host collate, no PCIe traffic, no synchronisation.
+//
+// grid = (B, 6): block (j, part) handles one array family of graph ids[j].  Every block derives the
+// destination offsets it needs itself -- a prefix sum over the sizes of the j graphs before it, B <= a few
+// thousand 8-byte loads spread over 256 threads -- so there is no scan launch and no inter-block dependency.
+#include "hscn_common.h"
+
+namespace {
+
+constexpr int CT = 256;
+
+__device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();                      // red is reused between calls
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  long long s = 0;
+#pragma unroll
+  for (int w = 0; w < CT / 64; ++w) s += red[w];
+  return s;
+}
+
+// (offset of graph slot j, size of graph slot j) in the table p of per-graph ranges
+__device__ __forceinline__ void slot_range(const int64_t* __restrict__ p, const int64_t* __restrict__ ids, int j,
+                                           long long* red, long long& off, long long& size) {
+  long long acc = 0;
+  for (int q = threadIdx.x; q < j; q += CT) {
+    const int64_t g = ids[q];
+    acc += p[g + 1] - p[g];
+  }
+  off = block_sum_ll(acc, red);
+  const int64_t g = ids[j];
+  size = p[g + 1] - p[g];
+}
+
+__global__ void __launch_bounds__(CT) k_collate_gather(const hscn_hetero_dataset D, const int64_t* __restrict__ ids,
+                                                       int B, const hscn_hetero_batch_out O, int32_t* __restrict__ flag) {
+  __shared__ long long red[CT / 64];
+  const int j = blockIdx.x, part = blockIdx.y;
+  const int64_t g = ids[j];
+  if (g < 0 || g >= D.G) {              // (uniform per block)
+    if (threadIdx.x == 0 && flag) atomicOr(flag, 8);
+    return;
+  }
+  long long on = 0, n = 0, ov = 0, nv = 0;
+  const bool need_n = part == 0 || part == 2 || part == 4 || part == 5;
+  const bool need_v = part == 1 || part == 3 || part == 4 || part == 5;
+  if (need_n) slot_range(D.nptr, ids, j, red, on, n);
+  if (need_v) slot_range(D.vptr, ids, j, red, ov, nv);
+  const bool fits_n = on + n <= O.ncap, fits_v = ov + nv <= O.vcap;
+  if (part == 0) {                      // local features + batch vector
+    if (!fits_n) { if (threadIdx.x == 0 && flag) atomicOr(flag, 8); return; }
+    const float* s = D.x_local + (size_t)D.nptr[g] * D.F;
+    float* d = O.x_local + (size_t)on * D.F;
+    for (long long i = threadIdx.x; i < n * D.F; i += CT) d[i] = s[i];
+    for (long long i = threadIdx.x; i < n; i += CT) O.batch_local[on + i] = j;
+  } else if (part == 1) {               // virtual features + batch vector
+    if (!fits_v) { if (threadIdx.x == 0 && flag) atomicOr(flag, 8); return; }
+    const float* s = D.x_virtual + (size_t)D.vptr[g] * D.F;
+    float* d = O.x_virtual + (size_t)ov * D.F;
+    for (long long i = threadIdx.x; i < nv * D.F; i += CT) d[i] = s[i];
+    for (long long i = threadIdx.x; i < nv; i += CT) O.batch_virtual[ov + i] = j;
+  } else if (part <= 4) {               // relation r = ll, vv, lv: local ids -> batch ids
+    const int r = part - 2;
+    long long oe, ne;
+    slot_range(D.eptr[r], ids, j, red, oe, ne);
+    if (oe + ne > O.ecap[r]) { if (threadIdx.x == 0 && flag) atomicOr(flag, 8); return; }
+    const long long os = r == 1 ? ov : on, od = r == 0 ? on : ov;
+    const int64_t e0 = D.eptr[r][g];
+    const int32_t* ss = D.src[r] + e0;
+    const int32_t* dd = D.dst[r] + e0;
+    int64_t* es = O.ei[r] + oe;
+    int64_t* ed = O.ei[r] + O.ecap[r] + oe;
+    for (long long e = threadIdx.x; e < ne; e += CT) {
+      es[e] = (int64_t)ss[e] + os;
+      ed[e] = (int64_t)dd[e] + od;
+    }
+  } else {                              // targets + the five segment tables (entry j; the last slot also writes the totals)
+    if (D.y && O.y)
+      for (int c = threadIdx.x; c < D.C; c += CT) O.y[(size_t)j * D.C + c] = D.y[(size_t)g * D.C + c];
+    long long oe[3], ne[3];
+    for (int r = 0; r < 3; ++r) slot_range(D.eptr[r], ids, j, red, oe[r], ne[r]);
+    if (threadIdx.x == 0) {
+      O.ptr_local[j] = on;    O.ptr32_local[j] = (int32_t)on;
+      O.ptr_virtual[j] = ov;  O.ptr32_virtual[j] = (int32_t)ov;
+      for (int r = 0; r < 3; ++r) O.eptr32[r][j] = (int32_t)oe[r];
+      if (j == B - 1) {
+        O.ptr_local[B] = on + n;    O.ptr32_local[B] = (int32_t)(on + n);
+        O.ptr_virtual[B] = ov + nv; O.ptr32_virtual[B] = (int32_t)(ov + nv);
+        for (int r = 0; r < 3; ++r) O.eptr32[r][B] = (int32_t)(oe[r] + ne[r]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int hscn_collate_gather(const hscn_hetero_dataset* ds, const int64_t* ids, int64_t B,
+                                   const hscn_hetero_batch_out* out, int32_t* flag, void* stream_) {
+  if (!ds || !out || B < 0 || B > 65535) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (!ids || !ds->x_local || !ds->x_virtual || !ds->nptr || !ds->vptr || ds->F < 1 || ds->G < 1) return HSCN_E_BADARG;
+  if (!out->x_local || !out->x_virtual || !out->ptr_local || !out->ptr_virtual || !out->ptr32_local ||
+      !out->ptr32_virtual || !out->batch_local || !out->batch_virtual)
+    return HSCN_E_BADARG;
+  for (int r = 0; r < 3; ++r)
+    if (!ds->src[r] || !ds->dst[r] || !ds->eptr[r] || !out->ei[r] || !out->eptr32[r] || out->ecap[r] < 1) return HSCN_E_BADARG;
+  if ((ds->y != nullptr) != (out->y != nullptr)) return HSCN_E_BADARG;
+  k_collate_gather<<<dim3((unsigned)B, 6), CT, 0, hscn_stream(stream_)>>>(*ds, ids, (int)B, *out, flag);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}

@@ -42,23 +42,37 @@ class StaticHeteroBatch:
         B = {int(b.num_graphs) for b in batches}
         if len(B) != 1:
             raise ValueError("all batches must hold the same number of graphs (drop or pad the last one)")
-        self.num_graphs = B.pop()
-        self.device = torch.device(device)
         cap = lambda f: max(int(f(b)) for b in batches)
-        self.N = cap(lambda b: b["local"].num_nodes)
-        self.V = cap(lambda b: b["virtual"].num_nodes)
-        self.E = {et: max(cap(lambda b, et=et: b[et].edge_index.size(1)), 1) for et in (LL, VV, LV)}
-        self.max_nodes = {"local": cap(lambda b: b["local"].max_nodes), "virtual": cap(lambda b: b["virtual"].max_nodes)}
-        self.max_edges = {et: cap(lambda b, et=et: b[et].max_edges) for et in (LL, VV, LV)}
-        F = int(batches[0]["local"].x.size(1))
         y0 = batches[0]["local"].y if "y" in batches[0]["local"] else None
-        G = self.num_graphs
+        C = None if y0 is None else (int(y0.size(1)) if num_classes is None else int(num_classes))
+        self._allocate(B.pop(), device, cap(lambda b: b["local"].num_nodes), cap(lambda b: b["virtual"].num_nodes),
+                       {et: cap(lambda b, et=et: b[et].edge_index.size(1)) for et in (LL, VV, LV)},
+                       {"local": cap(lambda b: b["local"].max_nodes), "virtual": cap(lambda b: b["virtual"].max_nodes)},
+                       {et: cap(lambda b, et=et: b[et].max_edges) for et in (LL, VV, LV)},
+                       int(batches[0]["local"].x.size(1)), C)
+
+    @classmethod
+    def from_capacities(cls, num_graphs: int, device, num_nodes: int, num_virtual: int, num_edges: dict,
+                        max_nodes: dict, max_edges: dict, num_features: int, num_classes: Optional[int]):
+        """Buffers for batches of ``num_graphs`` graphs with at most the given totals (nodes, virtual nodes,
+        edges per relation) and per-graph maxima (what sizes the LDS of the graph-resident launches)."""
+        self = cls.__new__(cls)
+        self._allocate(num_graphs, device, num_nodes, num_virtual, num_edges, max_nodes, max_edges, num_features,
+                       num_classes)
+        return self
+
+    def _allocate(self, G, device, N, V, E, max_nodes, max_edges, F, C):
+        self.num_graphs = int(G)
+        self.device = torch.device(device)
+        self.N, self.V = int(N), int(V)
+        self.E = {et: max(int(E[et]), 1) for et in (LL, VV, LV)}
+        self.max_nodes = {k: int(v) for k, v in max_nodes.items()}
+        self.max_edges = {et: int(max_edges[et]) for et in (LL, VV, LV)}
         fields = [("x_local", torch.float32, (self.N, F)), ("x_virtual", torch.float32, (self.V, F))]
         for nt, n in (("local", self.N), ("virtual", self.V)):
             fields += [(f"ptr_{nt}", torch.int64, (G + 1,)), (f"ptr32_{nt}", torch.int32, (G + 1,)),
                        (f"batch_{nt}", torch.int64, (n,))]
-        if y0 is not None:
-            C = int(y0.size(1)) if num_classes is None else int(num_classes)
+        if C is not None:
             fields.append(("y", torch.float32, (G, C)))
         for i, et in enumerate((LL, VV, LV)):
             fields += [(f"ei_{i}", torch.int64, (2, self.E[et])), (f"eptr_{i}", torch.int32, (G + 1,))]
@@ -142,8 +156,19 @@ class CapturedStep:
     they keep the parameters' gradient-accumulation nodes alive, bound to the stream those steps ran on,
     and autograd would then tie the capture to that (non-capturing) stream."""
 
-    def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3):
-        self.model, self.static, self.loss_fn = model, static, loss_fn
+    def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None):
+        """``optimizer``: a ``torch.optim`` optimizer built with ``capturable=True`` (``fused=True`` keeps it to one
+        launch); its ``step()`` is captured behind the backward, so a replay is a whole training iteration.
+        The ``warmup`` eager iterations that precede the capture run the optimizer too (PyTorch's whole-network
+        capture recipe); parameters and optimizer state are put back afterwards, IN PLACE (the captured launches
+        hold their addresses): state that existed before is restored, state the warm-up created is zeroed (the
+        initial state of the Adam family)."""
+        self.model, self.static, self.loss_fn, self.optimizer = model, static, loss_fn, optimizer
+        snap_p = snap_s = None
+        if optimizer is not None:
+            snap_p = [p.detach().clone() for p in model.parameters()]
+            snap_s = {id(p): {k: v.clone() for k, v in st.items() if isinstance(v, Tensor)}
+                      for p, st in optimizer.state.items()}
         hb = static.batch
         if "y" not in hb["local"]:
             raise ValueError("the static batch carries no targets")
@@ -154,6 +179,8 @@ class CapturedStep:
             pred = model(hb.x_dict, hb.edge_index_dict, hb)
             loss, score = criterion(loss_fn, pred, hb["local"].y)
             loss.backward()
+            if optimizer is not None:
+                optimizer.step()
             return pred.detach(), loss.detach(), score
 
         side = torch.cuda.Stream()
@@ -169,6 +196,15 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.pred, self.loss, self.score = step()
+        if optimizer is not None:
+            with torch.no_grad():
+                for p, s0 in zip(model.parameters(), snap_p):
+                    p.copy_(s0)
+                for p, st in optimizer.state.items():
+                    for k, v in st.items():
+                        if isinstance(v, Tensor):
+                            old = snap_s.get(id(p), {}).get(k)
+                            v.copy_(old) if old is not None else v.zero_()
 
     def replay(self) -> Tensor:
         self.graph.replay()

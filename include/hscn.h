@@ -268,6 +268,39 @@ int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t num_edges,
                       float* adj /*[n,n]*/, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Collate on the device (reference: the PyG DataLoader collates HeteroData on the host for every step,
+ * loader/hetero_data.py:91-106, loader/loader.py:48-60).  The hetero dataset stays in HBM as
+ * concatenated arrays with per-graph LOCAL node ids; hscn_collate_gather writes the batch made of graphs
+ * ids[0..B) -- features, batch vectors, targets, edge lists re-based to batch numbering (int64 [2, ecap] as the
+ * reference's edge_index), int64 / int32 per-graph segment tables -- into fixed-capacity buffers, bit for bit
+ * what Batch.from_data_list produces for that list of graphs.  One launch, no host synchronisation.
+ * Relations in the order ll, vv, lv (source type local, virtual, local; target type local, virtual, virtual).
+ * flag bit 8: an id outside [0, G) or a batch beyond a capacity (the offending part is not written). */
+typedef struct hscn_hetero_dataset {
+  const float* x_local;    /* [N,F] */
+  const float* x_virtual;  /* [V,F] */
+  const float* y;          /* [G,C] or NULL */
+  const int64_t* nptr;     /* [G+1] local-node ranges */
+  const int64_t* vptr;     /* [G+1] virtual-node ranges */
+  const int32_t* src[3];   /* per relation: source ids local to the graph */
+  const int32_t* dst[3];   /* per relation: target ids local to the graph */
+  const int64_t* eptr[3];  /* per relation: [G+1] edge ranges */
+  int64_t G;
+  int32_t F, C;
+} hscn_hetero_dataset;
+typedef struct hscn_hetero_batch_out {
+  float *x_local, *x_virtual, *y;                /* [ncap,F] [vcap,F] [B,C] (y NULL iff the dataset has none) */
+  int64_t *ptr_local, *ptr_virtual;              /* [B+1] */
+  int32_t *ptr32_local, *ptr32_virtual;          /* [B+1] */
+  int64_t *batch_local, *batch_virtual;          /* [ncap] [vcap] graph slot of every node */
+  int64_t* ei[3];                                /* [2, ecap[r]] */
+  int32_t* eptr32[3];                            /* [B+1] */
+  int64_t ncap, vcap, ecap[3];
+} hscn_hetero_batch_out;
+int hscn_collate_gather(const hscn_hetero_dataset* dataset, const int64_t* ids /*[B] device*/, int64_t B,
+                        const hscn_hetero_batch_out* out, int32_t* flag, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Loss tail (reference graph_hscn/loss.py:6-19, called at train/train.py:82) on the
  * [B,C] prediction, kind 0 = BCEWithLogits(mean), 1 = L1(mean):
  *   loss[0] = mean loss, score = sigmoid(pred) (may be NULL), grad = dloss/dpred.
