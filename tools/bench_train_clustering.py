@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Wall clock of the stage-A driver itself (train/train_clustering.py: cluster_epochs passes with an optimizer step
+per step + the assignment pass), reference trajectory (1 graph / step) and batched (128 graphs / step)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "graph-hscn_amd")]
+import torch
+
+from graph_hscn.config.config import HSCNConfig, OptimConfig, TrainingConfig
+from graph_hscn.loader.synthetic import make_dataset
+from graph_hscn.model.hscn import SCN
+from graph_hscn.train.train_clustering import train_clustering
+
+
+def main(G=1024, epochs=5, K=16):
+    graphs = make_dataset("peptides_func", G, seed=0)
+    mc = HSCNConfig("relu", num_clusters=K, cluster_epochs=epochs)
+    oc = OptimConfig("adam", lr=0.01)
+    tc = TrainingConfig("hscn", "cross_entropy", "ap")
+    out = {"graphs": G, "cluster_epochs": epochs}
+    for bg in (1, 128):
+        torch.manual_seed(0)
+        scn = SCN(mc.mp_units, "elu", 9, K).to("cuda")
+        train_clustering(None, graphs[:bg * 2], scn, HSCNConfig("relu", num_clusters=K, cluster_epochs=1), oc, tc, batch_graphs=bg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids = train_clustering(None, graphs, scn, mc, oc, tc, batch_graphs=bg)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        assert len(ids) == G
+        out[f"batch_graphs={bg}"] = {"seconds": t, "graph_visits_per_s": G * (epochs + 1) / t}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
