@@ -196,6 +196,8 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.pred, self.loss, self.score = step()
+        # the gradient tensors the captured backward writes (a later eager step re-points ``p.grad`` elsewhere)
+        self.grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
         if optimizer is not None:
             with torch.no_grad():
                 for p, s0 in zip(model.parameters(), snap_p):
@@ -209,3 +211,9 @@ class CapturedStep:
     def replay(self) -> Tensor:
         self.graph.replay()
         return self.loss
+
+    def bind_grads(self) -> None:
+        """Point every ``p.grad`` at the captured step's gradient buffers again (after eager steps of the same
+        model): an optimizer stepped OUTSIDE the graph reads ``p.grad``."""
+        for p, g in self.grads:
+            p.grad = g
