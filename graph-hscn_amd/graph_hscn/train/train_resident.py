@@ -24,9 +24,15 @@ from .train import eval_epoch, is_eval_epoch
 
 
 def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroData], eval_loaders: Sequence, model,
-                 batch_size: int, metric_fn: Optional[Callable] = None, seed: int = 0) -> List[tuple]:
+                 batch_size: int, metric_fn: Optional[Callable] = None, seed: int = 0, reducer=None) -> List[tuple]:
     """Returns ``[(mean train loss, train metric), ...]`` per epoch, like ``train.train``.  ``eval_loaders`` =
-    ``[validation, test]`` loaders of host batches (evaluated with ``train.eval_epoch``)."""
+    ``[validation, test]`` loaders of host batches (evaluated with ``train.eval_epoch``).
+
+    Data parallel: every rank calls this with ITS shard of the training graphs (``distributed.shard_list``; equal
+    shard sizes, so that all ranks take the same number of steps) and a ``distributed.FlatGradReducer`` as
+    ``reducer``.  The iteration is then two replays around one collective: forward + loss + backward, the RCCL
+    all-reduce of the flat gradient buffer where the backward left it, the optimizer step (captured on its own).
+    The eager tail batch is reduced the same way."""
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("fit_resident runs on the MI355X HIP path: move the model to 'cuda'")
@@ -40,12 +46,16 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
         optimizer = opt_cls(model.parameters(), capturable=True, fused=True, **kw)
     except (TypeError, RuntimeError):          # (Adagrad has neither switch: its step stays outside the graph)
         optimizer = opt_cls(model.parameters(), **kw)
-    in_graph = bool(optimizer.defaults.get("capturable", False))
+    capturable = bool(optimizer.defaults.get("capturable", False))
+    in_graph = capturable and reducer is None      # with a reducer the collective sits between backward and step
     gen = torch.Generator(device=dev).manual_seed(seed)
     model.train()
     model.engine = "resident"
     ds.gather(torch.arange(B, device=dev))
     step = CapturedStep(model, ds.static, training_cfg.loss_fn, optimizer=optimizer if in_graph else None)
+    opt_graph = None
+    if reducer is not None and capturable:
+        opt_graph = _capture_optimizer_step(model, optimizer, step)
     steps, tail = G // B, G % B
     C = ds.C
     loss_log = torch.zeros(steps + (1 if tail else 0), dtype=torch.float32, device=dev)
@@ -61,7 +71,11 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
         for i in range(steps):
             ds.gather(perm[i * B:(i + 1) * B])
             step.replay()
-            if not in_graph:
+            if reducer is not None:
+                reducer.reduce(float(B), float(B * reducer.world_size))
+            if opt_graph is not None:
+                opt_graph.replay()
+            elif not in_graph:
                 optimizer.step()
             loss_log[i].copy_(step.loss)
             if metric_fn:
@@ -73,6 +87,8 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
             pred = model(hb.x_dict, hb.edge_index_dict, hb)
             loss, score = criterion(training_cfg.loss_fn, pred, hb["local"].y)
             loss.backward()
+            if reducer is not None:
+                reducer.reduce(float(tail), float(tail * reducer.world_size))
             optimizer.step()
             loss_log[steps].copy_(loss.detach())
             if metric_fn:
@@ -99,3 +115,31 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
                         return history
     ds.check()
     return history
+
+
+def _capture_optimizer_step(model, optimizer, step: CapturedStep) -> torch.cuda.CUDAGraph:
+    """``optimizer.step()`` on the captured backward's gradient buffers as a graph of its own (a fused capturable
+    optimizer: one launch).  Parameters and optimizer state are put back in place after the warm-up steps."""
+    from torch import Tensor
+    step.bind_grads()
+    snap_p = [p.detach().clone() for p in model.parameters()]
+    snap_s = {id(p): {k: v.clone() for k, v in st.items() if isinstance(v, Tensor)} for p, st in optimizer.state.items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            optimizer.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        optimizer.step()
+    with torch.no_grad():
+        for p, s0 in zip(model.parameters(), snap_p):
+            p.copy_(s0)
+        for p, st in optimizer.state.items():
+            for k, v in st.items():
+                if isinstance(v, Tensor):
+                    old = snap_s.get(id(p), {}).get(k)
+                    v.copy_(old) if old is not None else v.zero_()
+    return g

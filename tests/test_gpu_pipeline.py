@@ -167,3 +167,41 @@ def test_resident_training_loop_learns_and_visits_every_graph():
     tc2 = TrainingConfig("hscn", "cross_entropy", "ap", epochs=6, eval_period=6, patience=50)
     hist2 = fit_resident(None, OptimConfig("adagrad", lr=0.05), tc2, hs[:50], loaders, model2, batch_size=16)
     assert hist2[-1][0] < hist2[0][0]
+
+
+def test_resident_training_loop_with_the_rccl_reducer_single_rank():
+    """The data-parallel form of fit_resident (replay, RCCL all-reduce of the flat gradient buffer, optimizer step
+    as its own graph) with a world of one: same parameters as the single-process loop, bit for bit."""
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    from graph_hscn.config.config import ACT_DICT, OptimConfig, TrainingConfig
+    from graph_hscn.data import DataLoader
+    from graph_hscn.distributed import FlatGradReducer
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import HSCN
+    from graph_hscn.train.train_resident import fit_resident
+    graphs = make_dataset("peptides_func", 40, seed=5)
+    rng = np.random.default_rng(1)
+    hs = [hetero_from_clusters(g, rng.integers(0, 8, g.num_nodes), 8) for g in graphs]
+    tc = TrainingConfig("hscn", "cross_entropy", "ap", epochs=3, eval_period=3, patience=50)
+    loaders = [DataLoader(hs[30:35], batch_size=5), DataLoader(hs[35:], batch_size=5)]
+
+    def run(reducer_factory):
+        torch.manual_seed(0)
+        m = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, 10, 3).to("cuda")
+        fit_resident(None, OptimConfig("adamW", lr=0.01), tc, hs[:30], loaders, m, batch_size=8,
+                     reducer=reducer_factory(m) if reducer_factory else None)
+        return [p.detach().clone() for p in m.parameters()]
+
+    want = run(None)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        got = run(lambda m: FlatGradReducer(m, single_rank_collective=True))
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
