@@ -41,6 +41,8 @@
 // multiply/add in the gather-reduce (same as the layered kernels).
 #include "hscn_common.h"
 #include "resident_common.h"
+#include <cstdio>
+#include <cstdlib>
 #include <cstdlib>
 
 namespace {
@@ -73,6 +75,7 @@ struct FwdArgs {
   float *vs_dinv_v, *vs_xv;
   int spec;  // 1: ll path and virtual branch run concurrently on two wave groups (needs a 3rd n x H buffer)
   int exp;   // 1: this launch also builds + exports the source-keyed ll CSR (needs LDS for it)
+  int exp_dinv;  // 1: this launch exports the ll degree norm (the workgroup that builds ll keyed by target has it)
   float slope;
 };
 
@@ -203,6 +206,46 @@ __device__ void lin_blk(const float* X, const float* Wt, float* Y, int n, const 
       for (int off = LPR >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
       if (og == 0) a_out[i] = d;
     }
+  }
+}
+
+// ---- attention logits of one side of a GAT relation without the transform: --------------------------
+// a[i] = att . (W x_i) = (W^T att) . x_i with w~ = Wt att; a row then costs one float4 read and a quad fold.
+template <int H>
+__device__ void att_logits(const float* X, const float* Wt, const float* att, float* a_out, int n, const Grp& G) {
+  constexpr int LPR = H / 4;                  // lanes per row
+  constexpr int RPW = 64 / LPR;               // rows per wave per pass
+  const int lane = threadIdx.x & 63, q = lane % LPR, rl = lane / LPR;
+  if (G.w * RPW >= n) return;
+  // w~ once per wave, spread over its lanes (every wave folding all of it out of LDS by itself saturated the
+  // LDS pipe of the CU): lane L owns k = L % H and one 64/H-th of the sum over o, the parts meet through
+  // xor-shuffles, the lane's quarter w~[4q .. 4q+3] arrives through four permutes
+  constexpr int P = 64 / H, OW = H / P;
+  float wk = 0.f;
+  {
+    const int k = lane % H, part = lane / H;
+#pragma unroll
+    for (int o4 = 0; o4 < OW / 4; ++o4) {
+      const float4 at = *reinterpret_cast<const float4*>(att + part * OW + 4 * o4);
+      const float4 wr = *reinterpret_cast<const float4*>(Wt + k * H + part * OW + 4 * o4);
+      wk = fmaf(at.w, wr.w, fmaf(at.z, wr.z, fmaf(at.y, wr.y, fmaf(at.x, wr.x, wk))));
+    }
+#pragma unroll
+    for (int off = H; off < 64; off <<= 1) wk += __shfl_xor(wk, off, 64);
+  }
+  float w[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) w[c] = __shfl(wk, 4 * q + c, 64);
+  for (int i0 = G.w * RPW; i0 < n; i0 += G.nw * RPW) {
+    const int i = i0 + rl;
+    float d = 0.f;
+    if (i < n) {
+      const float4 x = *reinterpret_cast<const float4*>(X + i * H + 4 * q);
+      d = fmaf(x.w, w[3], fmaf(x.z, w[2], fmaf(x.y, w[1], x.x * w[0])));
+    }
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+    if (q == 0 && i < n) a_out[i] = d;
   }
 }
 
@@ -364,7 +407,7 @@ __device__ void agg_gcn_lds(const int* rowptr, const int* col, const float* dr, 
 
 // LDS layout shared by host sizing and kernel carve (all counts in 4-byte words)
 struct FwdLayout {
-  size_t xa, bh, bs, xva, xvb, hv, a_s, a_d, sc, dinv, dinv_v, wt, headw, part, vec;
+  size_t xa, bh, xva, xvb, zs, a_s, a_d, sc, dinv, dinv_v, wt, headw, part, vec;
   size_t rowptr, col, rowptr_lv, col_lv, rowptr_vv, col_vv, cursorA, tmpA, cursorB, tmpB, wsum;
   size_t rowptr_t, col_t, cursorT, tmpT, cursorV, tmpV;
   size_t ck_tab, ck_first, ck_arrive, gpart;  // softmax chunks of the lv relation (64 members each)
@@ -385,13 +428,13 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
     if (xq + need <= xend) { const size_t r = xq; xq += need; return r; }
     return take(n);
   };
-  // transform outputs bh | bs; the staged COO slices (needed only before layer 0) overlay them
+  // second n x H buffer (a local layer writes it, then the two swap roles); the staged COO slices (needed only
+  // before layer 0) overlay it
   const size_t stage = (size_t)2 * (((size_t)max_ell + 3) / 4 * 4 + ((size_t)max_n + 3) / 4 * 4 +
                                     ((size_t)max_evv + 3) / 4 * 4);
-  size_t two = (size_t)(spec ? 2 : 1) * max_n * H;
+  const size_t two = (size_t)max_n * H;
   const size_t region = take(two > stage ? two : stage);
   Y.bh = region;
-  Y.bs = spec ? region + (size_t)max_n * H : region;  // sequential mode: bs aliases bh
   {
     size_t p = region;
     auto sub = [&](size_t n) { size_t r = p; p += (n + 3) & ~(size_t)3; return r; };
@@ -401,7 +444,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   }
   Y.xva = take((size_t)max_v * H);
   Y.xvb = take((size_t)max_v * H);
-  Y.hv = take((size_t)max_v * H);
+  Y.zs = take(max_v ? (size_t)(RT_MAX / 64) * 2 * H : 0);   // per wave: the two aggregated rows of the cluster it finishes
   Y.a_s = take(max_n);
   Y.a_d = take(max_v);
   Y.sc = take(max_n);
@@ -451,17 +494,27 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
   const bool vonly = A.compute_virtual == 2;  // virtual branch only: the local activations come from `acts`
-  const int e0 = A.eptr_ll[g], ne = vonly ? 0 : A.eptr_ll[g + 1] - e0;
+  // (a virtual-only workgroup touches the ll edges only when it builds the source-keyed CSR for the backward)
+  const int e0 = A.eptr_ll[g], ne = (vonly && !A.exp) ? 0 : A.eptr_ll[g + 1] - e0;
   const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
   const int el0 = A.eptr_lv[g], nel = A.eptr_lv[g + 1] - el0;
   if ((n > A.max_n) | (nv > A.max_v) | (ne > A.max_ell) | (nev > A.max_evv) | (nel > A.max_n) | (n < 0) | (nv < 0)) {
     if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    // the launches that consume this workgroup's exports walk them without knowing about the error: leave
+    // empty structure (all-zero row pointers) behind, never stale memory
+    if (A.exp && A.csr_rowptr_t && n >= 0)
+      for (int i = threadIdx.x; i <= n; i += RT) A.csr_rowptr_t[(size_t)n0 + g + i] = 0;
+    if (vonly && A.l_begin == 0 && A.l_end < A.L && A.vs_rowptr_lv && nv >= 0)
+      for (int i = threadIdx.x; i <= nv; i += RT) {
+        A.vs_rowptr_lv[(size_t)v0 + g + i] = 0;
+        A.vs_rowptr_vv[(size_t)v0 + g + i] = 0;
+      }
     return;
   }
   const FwdLayout Y = fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec, A.exp);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
-  float *xa = fb + Y.xa, *bh = fb + Y.bh, *bs = fb + Y.bs, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *hv = fb + Y.hv;
+  float *xa = fb + Y.xa, *bh = fb + Y.bh, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *zs = fb + Y.zs;
   float *a_s = fb + Y.a_s, *a_d = fb + Y.a_d, *sc = fb + Y.sc, *dinv = fb + Y.dinv, *dinv_v = fb + Y.dinv_v;
   float *wt = fb + Y.wt, *headw = fb + Y.headw, *part = fb + Y.part, *vec = fb + Y.vec;
   int *rowptr = ib + Y.rowptr, *col = ib + Y.col, *rowptr_lv = ib + Y.rowptr_lv, *col_lv = ib + Y.col_lv;
@@ -710,8 +763,9 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       for (int i = threadIdx.x; i <= n; i += RT) A.csr_rowptr_t[(size_t)n0 + g + i] = rowptr_t[i];
       const int cnt_t = rowptr_t[n];
       for (int p = threadIdx.x; p < cnt_t; p += RT) A.csr_col_t[(size_t)e0 + p] = col_t[p];
-      for (int i = threadIdx.x; i < n; i += RT) A.dinv_out[(size_t)n0 + i] = dinv[i];
     }
+    if (A.exp_dinv)
+      for (int i = threadIdx.x; i < n; i += RT) A.dinv_out[(size_t)n0 + i] = dinv[i];
   }
   } else {
     // ---- resumed virtual branch: the structure and the virtual features come from the state the
@@ -758,24 +812,16 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       float4* dst = reinterpret_cast<float4*>(to);
       for (int i = G_.t; i < n * (H / 4); i += G_.nt) dst[i] = src[i];
     };
+    // The virtual branch's transforms are linear and sit in front of linear aggregations, so they move BEHIND
+    // them (a cluster row instead of every member row is transformed):
+    //   lv GAT  out_v = W_src (sum_i alpha_i x_i) + b,  alpha from a_s[i] = (W_src^T att_src) . x_i and
+    //           a_d[v] = (W_dst^T att_dst) . xv_v;       vv GCN  out_v = W_vv (sum_u norm_uv xv_u) + b.
+    // Phase 1 is the n + nv attention dots; phase 2 aggregates INPUT rows and the finishing wave of a cluster
+    // applies the two H x H matrices to the two aggregated rows.  Same values as transform-then-aggregate,
+    // another rounding order.
     auto transforms_virtual = [&](const Grp& G_) {
-      // the two cluster-side transforms have a handful of rows: one wave each, beside the waves
-      // that transform the n local rows
-      constexpr int RPW = 64 / (H / OPT);   // rows one wave covers per pass
-      if (G_.nw >= 4 && nv <= 4 * RPW) {
-        const int ns = G_.nw - 2;
-        if (G_.w < ns) {
-          lin_blk<H, OPT>(xa, W + H * H, bs, n, att_s, a_s, Grp{G_.t, ns * 64, G_.w, ns});
-        } else if (G_.w == ns) {
-          lin_blk<H, OPT>(xva, W + 2 * H * H, nullptr, nv, att_d, a_d, Grp{G_.t - ns * 64, 64, 0, 1});
-        } else {
-          lin_blk<H, OPT>(xva, W + 3 * H * H, hv, nv, nullptr, nullptr, Grp{G_.t - (ns + 1) * 64, 64, 0, 1});
-        }
-        return;
-      }
-      lin_blk<H, OPT>(xa, W + H * H, bs, n, att_s, a_s, G_);               // lv source side (+ a_src)
-      lin_blk<H, OPT>(xva, W + 2 * H * H, nullptr, nv, att_d, a_d, G_);    // lv target side only through a_dst
-      lin_blk<H, OPT>(xva, W + 3 * H * H, hv, nv, nullptr, nullptr, G_);   // vv
+      att_logits<H>(xa, W + H * H, att_s, a_s, n, G_);
+      att_logits<H>(xva, W + 2 * H * H, att_d, a_d, nv, G_);
     };
     auto reduce_ll = [&](const Grp& G_) {
       agg_gcn_lds<H>(rowptr, col, dinv, dinv, bh, b_ll, xa, n, 1, A.acts + ((size_t)l * A.N + n0) * H, G_);
@@ -833,7 +879,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
             al[u] = ok ? sc[p] : 0.f;
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) hh[u] = *reinterpret_cast<const float4*>(bs + jj[u] * H + f);
+          for (int u = 0; u < 4; ++u) hh[u] = *reinterpret_cast<const float4*>(xa + jj[u] * H + f);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             if (p0 + u * S < ce) {
@@ -883,7 +929,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               ww[u] = mul_rn(dinv_v[jj[u]], di);
-              xx[u] = *reinterpret_cast<const float4*>(hv + jj[u] * H + f);
+              xx[u] = *reinterpret_cast<const float4*>(xva + jj[u] * H + f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -900,17 +946,40 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
             const float4 q = *reinterpret_cast<const float4*>(gpart + (size_t)(first + c2) * H + f);
             g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
           }
-          const float4 bv = *reinterpret_cast<const float4*>(b_vv + f);
-          const float4 bg = *reinterpret_cast<const float4*>(b_gat + f);
-          a.x = fmaxf((a.x + bv.x) + (g.x + bg.x), 0.f);
-          a.y = fmaxf((a.y + bv.y) + (g.y + bg.y), 0.f);
-          a.z = fmaxf((a.z + bv.z) + (g.z + bg.z), 0.f);
-          a.w = fmaxf((a.w + bv.w) + (g.w + bg.w), 0.f);
-          *reinterpret_cast<float4*>(xvb + v * H + f) = a;
+          // the two aggregated input rows of cluster v -> this wave's scratch (LDS executes a wave's operations
+          // in order: the lanes below read what these lanes wrote)
+          float* zw = zs + wave * 2 * H;
+          *reinterpret_cast<float4*>(zw + f) = g;          // z1 = sum_i alpha_i x_i
+          *reinterpret_cast<float4*>(zw + H + f) = a;      // z2 = sum_u norm_uv xv_u
+        }
+        {
+          const float* zw = zs + wave * 2 * H;
+          const float* Ws = W + H * H;                     // Wt_src[k][o]
+          const float* Wv = W + 3 * H * H;                 // Wt_vv[k][o]
+          for (int o = lane; o < H; o += 64) {
+            float og = 0.f, ov_ = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < H / 4; ++k4) {
+              const float4 z1 = *reinterpret_cast<const float4*>(zw + 4 * k4);
+              const float4 z2 = *reinterpret_cast<const float4*>(zw + H + 4 * k4);
+              og = fmaf(z1.x, Ws[(4 * k4 + 0) * H + o], og);
+              og = fmaf(z1.y, Ws[(4 * k4 + 1) * H + o], og);
+              og = fmaf(z1.z, Ws[(4 * k4 + 2) * H + o], og);
+              og = fmaf(z1.w, Ws[(4 * k4 + 3) * H + o], og);
+              ov_ = fmaf(z2.x, Wv[(4 * k4 + 0) * H + o], ov_);
+              ov_ = fmaf(z2.y, Wv[(4 * k4 + 1) * H + o], ov_);
+              ov_ = fmaf(z2.z, Wv[(4 * k4 + 2) * H + o], ov_);
+              ov_ = fmaf(z2.w, Wv[(4 * k4 + 3) * H + o], ov_);
+            }
+            xvb[v * H + o] = fmaxf((ov_ + b_vv[o]) + (og + b_gat[o]), 0.f);
+          }
         }
       }
     };
-    if (cv && A.spec) {
+    // (the two wave groups may only run side by side while the local layer leaves xa alone until the layer ends:
+    // group B gathers input rows from it in phase 2.  The unfused H = 64 local path rewrites xa in its second
+    // phase, so there the branches take turns)
+    if (cv && A.spec && (FUSE || vonly)) {
       // two barriers per layer: the ll path (group A) and the virtual branch (group B) side by side
       // (virtual-only launch: group A streams the next layer's local rows into the idle transform
       // buffer while group B works, the two buffers swap roles at the end of the layer)
@@ -979,9 +1048,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         if (vonly) load_next_local(ALL, xa); else reduce_ll(ALL);
         STAMP_T(43 + 4 * l, 0);
         lds_barrier();
-      } else {   // fused local layer: its output sits in bh; in this mode bs shares that buffer and follows it
+      } else {   // fused local layer: its output sits in bh
         float* t_ = xa; xa = bh; bh = t_;
-        bs = bh;
       }
     }
     if (more && !DB) {  // single weight buffer: everybody is done with it now
@@ -1574,6 +1642,7 @@ int launch_fwd(FwdArgs& A, int64_t B, hipStream_t st) {
     ok = lds <= 160 * 1024;
   }
   if (!ok) return HSCN_E_UNSUPPORTED;
+  A.exp_dinv = A.exp;
   static const int rt_env = getenv("HSCN_RT") ? atoi(getenv("HSCN_RT")) : 0;
   int rc;
   if (A.max_n <= 64 || rt_env == 256) rc = launch_fwd_rt<H, 256>(A, B, lds, st);
@@ -1626,6 +1695,7 @@ int launch_bwd_virtual(BwdArgs& Ab, FwdArgs& Af, int64_t B, hipStream_t st) {
   for (int spec = 1; spec >= 0 && !ok; --spec) {
     Af.spec = spec;
     Af.exp = 0;
+    Af.exp_dinv = 0;
     lf = fwd_lds_bytes(H, Af.C, Af.max_n, Af.max_v, Af.max_ell, Af.max_evv, spec, 0);
     ok = lf <= 160 * 1024;
   }
@@ -1672,7 +1742,7 @@ int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, cons
   A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_out = dinv_out;
   A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_v = max_v; A.max_ell = vonly ? 0 : max_ell; A.max_evv = max_evv;
-  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0;
+  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0; A.exp_dinv = 0;
   A.l_begin = 0; A.l_end = L;
   A.vs_rowptr_lv = A.vs_col_lv = A.vs_rowptr_vv = A.vs_col_vv = nullptr;
   A.vs_dinv_v = A.vs_xv = nullptr;
@@ -1702,30 +1772,40 @@ int launch_fwd_pair_rt(const FwdArgs& Al, const FwdArgs& Av, int64_t B, size_t l
 }
 template <int H>
 int launch_fwd_pair(FwdArgs& Al, FwdArgs& Av, int64_t B, hipStream_t st) {
-  // local part: no virtual branch, CSR export in the launch when LDS allows (else the side kernel)
+  // The backward launch wants the ll CSR keyed by source and the degree norm.  The local workgroup is the long
+  // pole of this launch, the virtual one has slack: the VIRTUAL workgroup builds and exports the source-keyed
+  // CSR (it loads the ll edges for that alone), the local one only adds the degree norm it computes anyway.
+  // Fallbacks when LDS is short: export from the local workgroup, then the light side kernel.
   const bool want_exp = Al.csr_rowptr_t != nullptr;
   size_t ll = 0, lv = 0;
   bool ok = false;
+  // (a virtual-only workgroup is sized without ll edges unless it takes this job: Al.max_ell is the real bound)
+  const bool v_can = want_exp && Av.ll_src && Av.csr_rowptr_t &&
+                     fwd_lds_bytes(H, Av.C, Av.max_n, Av.max_v, Al.max_ell, Av.max_evv, 1, 1) <= 160 * 1024;
+  Av.max_ell = v_can ? Al.max_ell : 0;
   for (int e = 1; e >= 0 && !ok; --e) {
     Al.spec = 0;
-    Al.exp = (want_exp && e) ? 1 : 0;
+    Al.exp = (want_exp && e && !v_can) ? 1 : 0;
     ll = fwd_lds_bytes(H, Al.C, Al.max_n, Al.max_v, Al.max_ell, Al.max_evv, 0, Al.exp);
     ok = ll <= 160 * 1024;
   }
   if (!ok) return HSCN_E_UNSUPPORTED;
+  Al.exp_dinv = (Al.exp || v_can) ? 1 : 0;
   ok = false;
   for (int spec = 1; spec >= 0 && !ok; --spec) {
     Av.spec = spec;
-    Av.exp = 0;
-    lv = fwd_lds_bytes(H, Av.C, Av.max_n, Av.max_v, Av.max_ell, Av.max_evv, spec, 0);
+    Av.exp = v_can ? 1 : 0;
+    Av.exp_dinv = 0;
+    lv = fwd_lds_bytes(H, Av.C, Av.max_n, Av.max_v, Av.max_ell, Av.max_evv, spec, Av.exp);
     ok = lv <= 160 * 1024;
   }
   if (!ok) return HSCN_E_UNSUPPORTED;
+  if (!v_can) { Av.ll_src = nullptr; Av.ll_dst = nullptr; }
   const size_t lds = ll > lv ? ll : lv;
   int rc = Al.max_n <= 64 ? launch_fwd_pair_rt<H, 256>(Al, Av, B, lds, st)
                           : launch_fwd_pair_rt<H, 1024>(Al, Av, B, lds, st);
   if (rc) return rc;
-  if (want_exp && !Al.exp) {
+  if (want_exp && !Al.exp && !v_can) {
     const size_t l2 = ((size_t)4 * Al.max_ell + 2 * ((size_t)Al.max_n + 1) + 16) * 4;
     if (l2 > 160 * 1024) return HSCN_E_UNSUPPORTED;
     if (l2 > 64 * 1024)
@@ -1921,6 +2001,9 @@ int hscn_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
   attach_state(Av, job);
   Av.l_begin = 0;
   Av.l_end = 1;
+  // what the virtual workgroup needs to build the backward's source-keyed ll CSR (launch_fwd_pair decides)
+  Av.ll_src = Al.ll_src; Av.ll_dst = Al.ll_dst;
+  Av.csr_rowptr_t = csr_rowptr_t; Av.csr_col_t = csr_col_t;
   hipStream_t st = hscn_stream(stream_);
   switch (H) {
     case 16: return launch_fwd_pair<16>(Al, Av, B, st);
