@@ -444,7 +444,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   }
   Y.xva = take((size_t)max_v * H);
   Y.xvb = take((size_t)max_v * H);
-  Y.zs = take(max_v ? (size_t)(RT_MAX / 64) * 2 * H : 0);   // per wave: the two aggregated rows of the cluster it finishes
+  Y.zs = take(max_v ? (size_t)(RT_MAX / 64) * H : 0);   // per wave: an aggregated row of the cluster it finishes
   Y.a_s = take(max_n);
   Y.a_d = take(max_v);
   Y.sc = take(max_n);
@@ -864,7 +864,10 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
           denom = wave_sum_dpp(sum) + 1e-16f;
         }
         if (on) sc[p_own] = expf(e_own - m) / denom;
-        // (in-order LDS: the slot loop below sees the alphas)  Four members per slot per trip: the
+        // LDS executes a wave's operations in order, so the slot loop below sees the alphas other lanes wrote --
+        // provided the COMPILER keeps the order too: a wavefront-scope fence pins it (it costs a waitcnt)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // Four members per slot per trip: the
         // index, alpha and row reads of a trip are independent.
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int p0 = cs + slot; p0 < ce; p0 += 4 * S) {
@@ -915,6 +918,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         if (arrived != cntv - 1) continue;
         // ---- last chunk of cluster v: finish row v ----
         if (lane == 0) ck_arrive[v] = 0;   // ready for the next layer
+        float4 z1r = make_float4(0.f, 0.f, 0.f, 0.f), z2r = z1r;
         if (slot == 0) {
           // virtual -> virtual GCN row v (edge order, separately rounded)
           const int s2 = rowptr_vv[v], t2 = rowptr_vv[v + 1];
@@ -946,32 +950,44 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
             const float4 q = *reinterpret_cast<const float4*>(gpart + (size_t)(first + c2) * H + f);
             g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
           }
-          // the two aggregated input rows of cluster v -> this wave's scratch (LDS executes a wave's operations
-          // in order: the lanes below read what these lanes wrote)
-          float* zw = zs + wave * 2 * H;
-          *reinterpret_cast<float4*>(zw + f) = g;          // z1 = sum_i alpha_i x_i
-          *reinterpret_cast<float4*>(zw + H + f) = a;      // z2 = sum_u norm_uv xv_u
+          // the two aggregated input rows of cluster v go through this wave's H-word scratch one after the other
+          // (LDS executes a wave's operations in order: the lanes below read what these lanes wrote, and the
+          // second row lands after the first has been read)
+          z1r = g;                                         // z1 = sum_i alpha_i x_i
+          z2r = a;                                         // z2 = sum_u norm_uv xv_u
         }
         {
-          const float* zw = zs + wave * 2 * H;
+          float* zw = zs + wave * H;
           const float* Ws = W + H * H;                     // Wt_src[k][o]
           const float* Wv = W + 3 * H * H;                 // Wt_vv[k][o]
-          for (int o = lane; o < H; o += 64) {
-            float og = 0.f, ov_ = 0.f;
+          float og[(H + 63) / 64], ov_[(H + 63) / 64];
 #pragma unroll
-            for (int k4 = 0; k4 < H / 4; ++k4) {
-              const float4 z1 = *reinterpret_cast<const float4*>(zw + 4 * k4);
-              const float4 z2 = *reinterpret_cast<const float4*>(zw + H + 4 * k4);
-              og = fmaf(z1.x, Ws[(4 * k4 + 0) * H + o], og);
-              og = fmaf(z1.y, Ws[(4 * k4 + 1) * H + o], og);
-              og = fmaf(z1.z, Ws[(4 * k4 + 2) * H + o], og);
-              og = fmaf(z1.w, Ws[(4 * k4 + 3) * H + o], og);
-              ov_ = fmaf(z2.x, Wv[(4 * k4 + 0) * H + o], ov_);
-              ov_ = fmaf(z2.y, Wv[(4 * k4 + 1) * H + o], ov_);
-              ov_ = fmaf(z2.z, Wv[(4 * k4 + 2) * H + o], ov_);
-              ov_ = fmaf(z2.w, Wv[(4 * k4 + 3) * H + o], ov_);
+          for (int pass = 0; pass < 2; ++pass) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (the previous pass's reads are done)
+            if (slot == 0) *reinterpret_cast<float4*>(zw + f) = pass == 0 ? z1r : z2r;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the row is in LDS before any lane reads it
+            const float* Wm = pass == 0 ? Ws : Wv;
+#pragma unroll
+            for (int oi = 0; oi < (H + 63) / 64; ++oi) {
+              const int o = lane + 64 * oi;
+              float acc_ = 0.f;
+              if (o < H) {
+#pragma unroll
+                for (int k4 = 0; k4 < H / 4; ++k4) {
+                  const float4 z = *reinterpret_cast<const float4*>(zw + 4 * k4);
+                  acc_ = fmaf(z.x, Wm[(4 * k4 + 0) * H + o], acc_);
+                  acc_ = fmaf(z.y, Wm[(4 * k4 + 1) * H + o], acc_);
+                  acc_ = fmaf(z.z, Wm[(4 * k4 + 2) * H + o], acc_);
+                  acc_ = fmaf(z.w, Wm[(4 * k4 + 3) * H + o], acc_);
+                }
+              }
+              if (pass == 0) og[oi] = acc_; else ov_[oi] = acc_;
             }
-            xvb[v * H + o] = fmaxf((ov_ + b_vv[o]) + (og + b_gat[o]), 0.f);
+          }
+#pragma unroll
+          for (int oi = 0; oi < (H + 63) / 64; ++oi) {
+            const int o = lane + 64 * oi;
+            if (o < H) xvb[v * H + o] = fmaxf((ov_[oi] + b_vv[o]) + (og[oi] + b_gat[o]), 0.f);
           }
         }
       }
@@ -1113,7 +1129,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       pooled[lane] = s;
       A.pooled[(size_t)g * H + lane] = s;
     }
-    // one wave: its LDS writes are visible to its own later reads
+    // one wave: its LDS writes are visible to its own later reads (wavefront fences pin the order for the compiler)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane < H) {
       float a1 = 0.f;
       const float4* wr = reinterpret_cast<const float4*>(headw + lane * H);
@@ -1133,6 +1150,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     }
     const float* W2l = headw + H * H + H;
     const float* b2l = W2l + A.C * H;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // zz (written by lanes < H just above) before it is read
     for (int c = lane; c < A.C; c += 64) {
       float a2 = 0.f;
       const float4* wr = reinterpret_cast<const float4*>(W2l + c * H);
