@@ -54,7 +54,7 @@ _SIGNATURES = {
     "hscn_build_hetero_count": (c_int, [P, c_int, P, P, c_int64, c_int, c_int, P, P, P, P, P]),
     "hscn_build_hetero_scan": (c_int, [P, c_int64, P, P, P, P, P, P, P]),
     "hscn_build_hetero_emit": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, c_int64, c_int64, P, P, P, P, P]),
-    "hscn_collate_gather": (c_int, [P, P, c_int64, P, P, P]),
+    "hscn_collate_gather": (c_int, [P, P, c_int64, P, P, P, P]),
     "hscn_criterion_fwd": (c_int, [P, P, c_int64, c_int, P, P, P, P]),
     "hscn_scale": (c_int, [P, P, P, c_int64, P]),
     "hscn_scn_resident_supported": (c_int, [c_int] * 5),

@@ -86,6 +86,8 @@ class DeviceHeteroDataset:
             {"local": int(sizes["local"].max()), "virtual": int(sizes["virtual"].max())},
             {et: int(esizes[et].max()) if esizes[et].numel() else 0 for et in _RELS}, self.F, self.C)
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._perm: Optional[Tensor] = None
+        self._cursor: Optional[Tensor] = None
         t = self._t
         p = _hip.ptr
         self._ds = _Dataset(p(t["x_local"]), p(t["x_virtual"]), p(t["y"]), p(t["nptr"]), p(t["vptr"]),
@@ -111,7 +113,30 @@ class DeviceHeteroDataset:
         if ids.dtype != torch.int64 or ids.device != self.device or ids.numel() != self.batch_size:
             raise ValueError(f"ids must be int64 [{self.batch_size}] on {self.device}")
         _hip.call("hscn_collate_gather", ctypes.byref(self._ds), _hip.ptr(ids.contiguous()), self.batch_size,
-                  ctypes.byref(self._out), _hip.ptr(self.flag), _hip.stream())
+                  ctypes.byref(self._out), _hip.ptr(self.flag), None, _hip.stream())
+        return self.static.batch
+
+    # ---- an epoch that walks by itself: the permutation and a batch counter live on the device ----------------
+    def new_epoch(self, generator: Optional[torch.Generator] = None) -> Tensor:
+        """Draw the epoch's permutation into the dataset's own buffer and rewind the batch counter.  Returns the
+        permutation (a device tensor; ``gather_next`` serves its first ``num_graphs // batch_size`` slices)."""
+        if self._perm is None:
+            # (one spare batch of valid ids behind the permutation: a replay too many reads those, not stray memory)
+            self._perm_buf = torch.zeros(self.num_graphs + self.batch_size, dtype=torch.int64, device=self.device)
+            self._perm = self._perm_buf[: self.num_graphs]
+            self._cursor = torch.zeros(1, dtype=torch.int32, device=self.device)
+        torch.randperm(self.num_graphs, device=self.device, generator=generator, out=self._perm)
+        self._cursor.zero_()
+        return self._perm
+
+    def gather_next(self) -> HeteroBatch:
+        """Gather the next batch of the current epoch's permutation and advance the device-side counter: two
+        launches with no host argument that changes from step to step, so they can be CAPTURED in front of the
+        training step (``CapturedStep(..., pre=ds.gather_next)``) -- a replay is then "next batch + iteration"."""
+        if self._perm is None:
+            raise RuntimeError("call new_epoch() first")
+        _hip.call("hscn_collate_gather", ctypes.byref(self._ds), _hip.ptr(self._perm), self.batch_size,
+                  ctypes.byref(self._out), _hip.ptr(self.flag), _hip.ptr(self._cursor), _hip.stream())
         return self.static.batch
 
     def check(self) -> None:

@@ -156,8 +156,11 @@ class CapturedStep:
     they keep the parameters' gradient-accumulation nodes alive, bound to the stream those steps ran on,
     and autograd would then tie the capture to that (non-capturing) stream."""
 
-    def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None):
-        """``optimizer``: a ``torch.optim`` optimizer built with ``capturable=True`` (``fused=True`` keeps it to one
+    def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None, pre=None):
+        """``pre``: a callable captured in front of the step that refreshes the static buffers from device-side
+        state only (``DeviceHeteroDataset.gather_next``); note that the warm-up iterations and the capture call
+        it too (rewind with ``new_epoch`` afterwards).
+        ``optimizer``: a ``torch.optim`` optimizer built with ``capturable=True`` (``fused=True`` keeps it to one
         launch); its ``step()`` is captured behind the backward, so a replay is a whole training iteration.
         The ``warmup`` eager iterations that precede the capture run the optimizer too (PyTorch's whole-network
         capture recipe); parameters and optimizer state are put back afterwards, IN PLACE (the captured launches
@@ -174,6 +177,8 @@ class CapturedStep:
             raise ValueError("the static batch carries no targets")
 
         def step():
+            if pre is not None:
+                pre()
             for p in model.parameters():
                 p.grad = None
             pred = model(hb.x_dict, hb.edge_index_dict, hb)

@@ -51,8 +51,10 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
     gen = torch.Generator(device=dev).manual_seed(seed)
     model.train()
     model.engine = "resident"
-    ds.gather(torch.arange(B, device=dev))
-    step = CapturedStep(model, ds.static, training_cfg.loss_fn, optimizer=optimizer if in_graph else None)
+    ds.new_epoch(gen)
+    # the gather of the next permutation slice is captured in front of the step: a replay = next batch + iteration
+    step = CapturedStep(model, ds.static, training_cfg.loss_fn, optimizer=optimizer if in_graph else None,
+                        pre=ds.gather_next)
     opt_graph = None
     if reducer is not None and capturable:
         opt_graph = _capture_optimizer_step(model, optimizer, step)
@@ -65,11 +67,10 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
     for epoch in range(training_cfg.epochs):
         start = time.time()
         model.train()
-        perm = torch.randperm(G, device=dev, generator=gen)
+        perm = ds.new_epoch(gen)               # permutation + batch counter on the device
         if not in_graph:
             step.bind_grads()                  # (the eager tail of the previous epoch re-pointed p.grad)
         for i in range(steps):
-            ds.gather(perm[i * B:(i + 1) * B])
             step.replay()
             if reducer is not None:
                 reducer.reduce(float(B), float(B * reducer.world_size))

@@ -275,7 +275,11 @@ int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t num_edges,
  * reference's edge_index), int64 / int32 per-graph segment tables -- into fixed-capacity buffers, bit for bit
  * what Batch.from_data_list produces for that list of graphs.  One launch, no host synchronisation.
  * Relations in the order ll, vv, lv (source type local, virtual, local; target type local, virtual, virtual).
- * flag bit 8: an id outside [0, G) or a batch beyond a capacity (the offending part is not written). */
+ * flag bit 8: an id outside [0, G) or a batch beyond a capacity (the offending part is not written).
+ * cursor (optional, device int32): the batch is ids[cursor[0]*B .. +B) -- `ids` is then a whole epoch's
+ * permutation -- and a one-thread launch behind the gather increments it, so a captured sequence of launches
+ * walks through the epoch by itself, one slice per replay (the caller re-fills `ids` and zeroes the cursor
+ * between epochs and must not replay past the permutation's end). */
 typedef struct hscn_hetero_dataset {
   const float* x_local;    /* [N,F] */
   const float* x_virtual;  /* [V,F] */
@@ -298,7 +302,8 @@ typedef struct hscn_hetero_batch_out {
   int64_t ncap, vcap, ecap[3];
 } hscn_hetero_batch_out;
 int hscn_collate_gather(const hscn_hetero_dataset* dataset, const int64_t* ids /*[B] device*/, int64_t B,
-                        const hscn_hetero_batch_out* out, int32_t* flag, void* stream);
+                        const hscn_hetero_batch_out* out, int32_t* flag, int32_t* cursor /*device [1] or NULL*/,
+                        void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Loss tail (reference graph_hscn/loss.py:6-19, called at train/train.py:82) on the

@@ -137,3 +137,35 @@ def test_captured_training_iterations_with_the_optimizer_equal_the_eager_loop():
         step.replay()
     for (n, a), (_, b) in zip(m_eager.named_parameters(), m_graph.named_parameters()):
         assert torch.equal(a, b), n
+
+
+def test_self_walking_epoch_equals_explicit_gathers():
+    """gather_next captured in front of the step (permutation + batch counter on the device): the sequence of
+    replays sees exactly the batches perm[0:B], perm[B:2B], ... -- same losses, same final gradients as explicit
+    gathers of those slices."""
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.loader.device_dataset import DeviceHeteroDataset
+    from graph_hscn.model.hscn import HSCN
+    from graph_hscn.replay import CapturedStep
+    G, B = 50, 8
+    hs = _dataset(G, 8, seed=11)
+    ds = DeviceHeteroDataset(hs, DEV, B)
+    torch.manual_seed(0)
+    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, 10, 3).to(DEV)
+    model.engine = "resident"
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    ds.new_epoch(gen)
+    walk = CapturedStep(model, ds.static, "cross_entropy", pre=ds.gather_next)
+    plain = CapturedStep(model, ds.static, "cross_entropy")
+    for epoch in range(2):
+        perm = ds.new_epoch(gen).clone()
+        got = []
+        for i in range(G // B):
+            got.append(walk.replay().clone())
+        want = []
+        for i in range(G // B):
+            ds.gather(perm[i * B:(i + 1) * B])
+            want.append(plain.replay().clone())
+        assert torch.equal(torch.stack(got), torch.stack(want))
+        assert len({float(x) for x in got}) > 1            # (different batches, not one batch six times)
+    ds.check()

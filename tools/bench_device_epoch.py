@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Epochs over an HBM-resident hetero dataset: per step one permutation slice (device tensor) -> one gather
-launch (hscn_collate_gather) -> one replay of the captured training step.  Shuffled batches every epoch, no host
+"""Epochs over an HBM-resident hetero dataset: the permutation and a batch counter live on the device, the gather
+of the next slice (hscn_collate_gather) is captured in front of the training step: per step ONE graph replay.  Shuffled batches every epoch, no host
 collate, no PCIe traffic.  Prints graphs/s over whole epochs and the dataset's footprint."""
 import json
 import os
@@ -36,17 +36,15 @@ def main(G=4096, B=128, K=16, epochs=5):
     model.engine = "resident"
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=True)
     gen = torch.Generator(device=dev).manual_seed(0)
-    perm = torch.randperm(G, device=dev, generator=gen)
-    ds.gather(perm[:B])
-    step = CapturedStep(model, ds.static, "cross_entropy")
-    step_opt = CapturedStep(model, ds.static, "cross_entropy", optimizer=opt)   # AdamW captured behind the backward
+    ds.new_epoch(gen)
+    step = CapturedStep(model, ds.static, "cross_entropy", pre=ds.gather_next)     # gather + step in one graph
+    step_opt = CapturedStep(model, ds.static, "cross_entropy", optimizer=opt, pre=ds.gather_next)   # + AdamW
     steps = G // B
 
     def epoch(with_opt):
-        perm = torch.randperm(G, device=dev, generator=gen)
+        ds.new_epoch(gen)
         st = step_opt if with_opt else step
         for i in range(steps):
-            ds.gather(perm[i * B:(i + 1) * B])
             st.replay()
 
     out = {"graphs": G, "graphs_per_batch": B, "dataset_bytes": ds.nbytes, "static_buffer_bytes": ds.static.nbytes,
