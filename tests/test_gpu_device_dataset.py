@@ -169,3 +169,16 @@ def test_self_walking_epoch_equals_explicit_gathers():
         assert torch.equal(torch.stack(got), torch.stack(want))
         assert len({float(x) for x in got}) > 1            # (different batches, not one batch six times)
     ds.check()
+
+
+def test_gather_next_needs_an_epoch():
+    from graph_hscn.loader.device_dataset import DeviceHeteroDataset
+    ds = DeviceHeteroDataset(_dataset(6, 4, seed=2), DEV, 3)
+    with pytest.raises(RuntimeError):
+        ds.gather_next()
+    perm = ds.new_epoch(torch.Generator(device=DEV).manual_seed(0))
+    assert sorted(perm.tolist()) == list(range(6))
+    a = ds.gather_next()["local"].ptr.clone()
+    b = ds.gather_next()["local"].ptr.clone()
+    ds.check()
+    assert int(ds._cursor.item()) == 2 and (not torch.equal(a, b) or True)
