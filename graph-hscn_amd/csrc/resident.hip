@@ -75,6 +75,7 @@ struct FwdArgs {
   float *vs_dinv_v, *vs_xv;
   int spec;  // 1: ll path and virtual branch run concurrently on two wave groups (needs a 3rd n x H buffer)
   int exp;   // 1: this launch also builds + exports the source-keyed ll CSR (needs LDS for it)
+  int db;        // 1: two weight buffers in LDS (the next layer's weights land under this layer's math)
   int exp_dinv;  // 1: this launch exports the ll degree norm (the workgroup that builds ll keyed by target has it)
   float slope;
 };
@@ -414,7 +415,7 @@ struct FwdLayout {
   size_t ek_ll, eo_ll, ek_lv, eo_lv, ek_vv, eo_vv, total;
 };
 __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max_v, int max_ell, int max_evv,
-                                                int spec, int exp) {
+                                                int db, int exp) {
   FwdLayout Y;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };  // keep 16-B alignment
@@ -450,7 +451,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   Y.sc = take(max_n);
   Y.dinv = take(max_n);
   Y.dinv_v = take(max_v);
-  Y.wt = take((size_t)(H <= 16 ? 2 : 1) * (4 * H * H + 5 * H));  // layer weights (double-buffered when small)
+  Y.wt = take((size_t)(db ? 2 : 1) * (4 * H * H + 5 * H));  // layer weights (double-buffered when LDS allows)
   Y.headw = take((size_t)H * H + H + (size_t)C * H + C);
   Y.part = take((size_t)(RT_MAX / 64) * H);           // one H-vector per wave (pool partials)
   Y.vec = take(128);
@@ -511,7 +512,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       }
     return;
   }
-  const FwdLayout Y = fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec, A.exp);
+  const FwdLayout Y = fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.db, A.exp);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   float *xa = fb + Y.xa, *bh = fb + Y.bh, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *zs = fb + Y.zs;
@@ -781,7 +782,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     for (int i = threadIdx.x; i < nel; i += RT) col_lv[i] = A.vs_col_lv[(size_t)el0 + i];
     for (int i = threadIdx.x; i < nev; i += RT) col_vv[i] = A.vs_col_vv[(size_t)ev0 + i];
     for (int i = threadIdx.x; i < nv; i += RT) dinv_v[i] = A.vs_dinv_v[(size_t)v0 + i];
-    ws.store(wt + ((H <= 16) ? (A.l_begin & 1) * WSZ : 0));
+    ws.store(wt + (A.db ? (A.l_begin & 1) * WSZ : 0));
     lds_barrier();
     if (wave == 0) build_chunk_table();
     lds_barrier();
@@ -789,7 +790,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   STAMP(3);
 
   for (int l = A.l_begin; l < A.l_end; ++l) {
-    constexpr bool DB = H <= 16;               // two weight buffers: the next layer's land under this layer's math
+    const bool DB = A.db != 0;                 // two weight buffers: the next layer's land under this layer's math
     float* W = wt + (DB ? (l & 1) * WSZ : 0);
     float* Wn = wt + (DB ? ((l + 1) & 1) * WSZ : 0);
     const float* b_ll = W + 4 * H * H;
@@ -1580,8 +1581,13 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd_virtual(const BwdArgs Ab, const
   else hscn_bwd_body<H, RT>(Ab, g);
 }
 
-inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int spec, int exp) {
-  return fwd_layout(H, C, max_n, max_v, max_ell, max_evv, spec, exp).total * 4;
+inline size_t fwd_lds_bytes(int H, int C, int max_n, int max_v, int max_ell, int max_evv, int db, int exp) {
+  return fwd_layout(H, C, max_n, max_v, max_ell, max_evv, db, exp).total * 4;
+}
+// double-buffered layer weights whenever the launch still fits a CU's LDS with them (H = 64: never, 64 KB)
+inline size_t pick_fwd_lds(FwdArgs& A, int H) {
+  A.db = (H <= 32 && fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, 1, A.exp) <= 160 * 1024) ? 1 : 0;
+  return fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.db, A.exp);
 }
 inline size_t bwd_lds_bytes(int H, int C, int max_n, int max_ell, int two) {
   return bwd_layout(H, C, max_n, max_ell, two).total * 4;
@@ -1650,13 +1656,12 @@ int launch_fwd(FwdArgs& A, int64_t B, hipStream_t st) {
   // preference order: concurrent wave groups + CSR export, then dropping the third n x H buffer,
   // then dropping the in-launch export (a separate light kernel builds it)
   const bool want_exp = A.csr_rowptr_t != nullptr;
-  const int tries[3][2] = {{1, 1}, {0, 1}, {0, 0}};
   size_t lds = 0;
   bool ok = false;
-  for (int t = 0; t < 3 && !ok; ++t) {
-    A.spec = (A.compute_virtual && tries[t][0]) ? 1 : 0;
-    A.exp = (want_exp && tries[t][1]) ? 1 : 0;
-    lds = fwd_lds_bytes(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.spec, A.exp);
+  A.spec = A.compute_virtual ? 1 : 0;       // (the side-by-side wave groups cost no LDS any more)
+  for (int e = 1; e >= 0 && !ok; --e) {
+    A.exp = (want_exp && e) ? 1 : 0;
+    lds = pick_fwd_lds(A, H);
     ok = lds <= 160 * 1024;
   }
   if (!ok) return HSCN_E_UNSUPPORTED;
@@ -1710,13 +1715,11 @@ int launch_bwd_virtual(BwdArgs& Ab, FwdArgs& Af, int64_t B, hipStream_t st) {
   const size_t lb = pick_bwd_lds(Ab, H);
   size_t lf = 0;
   bool ok = false;
-  for (int spec = 1; spec >= 0 && !ok; --spec) {
-    Af.spec = spec;
-    Af.exp = 0;
-    Af.exp_dinv = 0;
-    lf = fwd_lds_bytes(H, Af.C, Af.max_n, Af.max_v, Af.max_ell, Af.max_evv, spec, 0);
-    ok = lf <= 160 * 1024;
-  }
+  Af.spec = 1;
+  Af.exp = 0;
+  Af.exp_dinv = 0;
+  lf = pick_fwd_lds(Af, H);
+  ok = lf <= 160 * 1024;
   if (!ok || lb > 160 * 1024) return HSCN_E_UNSUPPORTED;
   const size_t lds = lb > lf ? lb : lf;
   if (Ab.max_n <= 64) return launch_bwd_virtual_rt<H, 256>(Ab, Af, B, lds, st);
@@ -1760,7 +1763,7 @@ int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, cons
   A.csr_rowptr_t = csr_rowptr_t; A.csr_col_t = csr_col_t; A.dinv_out = dinv_out;
   A.N = N; A.V = V; A.F = F; A.L = L; A.C = C; A.head_act = head_act;
   A.max_n = max_n; A.max_v = max_v; A.max_ell = vonly ? 0 : max_ell; A.max_evv = max_evv;
-  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0; A.exp_dinv = 0;
+  A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0; A.exp_dinv = 0; A.db = 0;
   A.l_begin = 0; A.l_end = L;
   A.vs_rowptr_lv = A.vs_col_lv = A.vs_rowptr_vv = A.vs_col_vv = nullptr;
   A.vs_dinv_v = A.vs_xv = nullptr;
@@ -1799,24 +1802,22 @@ int launch_fwd_pair(FwdArgs& Al, FwdArgs& Av, int64_t B, hipStream_t st) {
   bool ok = false;
   // (a virtual-only workgroup is sized without ll edges unless it takes this job: Al.max_ell is the real bound)
   const bool v_can = want_exp && Av.ll_src && Av.csr_rowptr_t &&
-                     fwd_lds_bytes(H, Av.C, Av.max_n, Av.max_v, Al.max_ell, Av.max_evv, 1, 1) <= 160 * 1024;
+                     fwd_lds_bytes(H, Av.C, Av.max_n, Av.max_v, Al.max_ell, Av.max_evv, 0, 1) <= 160 * 1024;
   Av.max_ell = v_can ? Al.max_ell : 0;
   for (int e = 1; e >= 0 && !ok; --e) {
     Al.spec = 0;
     Al.exp = (want_exp && e && !v_can) ? 1 : 0;
-    ll = fwd_lds_bytes(H, Al.C, Al.max_n, Al.max_v, Al.max_ell, Al.max_evv, 0, Al.exp);
+    ll = pick_fwd_lds(Al, H);
     ok = ll <= 160 * 1024;
   }
   if (!ok) return HSCN_E_UNSUPPORTED;
   Al.exp_dinv = (Al.exp || v_can) ? 1 : 0;
   ok = false;
-  for (int spec = 1; spec >= 0 && !ok; --spec) {
-    Av.spec = spec;
-    Av.exp = v_can ? 1 : 0;
-    Av.exp_dinv = 0;
-    lv = fwd_lds_bytes(H, Av.C, Av.max_n, Av.max_v, Av.max_ell, Av.max_evv, spec, Av.exp);
-    ok = lv <= 160 * 1024;
-  }
+  Av.spec = 1;
+  Av.exp = v_can ? 1 : 0;
+  Av.exp_dinv = 0;
+  lv = pick_fwd_lds(Av, H);
+  ok = lv <= 160 * 1024;
   if (!ok) return HSCN_E_UNSUPPORTED;
   if (!v_can) { Av.ll_src = nullptr; Av.ll_dst = nullptr; }
   const size_t lds = ll > lv ? ll : lv;
