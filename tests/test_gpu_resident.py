@@ -329,3 +329,25 @@ def test_wide_model_on_a_large_graph_takes_the_two_buffer_backward():
         for k in go:
             assert close(gd[k], go[k], atol=2e-4, rtol=1e-3), (eng, k)
     pb._resident_meta.check()
+
+
+@pytest.mark.timeout(120)
+def test_understated_batch_maxima_raise_the_flag_and_nothing_hangs():
+    """A batch whose per-graph maxima (the host ints that size the launches' LDS) are too small: the workgroups of
+    the offending graphs bail out, raise flag bit 4 and leave EMPTY structure behind, so the launches that consume
+    their exports (the backward, the resumed virtual branch) terminate; ``check()`` reports it."""
+    from graph_hscn.loss import criterion
+    _, pb = _batches("peptides_func", 6, 8, seed=2)
+    _, pm = _models(9, 16, 10, 3)
+    pm.engine = "resident"
+    for field, types in (("max_nodes", ("virtual",)), ("max_nodes", ("local",)), ("max_edges", (("local", "to", "local"),))):
+        d = pb.to(DEV)
+        for t in types:
+            setattr(d[t], field, max(1, getattr(d[t], field) // 2))          # half of the real maximum
+        pm.zero_grad(set_to_none=True)
+        pred = pm(d.x_dict, d.edge_index_dict, d)
+        loss, _ = criterion("cross_entropy", pred, d["local"].y)
+        loss.backward()
+        torch.cuda.synchronize()                                             # both launches of the step came back
+        with pytest.raises(ValueError):
+            d._resident_meta.check()
