@@ -108,8 +108,8 @@ class LazyLoss(torch.Tensor):
         from torch.utils._pytree import tree_map
         if func in (torch.ops.aten.detach.default, torch.ops.aten.alias.default):
             return LazyLoss(args[0].state, args[0].device)
-        if func is torch.ops.aten.ones_like.default:
-            return _one(args[0].device)
+        if func is torch.ops.aten.ones_like.default and (kwargs or {}).get("dtype") in (None, torch.float32):
+            return _one(args[0].device)        # (the implicit root gradient of loss.backward())
         un = lambda t: t.state.get() if isinstance(t, LazyLoss) else t
         return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
 
