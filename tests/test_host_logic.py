@@ -184,3 +184,32 @@ def test_mpnn_config_and_factory():
         build_mpnn(MPNNConfig("gcn", "relu", use_layer_norm=True), 9, 10)
     with pytest.raises(KeyError):
         build_mpnn(MPNNConfig("gin", "relu"), 9, 10)          # GINConv(dim, dim) is a TypeError in PyG
+
+
+def test_static_batch_buffers_pack_and_load_on_the_host():
+    """replay.StaticHeteroBatch is plain tensor bookkeeping: capacities are the maxima over the batches, every
+    field is a view of one flat buffer, pack() + load() reproduce a batch inside the valid ranges, and a batch
+    beyond a capacity is refused."""
+    from graph_hscn.replay import LL, LV, VV, StaticHeteroBatch
+    graphs = make_dataset("peptides_func", 12, seed=4)
+    rng = np.random.default_rng(0)
+    hs = [hetero_from_clusters(g, rng.integers(0, 8, g.num_nodes), 8) for g in graphs]
+    batches = [HeteroBatch.from_data_list(hs[i:i + 4]) for i in (0, 4, 8)]
+    st = StaticHeteroBatch(batches, "cpu")
+    assert st.N == max(b["local"].num_nodes for b in batches) and st.num_graphs == 4
+    assert st.flat.dtype == torch.uint8 and st.flat.numel() == st.nbytes
+    for b in batches:
+        flat = st.pack(b)
+        hb = st.load(flat)
+        n, v = b["local"].num_nodes, b["virtual"].num_nodes
+        assert torch.equal(hb["local"].x[:n], b["local"].x.float()) and torch.equal(hb["virtual"].x[:v], b["virtual"].x)
+        assert torch.equal(hb["local"].ptr32, b["local"].ptr32) and torch.equal(hb["local"].y, b["local"].y.float())
+        for et in (LL, VV, LV):
+            e = b[et].edge_index.size(1)
+            assert torch.equal(hb[et].edge_index[:, :e], b[et].edge_index) and torch.equal(hb[et].ptr32, b[et].ptr32)
+        assert hb["local"].x.data_ptr() == st.batch["local"].x.data_ptr()        # same buffers every time
+    big = HeteroBatch.from_data_list(hs[:4] + hs[4:8])
+    with pytest.raises(ValueError):
+        st.load(big)                                                             # 8 graphs into 4-graph buffers
+    with pytest.raises(ValueError):
+        st.load(torch.zeros(3, dtype=torch.uint8))
