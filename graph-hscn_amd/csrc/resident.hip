@@ -486,7 +486,11 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   return Y;
 }
 
-template <int H, int RT>
+// MODE: 0 = what the arguments say; 1 = local chain + head only (compute_virtual == 0), 2 = virtual branch only
+// (compute_virtual == 2) known at compile time -- the two workgroup programs of the paired launches are compiled
+// as their own specialisations, so each fetches only the code of its own path (the generic body is 75 KB of ISA
+// against a 64 KB instruction cache shared by two CUs, and a workgroup runs its program once per launch).
+template <int H, int RT, int MODE = 0>
 __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int OPT = Blk<H>::OPT;
@@ -494,7 +498,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   constexpr int WSZ = 4 * H * H + 5 * H;
   const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
-  const bool vonly = A.compute_virtual == 2;  // virtual branch only: the local activations come from `acts`
+  const bool vonly = MODE == 2 || (MODE == 0 && A.compute_virtual == 2);  // virtual branch only: the local activations come from `acts`
   // (a virtual-only workgroup touches the ll edges only when it builds the source-keyed CSR for the backward)
   const int e0 = A.eptr_ll[g], ne = (vonly && !A.exp) ? 0 : A.eptr_ll[g + 1] - e0;
   const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
@@ -523,7 +527,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   int* wsum = ib + Y.wsum;
   int *ck_tab = ib + Y.ck_tab, *ck_first = ib + Y.ck_first, *ck_arrive = ib + Y.ck_arrive;
   float* gpart = fb + Y.gpart;
-  const bool cv = A.compute_virtual != 0;
+  const bool cv = MODE == 2 || (MODE == 0 && A.compute_virtual != 0);
   const int F = A.F;
 
   // wave groups: with the virtual branch on, the upper half of the waves works on it
@@ -1186,7 +1190,8 @@ struct FwdPair {
 template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_fwd_pair(const FwdPair P) {
   // one copy of the body, the argument block (in the kernarg segment) chosen by the parity of the workgroup
-  hscn_fwd_body<H, RT>(P.a[blockIdx.x & 1], blockIdx.x >> 1);
+  if (blockIdx.x & 1) hscn_fwd_body<H, RT, 2>(P.a[1], blockIdx.x >> 1);
+  else hscn_fwd_body<H, RT, 1>(P.a[0], blockIdx.x >> 1);
 }
 
 // =============================== backward =====================================================
@@ -1577,7 +1582,7 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
 template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_bwd_virtual(const BwdArgs Ab, const FwdArgs Af) {
   const int g = blockIdx.x >> 1;
-  if (blockIdx.x & 1) hscn_fwd_body<H, RT>(Af, g);
+  if (blockIdx.x & 1) hscn_fwd_body<H, RT, 2>(Af, g);
   else hscn_bwd_body<H, RT>(Ab, g);
 }
 
