@@ -487,7 +487,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
 }
 
 // MODE: 0 = what the arguments say; 1 = local chain + head only (compute_virtual == 0), 2 = virtual branch only
-// (compute_virtual == 2) known at compile time -- the two workgroup programs of the paired launches are compiled
+// (compute_virtual == 2), 3 = both branches (compute_virtual == 1) known at compile time -- the two workgroup programs of the paired launches are compiled
 // as their own specialisations, so each fetches only the code of its own path (the generic body is 75 KB of ISA
 // against a 64 KB instruction cache shared by two CUs, and a workgroup runs its program once per launch).
 template <int H, int RT, int MODE = 0>
@@ -527,7 +527,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   int* wsum = ib + Y.wsum;
   int *ck_tab = ib + Y.ck_tab, *ck_first = ib + Y.ck_first, *ck_arrive = ib + Y.ck_arrive;
   float* gpart = fb + Y.gpart;
-  const bool cv = MODE == 2 || (MODE == 0 && A.compute_virtual != 0);
+  const bool cv = MODE >= 2 || (MODE == 0 && A.compute_virtual != 0);
   const int F = A.F;
 
   // wave groups: with the virtual branch on, the upper half of the waves works on it
@@ -1176,9 +1176,9 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   STAMP(63);
 }
 
-template <int H, int RT>
+template <int H, int RT, int MODE>
 __global__ void __launch_bounds__(RT) k_hscn_fwd(const FwdArgs A) {
-  hscn_fwd_body<H, RT>(A, blockIdx.x);
+  hscn_fwd_body<H, RT, MODE>(A, blockIdx.x);
 }
 
 // One launch, two kinds of workgroup: even blocks run the local chain + head of graph g, odd blocks
@@ -1610,14 +1610,21 @@ inline size_t pick_bwd_lds(BwdArgs& A, int H) {
 
 // Workgroup size: 16 waves (4 per SIMD) hide the LDS / global latency of the many short
 // phases; tiny graphs (PCQM-Contact, n <= 64) do not have the rows to feed them.
-template <int H, int RT>
-int launch_fwd_rt(const FwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
+template <int H, int RT, int MODE>
+int launch_fwd_mode(const FwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)k_hscn_fwd<H, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)k_hscn_fwd<H, RT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-  k_hscn_fwd<H, RT><<<(unsigned)B, RT, lds, st>>>(A);
+  k_hscn_fwd<H, RT, MODE><<<(unsigned)B, RT, lds, st>>>(A);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+template <int H, int RT>
+int launch_fwd_rt(const FwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
+  // one specialisation of the body per value of compute_virtual (see hscn_fwd_body: MODE)
+  if (A.compute_virtual == 0) return launch_fwd_mode<H, RT, 1>(A, B, lds, st);
+  if (A.compute_virtual == 2) return launch_fwd_mode<H, RT, 2>(A, B, lds, st);
+  return launch_fwd_mode<H, RT, 3>(A, B, lds, st);
 }
 // Source-keyed ll CSR + degree norm for the backward launch when the forward launch had no LDS
 // left to build them on the side (large graphs): a light kernel of its own, one workgroup per graph.
