@@ -487,7 +487,8 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
 }
 
 // MODE: 0 = what the arguments say; 1 = local chain + head only (compute_virtual == 0), 2 = virtual branch only
-// (compute_virtual == 2), 3 = both branches (compute_virtual == 1) known at compile time -- the two workgroup programs of the paired launches are compiled
+// (compute_virtual == 2) from its beginning, 4 = virtual branch only, resumed at layer l_begin > 0 from exported
+// state, 3 = both branches (compute_virtual == 1) known at compile time -- the two workgroup programs of the paired launches are compiled
 // as their own specialisations, so each fetches only the code of its own path (the generic body is 75 KB of ISA
 // against a 64 KB instruction cache shared by two CUs, and a workgroup runs its program once per launch).
 template <int H, int RT, int MODE = 0>
@@ -498,7 +499,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   constexpr int WSZ = 4 * H * H + 5 * H;
   const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
-  const bool vonly = MODE == 2 || (MODE == 0 && A.compute_virtual == 2);  // virtual branch only: the local activations come from `acts`
+  const bool vonly = MODE == 2 || MODE == 4 || (MODE == 0 && A.compute_virtual == 2);  // virtual branch only: the local activations come from `acts`
   // (a virtual-only workgroup touches the ll edges only when it builds the source-keyed CSR for the backward)
   const int e0 = A.eptr_ll[g], ne = (vonly && !A.exp) ? 0 : A.eptr_ll[g + 1] - e0;
   const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
@@ -565,7 +566,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   // ---- prologue: request every global input of this graph, then consume -----------------------
   STAMP(0);
   WStage<H, RT> ws;
-  const bool resume = vonly && A.l_begin > 0;
+  const bool resume = MODE == 4 || (MODE == 0 && vonly && A.l_begin > 0);
   if (!resume) {
   constexpr int EPT = 2;   // edges per thread held in registers (covers RT*EPT edges per relation)
   constexpr int XPT = 8;   // feature words per thread held in registers
@@ -1582,7 +1583,10 @@ __global__ void __launch_bounds__(RT) k_hscn_bwd(const BwdArgs A) {
 template <int H, int RT>
 __global__ void __launch_bounds__(RT) k_hscn_bwd_virtual(const BwdArgs Ab, const FwdArgs Af) {
   const int g = blockIdx.x >> 1;
-  if (blockIdx.x & 1) hscn_fwd_body<H, RT, 2>(Af, g);
+  if (blockIdx.x & 1) {
+    if (Af.l_begin > 0) hscn_fwd_body<H, RT, 4>(Af, g);
+    else hscn_fwd_body<H, RT, 2>(Af, g);
+  }
   else hscn_bwd_body<H, RT>(Ab, g);
 }
 
@@ -1623,7 +1627,7 @@ template <int H, int RT>
 int launch_fwd_rt(const FwdArgs& A, int64_t B, size_t lds, hipStream_t st) {
   // one specialisation of the body per value of compute_virtual (see hscn_fwd_body: MODE)
   if (A.compute_virtual == 0) return launch_fwd_mode<H, RT, 1>(A, B, lds, st);
-  if (A.compute_virtual == 2) return launch_fwd_mode<H, RT, 2>(A, B, lds, st);
+  if (A.compute_virtual == 2) return launch_fwd_mode<H, RT, 0>(A, B, lds, st);   // (first part or resumed: run time)
   return launch_fwd_mode<H, RT, 3>(A, B, lds, st);
 }
 // Source-keyed ll CSR + degree norm for the backward launch when the forward launch had no LDS
