@@ -56,6 +56,11 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=1,
                     help="graph mode, one GPU: capture this many consecutive steps in one hipGraph (the gap between two "
                          "replays, ~4 us, is then paid once per group); the timed region is still exactly --steps steps")
+    ap.add_argument("--cluster-ids", default="scn_untrained", choices=["scn_untrained", "uniform"],
+                    help="scn_untrained: argmax of a seeded random-weight SCN (SURVEY.md 8d; collapses to ~3 clusters per "
+                         "graph); uniform: ids drawn uniformly from 0..K-1 (U ~ K virtual nodes per graph, what a trained "
+                         "assignment produces).  The headline line carries the other choice's time as `other_cluster_ids`")
+    ap.add_argument("--no-other-ids", action="store_true", help="skip the second (other --cluster-ids) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming-spmm", action="store_true")
     ap.add_argument("--no-stage-a", action="store_true")
@@ -64,9 +69,9 @@ def parse():
     return ap.parse_args()
 
 
-def build_hetero_batch(workload, B, K, seed, dev):
-    """Synthetic graphs -> cluster ids from a seeded random-weight SCN on the HIP
-    path -> generate_hetero_data transform -> one collated batch on the device."""
+def build_hetero_batch(workload, B, K, seed, dev, cluster_ids="scn_untrained"):
+    """Synthetic graphs -> cluster ids (from a seeded random-weight SCN on the HIP path, or
+    uniform) -> generate_hetero_data transform -> one collated batch on the device."""
     from graph_hscn.data import Batch, HeteroBatch
     from graph_hscn.loader.hetero_data import hetero_from_clusters
     from graph_hscn.loader.synthetic import make_dataset
@@ -76,6 +81,11 @@ def build_hetero_batch(workload, B, K, seed, dev):
 
     graphs = make_dataset(workload, B, seed=seed)
     big = Batch.from_data_list(graphs)
+    if cluster_ids == "uniform":
+        ids = np.random.default_rng(4321 + seed).integers(0, K, big.num_nodes)
+        ptr = big.ptr.numpy()
+        hs = [hetero_from_clusters(g, ids[ptr[i]:ptr[i + 1]], K) for i, g in enumerate(graphs)]
+        return HeteroBatch.from_data_list(hs), graphs, ids
     torch.manual_seed(1234 + seed)
     scn = SCN([16], "elu", graphs[0].num_features, K).to(dev)
     with torch.no_grad():
@@ -173,6 +183,116 @@ def cpu_baseline(hb, args, C, loss_fn, seconds):
             "ms_per_step": 1e3 * dt / n}
 
 
+def capture(fn, warmup=3):
+    """Warm ``fn`` up on a side stream, then capture it as one hipGraph."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
+class TimedStep:
+    """One training step of stage C in the form the run asks for.  ``run(n)`` issues exactly n steps."""
+
+    def __init__(self, args, model, hb, loss_fn, reducer, B, world):
+        from graph_hscn import structure
+        from graph_hscn.loss import criterion
+        from graph_hscn.step import ResidentTrainStep
+        self.args, self.reducer = args, reducer
+        self.fused = None
+        self.multi, self.spg = None, 1
+        y = hb["local"].y
+        x_dict, ei_dict = hb.x_dict, hb.edge_index_dict
+        root_grad = torch.ones((), dtype=torch.float32, device=y.device)   # = loss.backward()'s implicit ones_like(loss)
+
+        def fwd_bwd_autograd():
+            if args.structure == "per-step":
+                structure.clear_cache()
+            for p in model.parameters():
+                p.grad = None
+            pred = model(x_dict, ei_dict, hb)
+            loss, _ = criterion(loss_fn, pred, y)
+            loss.backward(root_grad)
+            return loss
+
+        def reduce():
+            if reducer is not None:
+                reducer.reduce(B, B * world)
+
+        def step_eager():
+            loss = fwd_bwd_autograd()
+            reduce()
+            return loss
+
+        self.step_eager = step_eager
+        if args.mode == "eager":
+            self.loss = step_eager().detach()
+            self.run = lambda n: [step_eager() for _ in range(n)] and None
+            self.in_graph_allreduce = False
+            return
+        # graph mode.  The gradient all-reduce is captured INTO the step's hipGraph (RCCL kernels are capturable): one
+        # replay per step on every rank, no eager collective launch between replays.  HSCN_BENCH_GRAPH_ALLREDUCE=0
+        # issues it eagerly after each replay instead (round 1's default: +12 us per step at one rank).
+        self.in_graph_allreduce = reducer is not None and os.environ.get("HSCN_BENCH_GRAPH_ALLREDUCE", "1") != "0"
+        one = None
+        if args.engine != "layered":
+            try:
+                # the product's replayable step (graph_hscn.step / replay.CapturedStep): the same launches as the
+                # autograd path, issued directly on preallocated buffers -- no autograd engine inside the capture
+                self.fused = ResidentTrainStep(model, hb, loss_fn)
+                self.fused.bind_grads()
+                model.last_engine = "resident"
+                one = self.fused.run
+                self.loss = self.fused.loss
+            except RuntimeError:
+                if args.engine == "resident":
+                    raise
+        if one is None:     # layered operators: the autograd path is what gets captured
+            holder = {}
+
+            def one():
+                holder["loss"] = fwd_bwd_autograd()
+            one()
+            self.loss = None
+        if self.in_graph_allreduce:
+            body = lambda: (one(), reduce())
+        else:
+            body = one
+        graph = capture(body)
+        if self.loss is None:
+            self.loss = holder["loss"].detach()
+        self.spg = args.steps_per_graph if (reducer is None and args.steps_per_graph > 1) else 1
+        if self.spg > 1:
+            self.multi = capture(lambda: [one() for _ in range(self.spg)], warmup=1)
+
+        def run(n):
+            if self.multi is not None:
+                for _ in range(n // self.spg):
+                    self.multi.replay()
+                n %= self.spg
+            for _ in range(n):
+                graph.replay()
+                if reducer is not None and not self.in_graph_allreduce:
+                    reduce()
+        self.run = run
+
+
+def time_steps(ts, steps, warmup, barrier):
+    ts.run(warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ts.run(steps)
+    barrier()
+    return time.perf_counter() - t0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,106 +314,60 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
-    from graph_hscn import _hip, structure
+    from graph_hscn import _hip
     from graph_hscn.config.config import ACT_DICT
     from graph_hscn.distributed import FlatGradReducer
-    from graph_hscn.loss import criterion
     from graph_hscn.model.hscn import HSCN
 
     _hip.lib()
     shape, B0, K, C, loss_fn = WORKLOADS[args.workload]
     B = args.batch or B0
-    hb_host, graphs, _ = build_hetero_batch(shape, B, K, args.seed * 1000 + rank, dev)
+    hb_host, graphs, _ = build_hetero_batch(shape, B, K, args.seed * 1000 + rank, dev, args.cluster_ids)
     hb = hb_host.to(dev)
-    y = hb["local"].y
     F = hb["local"].x.size(1)
     torch.manual_seed(0)  # identical replicas
     model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], F, args.hidden, C, args.layers).to(dev)
     model.engine = args.engine
-    reducer = FlatGradReducer(model, single_rank_collective=force_dist) if (world > 1 or force_dist) else None
-    x_dict, ei_dict = hb.x_dict, hb.edge_index_dict
-    root_grad = torch.ones((), dtype=torch.float32, device=dev)   # = loss.backward()'s implicit ones_like(loss)
-
-    def fwd_bwd():
-        if args.structure == "per-step":
-            structure.clear_cache()
-        for p in model.parameters():
-            p.grad = None
-        pred = model(x_dict, ei_dict, hb)
-        loss, _ = criterion(loss_fn, pred, y)
-        loss.backward(root_grad)
-        return loss
-
-    def step_eager():
-        loss = fwd_bwd()
-        if reducer is not None:
-            reducer.reduce(B, B * world)
-        return loss
-
-    graph = None
-    multi, spg = None, 1
-    if args.mode == "graph":
-        # HSCN_BENCH_GRAPH_ALLREDUCE=1 captures the gradient all-reduce into the step's hipGraph as well
-        # (RCCL kernels are capturable); default: the collective is issued eagerly after each replay
-        in_graph = reducer is not None and os.environ.get("HSCN_BENCH_GRAPH_ALLREDUCE") == "1"
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step_eager() if in_graph else fwd_bwd()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step_eager() if in_graph else fwd_bwd()
-        spg = args.steps_per_graph if (reducer is None and args.steps_per_graph > 1) else 1
-        multi = None
-        if spg > 1:
-            multi = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(multi):
-                for _ in range(spg):
-                    static_loss = fwd_bwd()
-
-        def step():
-            graph.replay()
-            if reducer is not None and not in_graph:
-                reducer.reduce(B, B * world)
-            return static_loss
-    else:
-        step = step_eager
+    # every rank owns B graphs: equal weights, RCCL averages with no scaling launch
+    reducer = (FlatGradReducer(model, single_rank_collective=force_dist, equal_weights=True)
+               if (world > 1 or force_dist) else None)
 
     def barrier():
         if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(nsteps):
-        """exactly nsteps steps: groups of --steps-per-graph through the multi-step graph, the rest one by one"""
-        if args.mode == "graph" and multi is not None:
-            for _ in range(nsteps // spg):
-                multi.replay()
-            nsteps %= spg
-        for _ in range(nsteps):
-            step()
-
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    ts = TimedStep(args, model, hb, loss_fn, reducer, B, world)
+    dt = time_steps(ts, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
     value = B * world * args.steps / dt
+    spg = ts.spg
+    if ts.fused is not None:
+        ts.fused.check()
+
+    # ---- the same step on the OTHER choice of cluster ids (one GPU only): the untrained SCN's argmax collapses to
+    # ~3 clusters per graph, a trained assignment uses ~K -- the virtual branch's share of the step differs
+    other_ids = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_other_ids:
+        oc = "uniform" if args.cluster_ids == "scn_untrained" else "scn_untrained"
+        hb2 = build_hetero_batch(shape, B, K, args.seed * 1000 + rank, dev, oc)[0].to(dev)
+        ts2 = TimedStep(args, model, hb2, loss_fn, None, B, 1)
+        dt2 = time_steps(ts2, args.steps, args.warmup, barrier)
+        other_ids = {"cluster_ids": oc, "virtual_nodes_per_gpu": int(hb2["virtual"].num_nodes),
+                     "vv_edges_per_gpu": int(hb2[("virtual", "to", "virtual")].edge_index.size(1)),
+                     "ms_per_step": 1e3 * dt2 / args.steps, "graphs_per_s": B * args.steps / dt2}
+        del ts2, hb2
 
     # ---- roofline of the dominant kernel: eager steps, HIP events around its C-ABI launch ----
     roofline = None
     if rank == 0:
         import graph_hscn.engine as eng
         import graph_hscn.nn.functional as Fh
+        import graph_hscn.step as stepmod
         N = int(hb["local"].num_nodes)
         V = int(hb["virtual"].num_nodes)
         E = int(hb[("local", "to", "local")].edge_index.size(1))
@@ -306,7 +380,8 @@ def main():
         lin_b = 12 * N * H + 12 * V * H
         used_resident = model.last_engine == "resident"
         names = (["hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual",
-                  "hscn_resident_bwd_with_virtual"] if used_resident else ["hscn_spmm_csr_gcn"])
+                  "hscn_resident_bwd_with_virtual", "hscn_resident_train_step"] if used_resident
+                 else ["hscn_spmm_csr_gcn"])
         timer = KernelTimer(names)
         orig_call = _hip.call
 
@@ -315,15 +390,18 @@ def main():
 
         Fh.call = timed_call
         eng.call = timed_call
+        stepmod.call = timed_call
         nprof = max(5, min(50, args.steps))
+        prof_step = ts.fused.run if ts.fused is not None else ts.step_eager
         for _ in range(nprof):
             # park the stream for ~0.2 ms so the host runs ahead: the launches of this step then sit in the
             # queue back to back and the event pair brackets the kernel, not the host's launch latency
             torch.cuda._sleep(400000)
-            step_eager()
+            prof_step()
         torch.cuda.synchronize()
         Fh.call = orig_call
         eng.call = orig_call
+        stepmod.call = orig_call
 
         def avg_s(pred):
             """Average launch duration: the last recorded launch that matches is re-issued REP times back to
@@ -348,39 +426,59 @@ def main():
 
         if used_resident:
             split = any(nm == "hscn_resident_fwd_with_virtual" for (nm, a, s_, e_) in timer.events)
-            t_f, n_f = avg_s(lambda nm, a: nm in ("hscn_resident_fwd", "hscn_resident_fwd_with_virtual"))
-            t_b, n_b = avg_s(lambda nm, a: nm in ("hscn_resident_bwd", "hscn_resident_bwd_with_virtual"))
+            one_launch = any(nm == "hscn_resident_train_step" for (nm, a, s_, e_) in timer.events)
             virt_layer = lv_b + vv_b + 4 * N * H + 12 * V * H      # one layer of the virtual branch
             alg_f = L * (ll_b + lv_b + vv_b + lin_b)
             alg_b = L * (ll_b + lin_b)     # the backward only walks the local->local relation (+ its transforms)
-            if split:                      # layers 1.. of the virtual branch ride on the backward launch
-                alg_f -= (L - 1) * virt_layer
-                alg_b += (L - 1) * virt_layer
-            dom_fwd = t_f >= t_b
-            t, alg = (t_f, alg_f) if dom_fwd else (t_b, alg_b)
-            k_f = ("k_hscn_fwd_pair (hscn_resident_fwd_with_virtual: local chain + head | virtual CSRs + layer 0, "
-                   "2 workgroups/graph)") if split else "k_hscn_fwd (hscn_resident_fwd: all layers, 1 workgroup/graph)"
-            k_b = ("k_hscn_bwd_virtual + k_param_reduce (hscn_resident_bwd_with_virtual: backward | virtual layers 1..)"
-                   if split else "k_hscn_bwd + k_param_reduce (hscn_resident_bwd)")
-            roofline = {"bound": "hbm",
-                        "kernel": k_f if dom_fwd else k_b,
+            if one_launch:
+                t, n_t = avg_s(lambda nm, a: nm == "hscn_resident_train_step")
+                spmm_passes, unfused = 2 * L, alg_f + alg_b
+                kname = ("k_hscn_step + k_param_reduce (hscn_resident_train_step: forward, loss tail and backward of a "
+                         "graph in one workgroup | virtual branch, 2 workgroups/graph)")
+                extra = {"step_launch_us": t * 1e6}
+            else:
+                t_f, n_f = avg_s(lambda nm, a: nm in ("hscn_resident_fwd", "hscn_resident_fwd_with_virtual"))
+                t_b, n_b = avg_s(lambda nm, a: nm in ("hscn_resident_bwd", "hscn_resident_bwd_with_virtual"))
+                if split:                      # layers 1.. of the virtual branch ride on the backward launch
+                    alg_f -= (L - 1) * virt_layer
+                    alg_b += (L - 1) * virt_layer
+                dom_fwd = t_f >= t_b
+                t, unfused, n_t = (t_f, alg_f, n_f) if dom_fwd else (t_b, alg_b, n_b)
+                spmm_passes = L
+                k_f = ("k_hscn_fwd_pair (hscn_resident_fwd_with_virtual: local chain + head | virtual CSRs + layer 0, "
+                       "2 workgroups/graph)") if split else "k_hscn_fwd (hscn_resident_fwd: all layers, 1 workgroup/graph)"
+                k_b = ("k_hscn_bwd_virtual + k_param_reduce (hscn_resident_bwd_with_virtual: backward | virtual layers 1..)"
+                       if split else "k_hscn_bwd + k_param_reduce (hscn_resident_bwd)")
+                kname = k_f if dom_fwd else k_b
+                extra = {"fwd_us": t_f * 1e6, "bwd_us": t_b * 1e6, "fwd_unfused_model_bytes": alg_f,
+                         "bwd_unfused_model_bytes": alg_b}
+            # `achieved` / `frac`: SURVEY.md 8(d)'s numerator -- the local->local SpMM bytes of the passes this launch
+            # performs (one per layer and direction) -- over the launch's duration.  The launch keeps every
+            # intermediate in LDS, so its real HBM traffic (`traffic`, PMC) is of the same order, and both are a few
+            # per cent of peak: the step is bound by the dependent chain of its largest graph, not by bandwidth.
+            alg = spmm_passes * ll_b
+            roofline = {"bound": "hbm", "kernel": kname,
                         "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "algorithmic_bytes_per_launch": alg, "avg_launch_us": t * 1e6,
-                        "launches_timed": n_f if dom_fwd else n_b,
-                        "fwd_us": t_f * 1e6, "bwd_us": t_b * 1e6,
-                        "fwd_algorithmic_bytes": alg_f, "bwd_algorithmic_bytes": alg_b,
-                        "note": "latency-bound at this batch: the whole working set is a few MB (SURVEY.md 8d)"}
+                        "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None, "frac_traffic": None,
+                        "algorithmic_bytes_per_launch": alg, "ll_spmm_passes_per_launch": spmm_passes,
+                        "ll_spmm_bytes_per_pass": ll_b, "avg_launch_us": t * 1e6, "launches_timed": n_t,
+                        "frac_unfused_model": unfused / t / 1e9 / HBM_PEAK_GBS, "unfused_model_bytes": unfused,
+                        "note": "latency-bound at this batch (the whole working set is a few MB, SURVEY.md 8d); "
+                                "frac_unfused_model prices every operator's intermediates as if they went to HBM "
+                                "(they stay in LDS) and is NOT a bandwidth figure; the HBM-resident SpMM is "
+                                "streaming_spmm_scaled"}
+            roofline.update(extra)
         else:
             # args[7] = num_rows, args[8] = width of hscn_spmm_csr_gcn
             t, n_l = avg_s(lambda nm, a: a[7] == N and a[8] == H)
-            roofline = {"bound": "hbm", "kernel": "k_spmm<4,0> (hscn_spmm_csr_gcn, local->local fwd+bwd)",
+            roofline = {"bound": "hbm", "kernel": "k_spmm<4,0> (hscn_spmm_csr_gcn, local->local, one pass)",
                         "achieved": ll_b / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ll_b / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": ll_b / t / 1e9 / HBM_PEAK_GBS, "traffic": None, "frac_traffic": None,
                         "algorithmic_bytes_per_launch": ll_b, "avg_launch_us": t * 1e6, "launches_timed": n_l}
 
     # ---- the streaming (layered-engine) ll SpMM at a bandwidth-resident shape:
-    # the same generator tiled to 4096 graphs, hidden 128 -- the shape where "HBM roofline" means something
+    # the same generator tiled to 4096 graphs, hidden 128 -- the shape where "HBM roofline" means something;
+    # forward pass and backward pass (the same kernel on the source-keyed CSR), as 8(d) defines the figure
     streaming = None
     if rank == 0 and not args.no_streaming_spmm:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -388,21 +486,27 @@ def main():
         streaming = bench_spmm.measure(32, 128, 20, dev=dev)
         streaming["peak_GBs"] = HBM_PEAK_GBS
 
-    # HBM traffic from the committed PMC passes (profiles/r01_pmc_traffic.json; separate rocprofv3 runs,
-    # the counters cannot be read from inside this process)
+    # HBM traffic from PMC passes: separate rocprofv3 runs of this script (the counters cannot be read from inside
+    # the process); the file records the commit it was collected at
     if rank == 0:
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            default_shape = (args.workload == "peptides_func" and B == 128 and args.hidden == 16 and args.layers == 3)
-            if roofline and default_shape:
+        for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                pmc = doc["kernels"]
+            except (OSError, KeyError, ValueError):
+                continue
+            default_shape = (args.workload == "peptides_func" and B == 128 and args.hidden == 16 and args.layers == 3
+                             and args.cluster_ids == "scn_untrained")
+            if roofline and default_shape and roofline["traffic"] is None:
                 key = roofline["kernel"].split(" ")[0]      # exact kernel name
                 if key and key in pmc:
                     roofline["traffic"] = pmc[key]["traffic_bytes"]
-                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 fetch correction)"
-            if streaming and "k_spmm_scaled_H128" in pmc:
+                    roofline["frac_traffic"] = pmc[key]["traffic_bytes"] / (roofline["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    roofline["traffic_source"] = (f"profiles/{fname}: a SEPARATE rocprofv3 --pmc run of this command "
+                                                  f"(FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction), "
+                                                  f"collected at commit {doc.get('_commit', 'unrecorded')}")
+            if streaming and "traffic" not in streaming and "k_spmm_scaled_H128" in pmc:
                 streaming["traffic"] = pmc["k_spmm_scaled_H128"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
 
     # ---- stage A (MinCUT coarsening: gcn_norm + SCN fwd + (mc+o) bwd) on the same graphs, fused engine,
     # one hipGraph replay per 128-graph step; reported beside the stage C headline
@@ -410,25 +514,14 @@ def main():
     if rank == 0 and not args.no_stage_a:
         from graph_hscn.data import Batch
         from graph_hscn.model.hscn import SCN
+        from graph_hscn.step import ScnTrainStep
         torch.manual_seed(1)
         scn = SCN([16], "elu", F, K).to(dev)
         bigd = Batch.from_data_list(graphs).to(dev)
         bigd.x = bigd.x.float()
         if scn.resident_ok(bigd):
-            def a_step():
-                for p in scn.parameters():
-                    p.grad = None
-                scn.forward_graphs(bigd, with_total=True)[3].backward(root_grad)   # mc + o, as train_clustering does it
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    a_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                a_step()
+            a_step = ScnTrainStep(scn, bigd)      # (mc + o).backward() as two launches, no autograd in the capture
+            ga = capture(a_step.run)
             for _ in range(20):
                 ga.replay()
             torch.cuda.synchronize()
@@ -437,6 +530,7 @@ def main():
                 ga.replay()
             torch.cuda.synchronize()
             ta = (time.perf_counter() - t0) / args.steps
+            a_step.check()
             stage_a = {"what": "gcn_norm + SCN fwd + (mincut+ortho) bwd, batched, graph-resident kernels",
                        "ms_per_step": ta * 1e3, "graphs_per_s": B / ta,
                        "combined_A_plus_C_graphs_per_s": B / (ta + dt / args.steps)}
@@ -456,11 +550,18 @@ def main():
                        "graphs_per_gpu": B, "global_batch": B * world, "num_clusters": K, "hidden": args.hidden,
                        "layers": args.layers, "classes": C, "nodes_per_gpu": int(hb["local"].num_nodes),
                        "ll_edges_per_gpu": int(hb[("local", "to", "local")].edge_index.size(1)),
+                       "cluster_ids": args.cluster_ids,
                        "virtual_nodes_per_gpu": int(hb["virtual"].num_nodes),
+                       "vv_edges_per_gpu": int(hb[("virtual", "to", "virtual")].edge_index.size(1)),
                        "mode": args.mode, "engine": model.last_engine, "structure_build": args.structure,
                        "steps_per_graph": spg,
+                       "step_issue": ("direct C-ABI launches (graph_hscn.step.ResidentTrainStep)" if ts.fused is not None
+                                      else "autograd"),
+                       "allreduce": (None if reducer is None else
+                                     ("captured in the step's hipGraph" if ts.in_graph_allreduce else "eager, after each replay")),
                        "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "streaming_spmm_scaled": streaming, "stage_a": stage_a,
+            "roofline": roofline, "cpu_baseline": cpu, "other_cluster_ids": other_ids,
+            "streaming_spmm_scaled": streaming, "stage_a": stage_a,
         }
         if cpu:
             out["vs_cpu_baseline"] = value / cpu["value"]

@@ -90,6 +90,14 @@ class Data(Store):
         return out
 
 
+def _cat_targets(ys: Sequence[Tensor]) -> Tensor:
+    """PyG collate of ``y``: concatenate along dim 0 AS IS (a graph-level class index ``y=[c]`` of five graphs
+    gives ``[5]``, node labels ``y[N_i]`` give ``[sum N_i]``, ``[1, C]`` rows give ``[B, C]``); only 0-dim labels
+    are unsqueezed.  The reference's multiclass branch (``pred.ndim > 1 and true.ndim == 1``, loss.py:11)
+    depends on 1-D targets staying 1-D."""
+    return torch.cat([y.reshape(1) if y.dim() == 0 else y for y in ys], 0)
+
+
 class Batch(Data):
     """Block-diagonal union of ``Data`` graphs (PyG ``Batch.from_data_list``)."""
 
@@ -104,7 +112,7 @@ class Batch(Data):
             num_nodes=int(ptr[-1]),
         )
         if all(g.y is not None for g in graphs):
-            out.y = torch.cat([g.y if g.y.dim() >= 2 else g.y.view(1, -1) for g in graphs], 0)
+            out.y = _cat_targets([g.y for g in graphs])
         if all(g.edge_weight is not None for g in graphs):
             out.edge_weight = torch.cat([g.edge_weight for g in graphs], 0)
         out.batch = torch.repeat_interleave(torch.arange(len(ns)), torch.as_tensor(ns))
@@ -187,7 +195,7 @@ class HeteroBatch(HeteroData):
             st.max_nodes = int(max(ns)) if ns else 0
             st.num_nodes = int(ptr[-1])
             if all("y" in g[nt] and g[nt].y is not None for g in graphs):
-                st.y = torch.cat([g[nt].y if g[nt].y.dim() >= 2 else g[nt].y.view(1, -1) for g in graphs], 0)
+                st.y = _cat_targets([g[nt].y for g in graphs])
         for et in graphs[0].edge_types:
             s, _, d = et
             off = torch.stack([ptrs[s][:-1], ptrs[d][:-1]], 0)  # [2, B]

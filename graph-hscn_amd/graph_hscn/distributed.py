@@ -57,9 +57,16 @@ class FlatGradReducer:
     ``criterion`` is a mean over B x C elements (loss.py:9,16)."""
 
     def __init__(self, module: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None,
-                 single_rank_collective: bool = False):
+                 single_rank_collective: bool = False, equal_weights: bool = False):
+        """``equal_weights``: the caller promises that EVERY rank passes the same ``local_weight`` in every
+        call (equal shards: bench.py, fit_resident).  Only then may the reduction be RCCL's AVG with no scaling
+        launch.  The choice must be the same on all ranks -- one collective issued as AVG by some ranks and
+        as SUM by others is undefined behaviour -- so it is a constructor argument that identical code sets
+        identically everywhere, never a per-rank test of the weights (round 1 tested ``scale * ws == 1`` per
+        rank: with node-balanced shards of 16 / 15 / 17 graphs rank 0 would have issued AVG, the others SUM)."""
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.group = process_group
+        self.equal_weights = bool(equal_weights)
         self.always = single_rank_collective   # issue the collective even in a world of one (exercises the RCCL path)
         self._flat: Optional[torch.Tensor] = None
         self._mask: Optional[List[bool]] = None
@@ -107,6 +114,12 @@ class FlatGradReducer:
         flat.set_(g0.untyped_storage(), spans[0][0], (end - spans[0][0],))
         return flat
 
+    @staticmethod
+    def _check_equal(scale: float, ws: int) -> None:
+        if abs(scale * ws - 1.0) > 1e-9:
+            raise ValueError("FlatGradReducer(equal_weights=True) but this rank's weight is not 1/world_size of the "
+                             "total: build the reducer with equal_weights=False for unequal shards")
+
     def reduce(self, local_weight: float = 1.0, total_weight: Optional[float] = None) -> None:
         # replayed steps (hipGraph) write their gradients to the same addresses every time: when nothing
         # moved since the last call the layout check and the flat view are reused (the host must not be
@@ -116,7 +129,8 @@ class FlatGradReducer:
             if (sum(p.grad is not None for p in self.params) == len(key)
                     and all(p.grad is not None and p.grad.data_ptr() == k for p, k in zip(self._fast_params, key))):
                 scale = float(local_weight) / float(total_weight)
-                if abs(scale * ws - 1.0) < 1e-12 and self._fast_avg:
+                if self._fast_avg:
+                    self._check_equal(scale, ws)
                     dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
                 else:
                     flat.mul_(scale)
@@ -139,10 +153,11 @@ class FlatGradReducer:
         self.last_path = "aliased" if flat is not None else "packed"
         if flat is not None:
             self._fast_params = [p for p, m in zip(self.params, mask) if m]
-            self._fast_avg = dist.get_backend(self.group) == "nccl"
+            self._fast_avg = self.equal_weights and dist.get_backend(self.group) == "nccl"
             self._fast = (tuple(g.data_ptr() for g in grads), flat, ws)
             # one collective on the gradients where they already live
-            if abs(scale * ws - 1.0) < 1e-12 and dist.get_backend(self.group) == "nccl":
+            if self._fast_avg:
+                self._check_equal(scale, ws)
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # equal shards: RCCL averages
             else:
                 flat.mul_(scale)

@@ -61,7 +61,11 @@ class _LossState:
     __slots__ = ("pred", "target", "kind", "value", "grad")
 
     def __init__(self, pred, target, kind):
-        self.pred, self.target, self.kind = pred, target, kind
+        # VALUES only: the state outlives the step (``loss.detach()`` of a LazyLoss shares it, and a training loop
+        # collects those, train/train.py:85), so it must not hold the prediction's autograd graph -- that kept every
+        # iteration's saved activations alive until the epoch ended, and the parameters' gradient-accumulation
+        # nodes with them (round 1: the precursor of the capture_end crash)
+        self.pred, self.target, self.kind = pred.detach(), target.detach(), kind
         self.value = self.grad = None
 
     def fill(self, value):

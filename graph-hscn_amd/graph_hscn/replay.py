@@ -5,7 +5,8 @@ valid.  The graph-resident kernels read the per-graph node / edge ranges from de
 only host constants are capacities: ``StaticHeteroBatch`` owns device buffers sized for the largest
 batch of a loader (nodes, edges per relation, virtual nodes; per-graph maxima that size the LDS), each
 step's batch is copied INTO them (``load``), and the captured launches run on whatever the buffers
-hold.  ``CapturedStep`` captures ``zero grads -> HSCN.forward -> criterion -> backward`` once; afterwards
+hold.  ``CapturedStep`` captures ``zero grads -> HSCN.forward -> criterion -> backward`` once (as direct C-ABI
+launches, ``step.ResidentTrainStep``: no autograd inside the capture); afterwards
 a training iteration is ``static.load(batch); step.replay(); optimizer.step()``.
 
 The reference loop (train/train.py:73-95) issues ~150 small launches per step from Python; the eager
@@ -20,7 +21,6 @@ import torch
 from torch import Tensor
 
 from .data import HeteroBatch
-from .loss import criterion
 
 LL = ("local", "to", "local")
 VV = ("virtual", "to", "virtual")
@@ -150,11 +150,16 @@ class StaticHeteroBatch:
 class CapturedStep:
     """``zero grads -> model(batch) -> criterion -> backward`` captured once on ``static.batch``.
     ``replay()`` runs it on whatever was last loaded; ``loss`` / ``pred`` / ``score`` are the captured
-    output tensors (refreshed by every replay), parameter gradients live in the graph's memory pool.
+    output tensors (refreshed by every replay), parameter gradients are slices of one flat buffer
+    (``grads``; ``p.grad`` points into it).
 
-    Drop the outputs of earlier EAGER steps of the same model (``loss``, ``pred``) before constructing this:
-    they keep the parameters' gradient-accumulation nodes alive, bound to the stream those steps ran on,
-    and autograd would then tie the capture to that (non-capturing) stream."""
+    The captured region holds kernel nodes only: the step is issued through ``step.ResidentTrainStep``
+    (direct C-ABI launches on preallocated buffers), never through the autograd engine.  Round 1 captured
+    ``loss.backward()``; autograd's gradient-accumulation nodes are bound to the stream of the first step that
+    used them, a node kept alive by ANY earlier eager ``loss`` / ``pred`` tied the capture to that
+    non-capturing stream and ``capture_end`` died inside the HIP runtime (a host SIGSEGV).  With no autograd
+    in the capture, live tensors of earlier eager steps and earlier ``CapturedStep`` objects on the same model
+    cannot reach into it (tests/test_gpu_step.py)."""
 
     def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None, pre=None):
         """``pre``: a callable captured in front of the step that refreshes the static buffers from device-side
@@ -166,6 +171,7 @@ class CapturedStep:
         capture recipe); parameters and optimizer state are put back afterwards, IN PLACE (the captured launches
         hold their addresses): state that existed before is restored, state the warm-up created is zeroed (the
         initial state of the Adam family)."""
+        from .step import ResidentTrainStep
         self.model, self.static, self.loss_fn, self.optimizer = model, static, loss_fn, optimizer
         snap_p = snap_s = None
         if optimizer is not None:
@@ -175,18 +181,20 @@ class CapturedStep:
         hb = static.batch
         if "y" not in hb["local"]:
             raise ValueError("the static batch carries no targets")
+        try:
+            self.step = ResidentTrainStep(model, hb, loss_fn)
+        except RuntimeError as e:
+            raise RuntimeError("CapturedStep needs the graph-resident engine (the layered operators size their "
+                               "work by tensor shapes, which a static-capacity batch does not carry): " + str(e)) from e
+        self.step.bind_grads()
+        model.last_engine = "resident"
 
         def step():
             if pre is not None:
                 pre()
-            for p in model.parameters():
-                p.grad = None
-            pred = model(hb.x_dict, hb.edge_index_dict, hb)
-            loss, score = criterion(loss_fn, pred, hb["local"].y)
-            loss.backward()
+            self.step.run()
             if optimizer is not None:
                 optimizer.step()
-            return pred.detach(), loss.detach(), score
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -195,14 +203,12 @@ class CapturedStep:
                 step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if getattr(model, "last_engine", None) != "resident":
-            raise RuntimeError("CapturedStep needs the graph-resident engine (the layered operators size their "
-                               "work by tensor shapes, which a static-capacity batch does not carry)")
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.pred, self.loss, self.score = step()
+            step()
+        self.pred, self.loss, self.score = self.step.pred, self.step.loss, self.step.score
         # the gradient tensors the captured backward writes (a later eager step re-points ``p.grad`` elsewhere)
-        self.grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
+        self.grads = list(self.step.param_grads)
         if optimizer is not None:
             with torch.no_grad():
                 for p, s0 in zip(model.parameters(), snap_p):
@@ -220,5 +226,4 @@ class CapturedStep:
     def bind_grads(self) -> None:
         """Point every ``p.grad`` at the captured step's gradient buffers again (after eager steps of the same
         model): an optimizer stepped OUTSIDE the graph reads ``p.grad``."""
-        for p, g in self.grads:
-            p.grad = g
+        self.step.bind_grads()

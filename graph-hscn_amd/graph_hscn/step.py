@@ -1,0 +1,253 @@
+"""Training steps as plain sequences of C-ABI launches on preallocated buffers (no autograd inside).
+
+The reference's iteration is ``pred = model(...); loss = criterion(...); loss.backward()``
+(/root/reference/graph_hscn/train/train.py:73-95; stage A: train/train_clustering.py:44-50).  The
+eager product path keeps that form (``engine.HSCNResidentFn`` / ``SCNResidentFn`` are autograd
+Functions).  A step that is going to be REPLAYED (hipGraph) should not run the autograd engine while
+it is being captured: autograd binds every parameter's gradient-accumulation node to the stream it
+was first used on, and a node that an earlier eager step left alive ties the capture to that
+non-capturing stream -- ``capture_end`` then fails inside the HIP runtime (a host segfault, round 1:
+gpurun_out/t12.log, scn_dbg.log).  The classes here issue exactly the launches the autograd path
+issues -- same entry points, same arguments, bit-identical outputs (tests/test_gpu_step.py) -- into
+buffers allocated once, so a capture contains kernel nodes only and nothing of an earlier step can
+reach into it.
+
+  ResidentTrainStep  stage C: zero grads -> HSCN.forward -> criterion -> backward
+  ScnTrainStep       stage A: zero grads -> gcn_norm + SCN.forward -> (mc + o).backward
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _hip
+from . import engine as _engine
+from ._hip import call, ptr, stream
+
+LL, VV, LV = _engine.LL, _engine.VV, _engine.LV
+
+
+def _loss_kind(loss_fn: str, C_pred: Tuple[int, int], target: Tensor) -> int:
+    if target.dim() != 2 or tuple(target.shape) != tuple(C_pred):
+        raise ValueError("the fused step takes [B, C] targets (the multilabel BCE / L1 branches of "
+                         "loss.py:8-10,16-19); class-index targets go through loss.criterion")
+    return 0 if loss_fn == "cross_entropy" else 1
+
+
+class ResidentTrainStep:
+    """``for p: p.grad = None; pred = model(x_dict, edge_index_dict, batch); loss, score =
+    criterion(loss_fn, pred, batch["local"].y); loss.backward()`` on the graph-resident engine,
+    issued by ``run()`` as two or three launches on the current stream.
+
+    Outputs (tensors that every ``run()`` refreshes in place): ``pred`` [B,C], ``score`` [B,C]
+    (= sigmoid(pred), what ``criterion`` returns beside the loss), ``loss`` (0-dim), ``grads``
+    (flat, the parameter gradients in launch order) and ``virtual`` (final virtual features, as
+    ``HSCN.last_virtual``).  ``bind_grads()`` points every ``p.grad`` at its slice of ``grads``
+    (parameters the prediction does not depend on -- the whole virtual branch, DESIGN.md section 2 --
+    get ``None``, as autograd leaves them).
+
+    The batch may be a ``replay.StaticHeteroBatch.batch``: tensor shapes are capacities then, the
+    kernels read the real per-graph ranges from the device-side segment tables."""
+
+    def __init__(self, model, batch, loss_fn: str, target: Optional[Tensor] = None):
+        from .model.hscn import HSCN, _act_name
+        if not isinstance(model, HSCN):
+            raise TypeError("ResidentTrainStep drives graph_hscn.model.hscn.HSCN")
+        x_dict, ei_dict = batch.x_dict, batch.edge_index_dict
+        dev = x_dict["local"].device
+        if dev.type != "cuda":
+            raise RuntimeError("the graph-resident step runs on the MI355X HIP path: move the batch to 'cuda'")
+        keep = model.engine
+        model.engine = "resident"            # raises with the reason when the batch / model does not qualify
+        try:
+            meta, act_name = model._resident_plan(x_dict, ei_dict, batch)
+        finally:
+            model.engine = keep
+        self.model, self.batch, self.meta = model, batch, meta
+        self.loss_fn = loss_fn
+        params = [p.contiguous() for p in model._resident_params()]
+        L = (len(params) - 4) // 9
+        W1, b1, W2, b2 = params[9 * L:]
+        H, C = W1.shape[0], W2.shape[0]
+        self.x_local = x_dict["local"].contiguous()
+        self.x_virtual = x_dict["virtual"].contiguous()
+        if self.x_local.dtype != torch.float32:
+            raise TypeError("node features must be float32 (train/train.py:79 casts them)")
+        self.ei = {k: ei_dict[k].contiguous() for k in (LL, VV, LV)}
+        N, F = self.x_local.shape
+        V = self.x_virtual.shape[0]
+        B = meta.num_graphs
+        self.dims = (N, V, F, H, L, C, B)
+        self.head_act = _engine.ACT[act_name]
+        self.slope = float(model.convs[0].convs["__".join(LV)].negative_slope)
+        y = target if target is not None else batch["local"].y
+        if y.dtype != torch.float32 or not y.is_contiguous() or y.device != dev:
+            raise TypeError("targets must be a contiguous float32 tensor on the batch's device")
+        self.kind = _loss_kind(loss_fn, (B, C), y)
+        self.target = y
+        self._params = params
+        self._table = _engine._ptr_table(params[: 9 * L])
+        self._wll_table = _engine._ptr_table([params[9 * l] for l in range(L)])
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.acts = torch.empty(L, N, H, **f32)
+        self.pooled = torch.empty(B, H, **f32)
+        self.z = torch.empty(B, H, **f32)
+        self.pred = torch.empty(B, C, **f32)
+        self.score = torch.empty(B, C, **f32)
+        E_ll, E_vv, E_lv = (self.ei[k].size(1) for k in (LL, VV, LV))
+        self.csr = (torch.empty(N + B, **i32), torch.empty(max(E_ll, 1), **i32), torch.empty(max(N, 1), **f32))
+        self.virtual = torch.empty(max(V, 1), H, **f32) if model.compute_virtual else None
+        # the virtual branch rides on the two launches as extra workgroups while they land on idle CUs
+        self.defer = bool(model.compute_virtual and model.overlap_virtual and V > 0 and L >= 2
+                          and 2 * B <= _engine._cu_count(dev))
+        self._state = None
+        if self.defer:
+            self._state = (torch.empty(V + B, **i32), torch.empty(max(E_lv, 1), **i32), torch.empty(V + B, **i32),
+                           torch.empty(max(E_vv, 1), **i32), torch.empty(V, **f32), torch.empty(V, H, **f32))
+        P = int(_hip.lib().hscn_resident_param_count(F, H, L, C))
+        self.P = P
+        self.partials = torch.empty(B, P + 1, **f32)
+        self.grads = torch.zeros(P + 1, **f32)
+        self.loss = self.grads[P:P + 1].view(())
+        self._tail = _engine._LossTail(ptr(self.pred), ptr(self.target), int(self.kind))
+        # parameter -> slice of the flat gradient buffer (launch order: {W_ll, b_ll} per layer, W1, b1, W2, b2)
+        views: List[Tuple[Tensor, Tensor]] = []
+        off = 0
+        mparams = model._resident_params()
+        for l in range(L):
+            fin = F if l == 0 else H
+            views.append((mparams[9 * l], self.grads[off: off + H * fin].view(H, fin))); off += H * fin
+            views.append((mparams[9 * l + 1], self.grads[off: off + H])); off += H
+        for p, n in zip(mparams[9 * L:], (H * H, H, C * H, C)):
+            views.append((p, self.grads[off: off + n].view_as(p))); off += n
+        assert off == P
+        self.param_grads = views
+
+    def bind_grads(self) -> None:
+        has = {id(p) for p, _ in self.param_grads}
+        for p in self.model.parameters():
+            if id(p) not in has:
+                p.grad = None
+        for p, g in self.param_grads:
+            p.grad = g
+
+    def _job(self, xv_out: Optional[Tensor]) -> "_engine._VirtualJob":
+        N, V, F, H, L, C, B = self.dims
+        m = self.meta
+        return _engine._VirtualJob(ptr(self.x_virtual), ptr(self.ei[VV]), self.ei[VV].size(1), ptr(self.ei[LV]),
+                                   self.ei[LV].size(1), ptr(m.vptr), ptr(m.eptr_vv), ptr(m.eptr_lv),
+                                   ctypes.cast(self._table, ctypes.c_void_p), ptr(xv_out), V, m.max_v, m.max_evv,
+                                   self.slope, *[ptr(t) for t in self._state])
+
+    def run(self) -> Tensor:
+        """Issue the step on the current stream; returns ``loss`` (valid once the stream has run)."""
+        N, V, F, H, L, C, B = self.dims
+        m = self.meta
+        W1, b1, W2, b2 = self._params[9 * L:]
+        st = stream()
+        ei_ll = self.ei[LL]
+        E_ll = ei_ll.size(1)
+        csr_rp, csr_col, dinv = self.csr
+        bwd_args = (ptr(self.x_local), ptr(ei_ll), E_ll, ptr(m.lptr), ptr(m.eptr_ll), N, B, F, H, L, C,
+                    self.head_act, self._wll_table, ptr(W1), ptr(W2), ptr(self.acts), ptr(self.pooled), ptr(self.z),
+                    None, None, ptr(csr_rp), ptr(csr_col), ptr(dinv), m.max_n, m.max_ell, ptr(self.partials),
+                    ptr(self.grads), ptr(m.flag), ctypes.byref(self._tail))
+        if self.defer:
+            call("hscn_resident_fwd_with_virtual", ptr(self.x_local), ptr(ei_ll), E_ll, ptr(m.lptr), ptr(m.eptr_ll),
+                 N, B, F, H, L, C, self.head_act, self._table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), m.max_n,
+                 m.max_ell, ptr(self.acts), ptr(self.pooled), ptr(self.z), ptr(self.pred), ptr(self.score),
+                 ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(m.flag), ctypes.byref(self._job(None)), st)
+            call("hscn_resident_bwd_with_virtual", *bwd_args, ctypes.byref(self._job(self.virtual)), st)
+        else:
+            cv = int(bool(self.model.compute_virtual))
+            call("hscn_resident_fwd", ptr(self.x_local), ptr(self.x_virtual), ptr(ei_ll), E_ll, ptr(self.ei[VV]),
+                 self.ei[VV].size(1), ptr(self.ei[LV]), self.ei[LV].size(1), ptr(m.lptr), ptr(m.vptr),
+                 ptr(m.eptr_ll), ptr(m.eptr_vv), ptr(m.eptr_lv), N, V, B, F, H, L, C, self.head_act, self.slope,
+                 self._table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), m.max_n, m.max_v, m.max_ell, m.max_evv, cv,
+                 ptr(self.acts), ptr(self.pooled), ptr(self.z), ptr(self.pred), ptr(self.score),
+                 ptr(self.virtual) if cv else None, ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(m.flag), st)
+            call("hscn_resident_bwd", *bwd_args, st)
+        return self.loss
+
+    def check(self) -> None:
+        """Synchronising validity check of the launches issued so far (block-diagonal batch, sizes)."""
+        self.meta.check()
+
+
+class ScnTrainStep:
+    """``optimizer.zero_grad(); S, mc, o = model.forward_graphs(data); (mc + o).backward()`` -- the body of
+    the reference's clustering loop (train/train_clustering.py:37-49) for one ``Data`` graph or a block-diagonal
+    ``Batch`` of raw graphs -- as the two graph-resident launches on preallocated buffers.
+
+    Outputs refreshed by ``run()``: ``S`` [N,K] (softmax assignment), ``losses`` [3] = {mincut, ortho, their sum},
+    ``grads`` (flat: W_rel, b_rel, W_root, W_mlp, b_mlp)."""
+
+    def __init__(self, model, data):
+        from .model.hscn import SCN
+        if not isinstance(model, SCN):
+            raise TypeError("ScnTrainStep drives graph_hscn.model.hscn.SCN")
+        if not model.resident_ok(data):
+            raise RuntimeError("the fused stage-A step needs the reference's SCN shape (mp_units=[H], mlp_units=[]) "
+                               "and graphs that fit one CU's LDS")
+        conv, lin = model.mp.module_0, list(model.mlp)[0]
+        dev = conv.lin_rel.weight.device
+        self.model = model
+        self.meta = meta = _engine.scn_meta(data, dev)
+        self.x = (data.x if data.x.is_cuda else data.x.to(dev)).float().contiguous()
+        self.ei = (data.edge_index if data.edge_index.is_cuda else data.edge_index.to(dev)).contiguous()
+        self.act = _engine.ACT[model.mp.act]
+        self._mp = [conv.lin_rel.weight, conv.lin_rel.bias, conv.lin_root.weight, lin.weight, lin.bias]
+        N, F = self.x.shape
+        H, K = conv.lin_rel.weight.shape[0], lin.weight.shape[0]
+        B, E = meta.num_graphs, self.ei.size(1)
+        self.dims = (N, F, H, K, B, E)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.S = torch.empty(N, K, **f32)
+        self.y = torch.empty(N, H, **f32)
+        self.stats = torch.empty(B, 4, **f32)
+        self.ss = torch.empty(B, K, K, **f32)
+        self.losses = torch.empty(3, **f32)
+        if meta.ticket is None:
+            meta.ticket = torch.zeros(1, **i32)
+        self.ex = (torch.empty(N + B, **i32), torch.empty(max(E, 1), **i32), torch.empty(N + B, **i32),
+                   torch.empty(max(E, 1), **i32), torch.empty(max(N, 1), 16, **f32), torch.empty(max(N, 1), **f32))
+        P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
+        self.partials = torch.empty(B, P, **f32)
+        self.grads = torch.zeros(P, **f32)
+        self.one = torch.ones(1, **f32)
+        views, off = [], 0
+        for p in self._mp:
+            views.append((p, self.grads[off: off + p.numel()].view_as(p)))
+            off += p.numel()
+        assert off == P
+        self.param_grads = views
+
+    @property
+    def loss(self) -> Tensor:
+        return self.losses[2]
+
+    def bind_grads(self) -> None:
+        for p, g in self.param_grads:
+            p.grad = g
+
+    def run(self) -> Tensor:
+        N, F, H, K, B, E = self.dims
+        m = self.meta
+        W_rel, b_rel, W_root, W_mlp, b_mlp = (p.contiguous() for p in self._mp)
+        st = stream()
+        eip = ptr(self.ei) if E else None
+        call("hscn_scn_resident_fwd", ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
+             ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), m.max_n, m.max_e, ptr(self.S), ptr(self.y),
+             ptr(self.stats), ptr(self.ss), ptr(self.losses), ptr(m.ticket), *[ptr(t) for t in self.ex], ptr(m.flag), st)
+        call("hscn_scn_resident_bwd", ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
+             ptr(W_mlp), ptr(self.S), ptr(self.y), ptr(self.stats), ptr(self.ss), ptr(self.one), ptr(self.one),
+             *[ptr(t) for t in self.ex], m.max_n, m.max_e, ptr(self.partials), ptr(self.grads), ptr(m.flag), st)
+        return self.losses[2]
+
+    def check(self) -> None:
+        self.meta.check()

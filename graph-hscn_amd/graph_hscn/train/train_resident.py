@@ -30,12 +30,19 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
 
     Data parallel: every rank calls this with ITS shard of the training graphs (``distributed.shard_list``; equal
     shard sizes, so that all ranks take the same number of steps) and a ``distributed.FlatGradReducer`` as
-    ``reducer``.  The iteration is then two replays around one collective: forward + loss + backward, the RCCL
+    ``reducer`` (built with ``equal_weights=True`` it averages with no scaling launch).  The iteration is then two replays around one collective: forward + loss + backward, the RCCL
     all-reduce of the flat gradient buffer where the backward left it, the optimizer step (captured on its own).
     The eager tail batch is reduced the same way."""
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("fit_resident runs on the MI355X HIP path: move the model to 'cuda'")
+    # what the captured iteration does not implement must not be dropped silently (train/train.py:89-95 honours both)
+    if int(getattr(optim_cfg, "batch_accumulation", 1) or 1) != 1:
+        raise NotImplementedError("fit_resident steps the optimizer every batch: batch_accumulation != 1 needs "
+                                  "train.train (the reference-shaped loop)")
+    if getattr(optim_cfg, "clip_grad_norm", False):
+        raise NotImplementedError("fit_resident has no gradient clipping between the captured backward and the "
+                                  "optimizer step: use train.train for clip_grad_norm")
     G, B = len(train_graphs), int(batch_size)
     if G < B:
         raise ValueError("fewer training graphs than one batch")
@@ -105,6 +112,13 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
             for split, loader in zip(["Validation", "Test"], eval_loaders):
                 vloss, _ = eval_epoch(epoch, logger, loader, model, training_cfg.loss_fn, metric_fn, split)
                 if split == "Validation":
+                    if reducer is not None and reducer.world_size > 1:
+                        # every rank must take the same stop decision (the next collective would hang otherwise):
+                        # the ranks agree on the mean of their validation losses
+                        import torch.distributed as dist
+                        t = torch.tensor([vloss], dtype=torch.float64, device=dev)
+                        dist.all_reduce(t, group=reducer.group)
+                        vloss = float(t.item()) / reducer.world_size
                     if vloss < best - training_cfg.min_delta:
                         best, stale = vloss, 0
                     else:

@@ -182,3 +182,27 @@ def assign_clusters(soft: Tensor) -> np.ndarray:
     """train_clustering.py:68 -- ``clust.max(1)[1].cpu().numpy()`` (first maximal
     index wins on ties)."""
     return soft.max(1)[1].cpu().numpy()
+
+
+def train_clustering_loop(model: SCN, graphs, cluster_epochs: int, optimizer: torch.optim.Optimizer):
+    """The stage-A driver, /root/reference/graph_hscn/train/train_clustering.py:34-69, restated: per epoch, per
+    graph: gcn_norm(add_self_loops=True) (:37-42) -> forward (:45-47) -> ``loss = mc_loss + o_loss`` (:48) ->
+    backward, ONE optimizer step per graph (:49-50); then the assignment pass (:57-69): same normalisation and
+    forward per graph, ``clust.max(1)[1]`` (:68).  ``graphs``: objects with ``.x`` and ``.edge_index``; the raw
+    graph is re-normalised on every visit, as iterating a PyG ``InMemoryDataset`` hands out a fresh copy each time
+    (the in-place overwrite at :37 persists only for ``list`` datasets).  Like the reference, the
+    assignment pass runs with autograd on (:57-69 has no ``no_grad``); its graphs are simply dropped.
+    Returns (list of int64 id arrays, list of the soft assignments of the final pass)."""
+    for _ in range(cluster_epochs):
+        for g in graphs:
+            optimizer.zero_grad()
+            _, mc, o, _, _, _ = scn_step_single_graph(model, g.x, g.edge_index)
+            loss = mc + o
+            loss.backward()
+            optimizer.step()
+    ids, soft = [], []
+    for g in graphs:
+        s, *_ = scn_step_single_graph(model, g.x, g.edge_index)
+        soft.append(s.detach())
+        ids.append(assign_clusters(s))
+    return ids, soft

@@ -98,8 +98,9 @@ def test_scn_single_graph_step_matches_oracle(K, act, units):
 
 
 def test_cluster_assignment_bit_exact_over_many_graphs():
-    """argmax ids from the HIP path == oracle ids on every node of 64 graphs
-    (train_clustering.py:68); also reports the top-2 margin."""
+    """argmax ids from the HIP path == oracle ids on EVERY node of 64 graphs (train_clustering.py:68), through the
+    layered operators and through the fused stage-A launch; no flip is tolerated on these committed seeds.  Prints
+    the histogram of the oracle's top-2 margins (how close the nearest tie is)."""
     from graph_hscn import _hip
     from graph_hscn.loader.synthetic import make_dataset
     from graph_hscn.model.hscn import SCN
@@ -110,22 +111,26 @@ def test_cluster_assignment_bit_exact_over_many_graphs():
     pm = SCN([16], "elu", 9, K).to(DEV)
     pm.load_state_dict(om.state_dict())
     margins = []
+    flips = {"layered": 0, "resident": 0}
     with torch.no_grad():
         for g in make_dataset("peptides_func", 64, seed=11):
             S_o, *_ = OM.scn_step_single_graph(om, g.x, g.edge_index)
-            ei, ew = gcn_norm(g.edge_index.to(DEV), None, g.num_nodes, add_self_loops=True)
-            S_d, *_ = pm(g.x.to(DEV).float(), ei, ew)
-            ids = torch.empty(g.num_nodes, dtype=torch.int64, device=DEV)
-            _hip.call("hscn_assign_argmax", _hip.ptr(S_d), _hip.ptr(ids), g.num_nodes, K, _hip.stream())
             top2 = S_o.topk(2, dim=1).values
             margins.append((top2[:, 0] - top2[:, 1]))
             want = OM.assign_clusters(S_o)
-            got = ids.cpu().numpy()
-            bad = np.nonzero(want != got)[0]
-            # a flip is only tolerable where the oracle's own top-2 gap is below float noise
-            assert all(float(top2[i, 0] - top2[i, 1]) < 1e-6 for i in bad), (len(bad), g.num_nodes)
+            ei, ew = gcn_norm(g.edge_index.to(DEV), None, g.num_nodes, add_self_loops=True)
+            S_l, *_ = pm(g.x.to(DEV).float(), ei, ew)
+            S_r, *_ = pm.forward_graphs(g.to(DEV))
+            assert pm.last_engine == "resident"
+            for tag, S_d in (("layered", S_l), ("resident", S_r)):
+                ids = torch.empty(g.num_nodes, dtype=torch.int64, device=DEV)
+                _hip.call("hscn_assign_argmax", _hip.ptr(S_d.contiguous()), _hip.ptr(ids), g.num_nodes, K, _hip.stream())
+                flips[tag] += int((want != ids.cpu().numpy()).sum())
     m = torch.cat(margins)
-    print(f"top-2 margin: min {m.min():.3e} median {m.median():.3e}; nodes {m.numel()}")
+    edges = [0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0]
+    hist = torch.histogram(m.clamp(max=1.0), bins=torch.tensor(edges)).hist.int().tolist()
+    print(f"top-2 margin histogram over {m.numel()} nodes, bin edges {edges}: {hist}; min {m.min():.3e}; flips {flips}")
+    assert flips == {"layered": 0, "resident": 0}, flips
 
 
 def test_scn_batched_equals_mean_of_single_graph_losses():

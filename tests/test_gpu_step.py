@@ -1,0 +1,177 @@
+"""graph_hscn.step: the training steps as direct C-ABI launches == the autograd path, bit for bit; and the
+capture of such a step is immune to whatever earlier eager steps left alive (round 1: host SIGSEGV at
+capture_end when an eager ``loss`` / ``pred`` of the same model was still referenced)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(B, K, C, seeds, dev=None):
+    from graph_hscn.data import HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    rng = np.random.default_rng(0)
+    out = []
+    for seed in seeds:
+        graphs = make_dataset("peptides_func", B, seed=seed)
+        for g in graphs:
+            g.y = torch.from_numpy((rng.random((1, C)) < 0.3).astype(np.float32))
+        out.append(HeteroBatch.from_data_list(
+            [hetero_from_clusters(g, rng.integers(0, K, g.num_nodes), K) for g in graphs]))
+    return out
+
+
+def _model(C, H=16, L=3, dev="cuda"):
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.model.hscn import HSCN
+    torch.manual_seed(0)
+    m = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, H, C, L).to(dev)
+    m.engine = "resident"
+    return m
+
+
+def _eager(model, d, loss_fn):
+    from graph_hscn.loss import criterion
+    model.zero_grad(set_to_none=True)
+    pred = model(d.x_dict, d.edge_index_dict, d)
+    loss, score = criterion(loss_fn, pred, d["local"].y)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    return pred, loss, score, grads
+
+
+@pytest.mark.parametrize("overlap,compute_virtual,loss_fn", [(True, True, "cross_entropy"), (False, True, "l1"),
+                                                             (True, False, "cross_entropy")])
+def test_direct_step_is_the_autograd_step_bit_for_bit(overlap, compute_virtual, loss_fn):
+    import graph_hscn.engine as eng
+    from graph_hscn.step import ResidentTrainStep
+    dev = torch.device("cuda:0")
+    (hb,) = _batches(7, 16, 10, (4,))
+    d = hb.to(dev)
+    model = _model(10)
+    model.overlap_virtual, model.compute_virtual = overlap, compute_virtual
+    pred, loss, score, grads = _eager(model, d, loss_fn)
+    want_v = eng.last_deferred_virtual.clone() if (overlap and compute_virtual) else None
+    rs = ResidentTrainStep(model, d, loss_fn)
+    assert rs.defer == (overlap and compute_virtual)
+    rs.bind_grads()
+    rs.run()
+    rs.run()                      # idempotent: buffers are rewritten, not accumulated into
+    torch.cuda.synchronize()
+    rs.check()
+    assert torch.equal(rs.pred, pred.detach())
+    assert torch.equal(rs.score, score)
+    assert torch.equal(rs.loss, loss.detach())
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert got.keys() == grads.keys()
+    for n in grads:
+        assert torch.equal(got[n], grads[n]), n
+    if want_v is not None:
+        assert torch.equal(rs.virtual, want_v)
+    if compute_virtual and not overlap:
+        model.keep_virtual = True
+        with torch.no_grad():
+            model(d.x_dict, d.edge_index_dict, d)
+        assert torch.equal(rs.virtual, model.last_virtual)
+
+
+def test_capture_is_immune_to_live_eager_tensors_and_earlier_captures():
+    """The regression for round 1's capture_end crash: an eager loss / prediction of the same model is ALIVE while
+    a CapturedStep is built, then a second CapturedStep is built on the same model; both replay correctly."""
+    from graph_hscn.replay import CapturedStep, StaticHeteroBatch
+    dev = torch.device("cuda:0")
+    batches = _batches(6, 16, 10, (1, 2))
+    model = _model(10)
+    ref = []
+    keep_alive = []
+    for hb in batches:
+        d = hb.to(dev)
+        pred, loss, score, grads = _eager(model, d, "cross_entropy")
+        ref.append((pred.detach().clone(), loss.detach().clone(), grads))
+        keep_alive.append((pred, loss, loss.detach(), d))       # autograd graphs of eager steps stay referenced
+    static = StaticHeteroBatch(batches, dev)
+    static.load(batches[0])
+    step1 = CapturedStep(model, static, "cross_entropy")
+    step2 = CapturedStep(model, static, "cross_entropy")          # an earlier capture on the same model is alive too
+    for step in (step1, step2, step1):
+        for i in (1, 0):
+            static.load(batches[i])
+            loss = step.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(step.pred, ref[i][0])
+            assert torch.equal(loss, ref[i][1])
+            step.bind_grads()
+            for n, p in model.named_parameters():
+                if n in ref[i][2]:
+                    assert torch.equal(p.grad, ref[i][2][n]), (i, n)
+    # and an eager step still works afterwards, on the tensors that were kept
+    pred, loss, score, grads = _eager(model, batches[1].to(dev), "cross_entropy")
+    assert torch.equal(pred.detach(), ref[1][0])
+
+
+def test_lazy_loss_detach_drops_the_graph():
+    """``loss.detach()`` of the lazily valued loss shares its state; the state holds values only, so collecting
+    detached losses over an epoch (train/train.py:85) does not keep every step's activations alive."""
+    import gc
+    import weakref
+    dev = torch.device("cuda:0")
+    (hb,) = _batches(3, 8, 10, (5,))
+    d = hb.to(dev)
+    model = _model(10)
+    from graph_hscn.loss import LazyLoss, criterion
+    pred = model(d.x_dict, d.edge_index_dict, d)
+    loss, _ = criterion("cross_entropy", pred, d["local"].y)
+    assert isinstance(loss, LazyLoss)
+    kept = loss.detach()
+    node = weakref.ref(pred.grad_fn)
+    loss.backward()
+    want = float(loss)
+    del pred, loss
+    gc.collect()
+    assert node() is None, "the detached loss keeps the prediction's autograd graph alive"
+    assert float(kept) == want
+
+
+def test_scn_direct_step_is_the_autograd_step_bit_for_bit():
+    from graph_hscn.data import Batch
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import SCN
+    from graph_hscn.step import ScnTrainStep
+    dev = torch.device("cuda:0")
+    graphs = make_dataset("peptides_func", 9, seed=2)
+    torch.manual_seed(0)
+    scn = SCN([16], "elu", 9, 16).to(dev)
+    big = Batch.from_data_list(graphs).to(dev)
+    big.x = big.x.float()
+    scn.zero_grad(set_to_none=True)
+    S, mc, o, total = scn.forward_graphs(big, with_total=True)
+    total.backward()
+    want = [p.grad.clone() for p in scn.parameters()]
+    st = ScnTrainStep(scn, big)
+    st.bind_grads()
+    st.run()
+    st.run()
+    torch.cuda.synchronize()
+    st.check()
+    assert torch.equal(st.S, S)
+    assert torch.equal(st.losses, torch.stack([mc.detach(), o.detach(), total.detach()]))
+    for p, w in zip(scn.parameters(), want):
+        assert torch.equal(p.grad, w)
+    g = torch.cuda.CUDAGraph()
+    keep = (S, mc, o, total)                       # eager outputs alive during the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        st.run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        st.run()
+    st.grads.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for p, w in zip(scn.parameters(), want):
+        assert torch.equal(p.grad, w)
+    del keep

@@ -213,3 +213,26 @@ def test_static_batch_buffers_pack_and_load_on_the_host():
         st.load(big)                                                             # 8 graphs into 4-graph buffers
     with pytest.raises(ValueError):
         st.load(torch.zeros(3, dtype=torch.uint8))
+
+
+def test_collate_keeps_target_rank_like_pyg():
+    """PyG's collate concatenates ``y`` along dim 0 as is: graph-level class indices stay 1-D (the reference's
+    multiclass branch, loss.py:11, needs ``true.ndim == 1``), node labels stay per node, [1, C] rows stack."""
+    from graph_hscn.data import Batch, Data, DataLoader
+    from graph_hscn.loss import criterion
+    ei = torch.tensor([[0, 1], [1, 0]])
+    gl = [Data(x=torch.zeros(2, 3), edge_index=ei, y=torch.tensor([c])) for c in (0, 2, 1, 1, 0)]
+    b = Batch.from_data_list(gl)
+    assert b.y.shape == (5,) and b.y.tolist() == [0, 2, 1, 1, 0]
+    nl = [Data(x=torch.zeros(n, 3), edge_index=ei, y=torch.arange(n)) for n in (2, 3, 4)]
+    assert Batch.from_data_list(nl).y.shape == (9,)
+    ml = [Data(x=torch.zeros(2, 3), edge_index=ei, y=torch.ones(1, 4)) for _ in range(3)]
+    assert Batch.from_data_list(ml).y.shape == (3, 4)
+    zl = [Data(x=torch.zeros(2, 3), edge_index=ei, y=torch.tensor(1.5)) for _ in range(3)]
+    assert Batch.from_data_list(zl).y.shape == (3,)
+    # through the loader into the reference's multiclass branch
+    batch = next(iter(DataLoader(gl, batch_size=5)))
+    pred = torch.randn(5, 3)
+    loss, score = criterion("cross_entropy", pred, batch.y)
+    want = torch.nn.functional.nll_loss(torch.log_softmax(pred, -1), batch.y)
+    assert torch.allclose(loss, want) and score.shape == (5, 3)

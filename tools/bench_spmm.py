@@ -32,26 +32,39 @@ def scaled_relation(tiles, seed=0, dev="cuda"):
     return Relation(ei_t, n * tiles, n * tiles), n * tiles, ei_t.size(1)
 
 
-def measure(tiles, H, iters, dev="cuda"):
-    rel, N, E = scaled_relation(tiles, dev=dev)
-    rel.check()
-    h = torch.randn(N, H, device=dev)
-    bias = torch.randn(H, device=dev)
-    dinv = rel.dinv
+def _median_s(fn, iters):
     for _ in range(3):
-        Fh.spmm_gcn_raw(rel.csr, dinv, dinv, h, bias, 1)
+        fn()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in ev:
         s.record()
-        Fh.spmm_gcn_raw(rel.csr, dinv, dinv, h, bias, 1)
+        fn()
         e.record()
     torch.cuda.synchronize()
     ts = sorted(s.elapsed_time(e) * 1e-3 for s, e in ev)
-    t = ts[len(ts) // 2]
+    return ts[len(ts) // 2]
+
+
+def measure(tiles, H, iters, dev="cuda"):
+    """Forward pass (target-keyed CSR, + bias + ReLU) and backward pass (the same kernel on the source-keyed CSR,
+    gradient rows in, no epilogue): SURVEY.md 8(d) defines the SpMM roofline over the pair,
+    ``2 * ll_bytes / (t_fwd + t_bwd)``."""
+    rel, N, E = scaled_relation(tiles, dev=dev)
+    rel.check()
+    h = torch.randn(N, H, device=dev)
+    g = torch.randn(N, H, device=dev)
+    bias = torch.randn(H, device=dev)
+    dinv = rel.dinv
+    csr_t = rel.csr_t
+    t_f = _median_s(lambda: Fh.spmm_gcn_raw(rel.csr, dinv, dinv, h, bias, 1), iters)
+    t_b = _median_s(lambda: Fh.spmm_gcn_raw(csr_t, dinv, dinv, g, None, 0), iters)
     alg = 4 * (N + 1) + 4 * E + 4 * N + 8 * N * H
-    return {"kernel": "k_spmm<4,0> (hscn_spmm_csr_gcn) fwd + bias + ReLU", "graphs": 128 * tiles, "nodes": N,
-            "edges": E, "hidden": H, "algorithmic_bytes": alg, "median_us": t * 1e6,
-            "achieved_GBs": alg / t / 1e9, "frac_of_8TBs": alg / t / 8e12}
+    return {"kernel": "k_spmm<4,0> (hscn_spmm_csr_gcn): fwd (+ bias + ReLU) and bwd (source-keyed CSR)",
+            "graphs": 128 * tiles, "nodes": N, "edges": E, "hidden": H, "algorithmic_bytes": alg,
+            "median_us": t_f * 1e6, "achieved_GBs": alg / t_f / 1e9, "frac_of_8TBs": alg / t_f / 8e12,
+            "bwd_median_us": t_b * 1e6, "bwd_achieved_GBs": alg / t_b / 1e9, "bwd_frac_of_8TBs": alg / t_b / 8e12,
+            "fwd_plus_bwd_achieved_GBs": 2 * alg / (t_f + t_b) / 1e9,
+            "fwd_plus_bwd_frac_of_8TBs": 2 * alg / (t_f + t_b) / 8e12}
 
 
 if __name__ == "__main__":
