@@ -61,6 +61,9 @@ def parse():
                          "graph); uniform: ids drawn uniformly from 0..K-1 (U ~ K virtual nodes per graph, what a trained "
                          "assignment produces).  The headline line carries the other choice's time as `other_cluster_ids`")
     ap.add_argument("--no-other-ids", action="store_true", help="skip the second (other --cluster-ids) measurement")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="f16: node features and inter-layer activations stored as IEEE half in HBM, float accumulation "
+                         "(BASELINE.json configs[4]: PCQM-Contact, 'fp16 feat + bf16 accum'); graph-resident engine only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming-spmm", action="store_true")
     ap.add_argument("--no-stage-a", action="store_true")
@@ -108,14 +111,14 @@ class KernelTimer:
         self.events = []
 
     def wrap(self, name, fn, *args):
-        if name not in self.names:
+        if name.replace("_f16", "") not in self.names:      # (the half-storage twins count as their float namesakes)
             return fn(*args)
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         rc = fn(*args)
         e.record()
-        self.events.append((name, args, s, e))
+        self.events.append((name.replace("_f16", ""), args, s, e, name))
         return rc
 
 
@@ -324,6 +327,8 @@ def main():
     B = args.batch or B0
     hb_host, graphs, _ = build_hetero_batch(shape, B, K, args.seed * 1000 + rank, dev, args.cluster_ids)
     hb = hb_host.to(dev)
+    if args.dtype == "f16":
+        hb = hb.with_feature_dtype(torch.float16)
     F = hb["local"].x.size(1)
     torch.manual_seed(0)  # identical replicas
     model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], F, args.hidden, C, args.layers).to(dev)
@@ -355,6 +360,8 @@ def main():
     if rank == 0 and world == 1 and not force_dist and not args.no_other_ids:
         oc = "uniform" if args.cluster_ids == "scn_untrained" else "scn_untrained"
         hb2 = build_hetero_batch(shape, B, K, args.seed * 1000 + rank, dev, oc)[0].to(dev)
+        if args.dtype == "f16":
+            hb2 = hb2.with_feature_dtype(torch.float16)
         ts2 = TimedStep(args, model, hb2, loss_fn, None, B, 1)
         dt2 = time_steps(ts2, args.steps, args.warmup, barrier)
         other_ids = {"cluster_ids": oc, "virtual_nodes_per_gpu": int(hb2["virtual"].num_nodes),
@@ -373,11 +380,12 @@ def main():
         E = int(hb[("local", "to", "local")].edge_index.size(1))
         Evv = int(hb[("virtual", "to", "virtual")].edge_index.size(1))
         H, L = args.hidden, args.layers
-        # SURVEY.md 8(d) algorithmic bytes, summed over the batch (fp32 values, int32 CSR indices):
-        ll_b = 4 * (N + B) + 4 * E + 4 * N + 8 * N * H          # rowptr + col + dinv + read h + write out
-        lv_b = 4 * N * H + 8 * N + 4 * V + 4 * V * H
-        vv_b = 8 * V * H + 4 * Evv
-        lin_b = 12 * N * H + 12 * V * H
+        # SURVEY.md 8(d) algorithmic bytes, summed over the batch (feature values of `sz` bytes, int32 CSR indices):
+        sz = 2 if args.dtype == "f16" else 4
+        ll_b = 4 * (N + B) + 4 * E + 4 * N + 2 * sz * N * H     # rowptr + col + dinv + read h + write out
+        lv_b = sz * N * H + 8 * N + 4 * V + sz * V * H
+        vv_b = 2 * sz * V * H + 4 * Evv
+        lin_b = 3 * sz * N * H + 3 * sz * V * H
         used_resident = model.last_engine == "resident"
         names = (["hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual",
                   "hscn_resident_bwd_with_virtual", "hscn_resident_train_step"] if used_resident
@@ -407,7 +415,7 @@ def main():
             """Average launch duration: the last recorded launch that matches is re-issued REP times back to
             back between ONE HIP-event pair on its stream (same arguments, same outputs), so the events'
             own cost and the host's launch latency are amortised instead of added to every launch."""
-            hits = [(nm, a) for (nm, a, s_, e_) in timer.events if pred(nm, a)]
+            hits = [(real, a) for (nm, a, s_, e_, real) in timer.events if pred(nm, a)]
             if not hits:
                 return float("nan"), 0
             nm, a = hits[-1]
@@ -425,8 +433,8 @@ def main():
             return s_.elapsed_time(e_) * 1e-3 / REP, REP
 
         if used_resident:
-            split = any(nm == "hscn_resident_fwd_with_virtual" for (nm, a, s_, e_) in timer.events)
-            one_launch = any(nm == "hscn_resident_train_step" for (nm, a, s_, e_) in timer.events)
+            split = any(ev[0] == "hscn_resident_fwd_with_virtual" for ev in timer.events)
+            one_launch = any(ev[0] == "hscn_resident_train_step" for ev in timer.events)
             virt_layer = lv_b + vv_b + 4 * N * H + 12 * V * H      # one layer of the virtual branch
             alg_f = L * (ll_b + lv_b + vv_b + lin_b)
             alg_b = L * (ll_b + lin_b)     # the backward only walks the local->local relation (+ its transforms)
@@ -518,7 +526,7 @@ def main():
         torch.manual_seed(1)
         scn = SCN([16], "elu", F, K).to(dev)
         bigd = Batch.from_data_list(graphs).to(dev)
-        bigd.x = bigd.x.float()
+        bigd.x = bigd.x.half() if args.dtype == "f16" else bigd.x.float()
         if scn.resident_ok(bigd):
             a_step = ScnTrainStep(scn, bigd)      # (mc + o).backward() as two launches, no autograd in the capture
             ga = capture(a_step.run)
@@ -545,7 +553,8 @@ def main():
             else f"graphs/sec (fwd+bwd) on {args.workload}",
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "f32" else "f16 storage (features + activations), f32 accumulate",
+            "data": "synthetic",
             "config": {"workload": f"Graph-HSCN stage C (HSCN fwd+loss+bwd) on {args.workload}-shaped graphs",
                        "graphs_per_gpu": B, "global_batch": B * world, "num_clusters": K, "hidden": args.hidden,
                        "layers": args.layers, "classes": C, "nodes_per_gpu": int(hb["local"].num_nodes),

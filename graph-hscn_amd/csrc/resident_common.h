@@ -8,6 +8,33 @@ namespace {
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// ---- storage type of node features and inter-layer activations in HBM: float, or IEEE half (BASELINE.json
+// configs[4]: "fp16 feat").  Arithmetic is float either way: values are widened on load, every sum (gather-reduce,
+// MFMA, pool, gradient partials) accumulates in float registers, and an activation is rounded to the storage type
+// ONCE, where it is produced -- the copy that stays in LDS for the next layer holds the same rounded value as the
+// copy that goes to HBM, so forward and backward see one and the same activation.
+typedef _Float16 half_t;
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ldf(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ldf(const half_t* p, size_t i) { return (float)p[i]; }
+__device__ __forceinline__ float4 ldf4(const float* p, size_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+__device__ __forceinline__ float4 ldf4(const half_t* p, size_t i4) {
+  const half4_t v = reinterpret_cast<const half4_t*>(p)[i4];
+  return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void stf(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void stf(half_t* p, size_t i, float v) { p[i] = (half_t)v; }
+__device__ __forceinline__ void stf4(float* p, size_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+__device__ __forceinline__ void stf4(half_t* p, size_t i4, float4 v) {
+  half4_t h;
+  h.x = (half_t)v.x; h.y = (half_t)v.y; h.z = (half_t)v.z; h.w = (half_t)v.w;
+  reinterpret_cast<half4_t*>(p)[i4] = h;
+}
+// the value an activation has after it was stored as TS (round to nearest even; float: unchanged)
+template <typename TS> __device__ __forceinline__ float rnd(float v);
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<half_t>(float v) { return (float)(half_t)v; }
+
 // Phase stamps exist only in the diagnostic build (make diag -> libhscn_diag.so); the
 // shipped kernels execute none.  Values go to a buffer nothing else reads.
 #ifdef HSCN_STAMPS

@@ -211,10 +211,11 @@ __device__ __forceinline__ void scn_losses_wave(const float* stats, float* losse
 // source-keyed for A S) are built side by side by two wave groups between the same barriers, the
 // gcn_norm degrees follow from the row lengths, and agg = A_hat x is reduced in edge order, loop last.
 // Weights land transposed: WrT / WoT [FP][H] (rows k >= F zero), brl [H], WmT [H][K], bml [K].
-template <int H>
+template <int H, typename TS>
 __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* ib, int n0, int n, int e0, int ne,
                           int g) {
   constexpr int NW = SRT / 64;
+  const TS* const xg = reinterpret_cast<const TS*>(A.x);   // node features in their storage type (float or half)
   const int K = A.K, F = A.F;
   float *xs = fb + Y.R1, *agg = fb + Y.R1 + (size_t)A.max_n * FP, *dinv = fb + Y.dinv, *dout = fb + Y.dout;
   float* WrT = fb + Y.wt;
@@ -271,7 +272,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
     const bool ok = idx < n * FP && k < F;
     xr[i] = 0.f;
     if (wbase + i * SRT < n * FP) {
-      const float t = A.x[ok ? (size_t)(n0 + r) * F + k : 0];
+      const float t = ldf(xg, ok ? (size_t)(n0 + r) * F + k : 0);
       xr[i] = ok ? t : 0.f;
     }
   }
@@ -298,7 +299,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   }
   for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
     const int i = idx / FP, k = idx - i * FP;
-    xs[idx] = k < F ? A.x[(size_t)(n0 + i) * F + k] : 0.f;
+    xs[idx] = k < F ? ldf(xg, (size_t)(n0 + i) * F + k) : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < WPT; ++i) {
@@ -369,7 +370,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   STAMP(3);
 }
 
-template <int H>
+template <int H, typename TS>
 __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NW = SRT / 64;
@@ -394,7 +395,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   int *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
   STAMP(0);
-  scn_front<H>(A, Y, fb, ib, n0, n, e0, ne, g);
+  scn_front<H, TS>(A, Y, fb, ib, n0, n, e0, ne, g);
 
   // y = act(W_rel agg + b_rel + W_root x): thread (row, o); both weight columns in registers
   {
@@ -414,9 +415,9 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
         a2 = fmaf(xv.x, wo[4 * k4 + 0], a2); a2 = fmaf(xv.y, wo[4 * k4 + 1], a2);
         a2 = fmaf(xv.z, wo[4 * k4 + 2], a2); a2 = fmaf(xv.w, wo[4 * k4 + 3], a2);
       }
-      const float v = apply_act((a1 + b) + a2, A.act);
+      const float v = rnd<TS>(apply_act((a1 + b) + a2, A.act));   // the hidden activation as its storage type holds it
       yl[i * H + o] = v;
-      A.y[(size_t)(n0 + i) * H + o] = v;
+      stf(reinterpret_cast<TS*>(A.y), (size_t)(n0 + i) * H + o, v);
     }
   }
   __syncthreads();
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   STAMP(63);
 }
 
-template <int H>
+template <int H, typename TS>
 __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NW = SRT / 64;
@@ -576,7 +577,8 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
       }
     }
     const float* pS = A.S + (size_t)n0 * K;
-    const float* py = A.y + (size_t)n0 * H;
+    const TS* py = reinterpret_cast<const TS*>(A.y) + (size_t)n0 * H;
+    const TS* xg = reinterpret_cast<const TS*>(A.x);
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int idx = threadIdx.x + i * SRT;
@@ -585,11 +587,11 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
       agr[i] = 0.f; xr[i] = 0.f; sr[i] = 0.f; yr[i] = 0.f;
       if (wbase + i * SRT < n * FP) {
         agr[i] = pag[idx < n * FP ? idx : 0];
-        const float t = A.x[okx ? (size_t)(n0 + r) * A.F + k : 0];
+        const float t = ldf(xg, okx ? (size_t)(n0 + r) * A.F + k : 0);
         xr[i] = okx ? t : 0.f;
       }
       if (wbase + i * SRT < n * K) sr[i] = pS[idx < n * K ? idx : 0];
-      if (wbase + i * SRT < n * H) yr[i] = py[idx < n * H ? idx : 0];
+      if (wbase + i * SRT < n * H) yr[i] = ldf(py, idx < n * H ? idx : 0);
     }
 #pragma unroll
     for (int i = 0; i < MPT; ++i) {
@@ -631,7 +633,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
       if (idx < n * H) yl[idx] = yr[i];
     }
     for (int idx = threadIdx.x + XPT * SRT; idx < n * K; idx += SRT) Sl[idx] = pS[idx];
-    for (int idx = threadIdx.x + XPT * SRT; idx < n * H; idx += SRT) yl[idx] = py[idx];
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * H; idx += SRT) yl[idx] = ldf(py, idx);
 #pragma unroll
     for (int i = 0; i < MPT; ++i) {
       const int d = threadIdx.x + i * SRT;
@@ -753,7 +755,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   }
   for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
     const int i = idx / FP, k = idx - i * FP;
-    xs[idx] = k < A.F ? A.x[(size_t)(n0 + i) * A.F + k] : 0.f;
+    xs[idx] = k < A.F ? ldf(reinterpret_cast<const TS*>(A.x), (size_t)(n0 + i) * A.F + k) : 0.f;
   }
   __syncthreads();
   gram_mfma<NW>(yl, H, H, xs, FP, FP, n, agg, part + oWroot, A.F, A.F);   // dW_root[o][k] = sum_i dz[i][o] x[i][k]
@@ -767,18 +769,18 @@ __global__ void k_scn_losses(const float* __restrict__ stats, float* __restrict_
 
 inline int64_t scn_param_count(int F, int H, int K) { return (int64_t)2 * H * F + H + (int64_t)K * H + K; }
 
-template <int H>
+template <int H, typename TS>
 int launch_scn(ScnArgs& A, int bwd, hipStream_t st) {
   const size_t lds = scn_layout(H, A.K, A.max_n, A.max_e, bwd).total * 4;
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
   if (bwd) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_scn_bwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_scn_bwd<H><<<(unsigned)A.B, SRT, lds, st>>>(A);
+      (void)hipFuncSetAttribute((const void*)k_scn_bwd<H, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_scn_bwd<H, TS><<<(unsigned)A.B, SRT, lds, st>>>(A);
   } else {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_scn_fwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_scn_fwd<H><<<(unsigned)A.B, SRT, lds, st>>>(A);
+      (void)hipFuncSetAttribute((const void*)k_scn_fwd<H, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_scn_fwd<H, TS><<<(unsigned)A.B, SRT, lds, st>>>(A);
   }
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
@@ -804,7 +806,7 @@ int hscn_scn_resident_supported(int F, int H, int K, int max_n, int max_e) {
 
 int64_t hscn_scn_resident_param_count(int F, int H, int K) { return scn_param_count(F, H, K); }
 
-int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+static int scn_fwd_impl(int f16, const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
                           const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
@@ -829,7 +831,8 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
   A.ex_agg = ex_agg; A.ex_dout = ex_dout; A.losses = losses; A.ticket = ticket;
   A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
   hipStream_t st = hscn_stream(stream_);
-  int rc = H == 16 ? launch_scn<16>(A, 0, st) : launch_scn<32>(A, 0, st);
+  int rc = f16 ? (H == 16 ? launch_scn<16, half_t>(A, 0, st) : launch_scn<32, half_t>(A, 0, st))
+               : (H == 16 ? launch_scn<16, float>(A, 0, st) : launch_scn<32, float>(A, 0, st));
   if (rc) return rc;
   if (!ticket) {   // no ticket counter: the statistics are reduced by a launch of their own
     k_scn_losses<<<1, 64, 0, st>>>(stats, losses, (int)B);
@@ -838,7 +841,7 @@ int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, 
   return 0;
 }
 
-int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+static int scn_bwd_impl(int f16, const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                           const float* W_mlp, const float* S, const float* y, const float* stats, const float* ss,
                           const float* g_mc, const float* g_o, const int32_t* ex_rowptr_d, const int32_t* ex_col_d,
@@ -860,11 +863,59 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
   A.partials = partials; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
   A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
   hipStream_t st = hscn_stream(stream_);
-  int rc = H == 16 ? launch_scn<16>(A, 1, st) : launch_scn<32>(A, 1, st);
+  int rc = f16 ? (H == 16 ? launch_scn<16, half_t>(A, 1, st) : launch_scn<32, half_t>(A, 1, st))
+               : (H == 16 ? launch_scn<16, float>(A, 1, st) : launch_scn<32, float>(A, 1, st));
   if (rc) return rc;
   k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P, -1, 0.f);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+
+int hscn_scn_resident_fwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                          const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                          const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
+                          const float* b_mlp, int max_n, int max_e, float* S, float* y, float* stats, float* ss,
+                          float* losses, int32_t* ticket, int32_t* ex_rowptr_d, int32_t* ex_col_d,
+                          int32_t* ex_rowptr_s, int32_t* ex_col_s, float* ex_agg, float* ex_dout, int32_t* flag,
+                          void* stream_) {
+  return scn_fwd_impl(0, x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_rel, b_rel, W_root, W_mlp, b_mlp, max_n,
+                      max_e, S, y, stats, ss, losses, ticket, ex_rowptr_d, ex_col_d, ex_rowptr_s, ex_col_s, ex_agg,
+                      ex_dout, flag, stream_);
+}
+int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                          const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                          const float* W_mlp, const float* S, const float* y, const float* stats, const float* ss,
+                          const float* g_mc, const float* g_o, const int32_t* ex_rowptr_d, const int32_t* ex_col_d,
+                          const int32_t* ex_rowptr_s, const int32_t* ex_col_s, const float* ex_agg,
+                          const float* ex_dout, int max_n, int max_e, float* partials, float* grads, int32_t* flag,
+                          void* stream_) {
+  return scn_bwd_impl(0, x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_mlp, S, y, stats, ss, g_mc, g_o,
+                      ex_rowptr_d, ex_col_d, ex_rowptr_s, ex_col_s, ex_agg, ex_dout, max_n, max_e, partials, grads,
+                      flag, stream_);
+}
+// IEEE-half storage of the node features x and of the saved hidden activation y (include/hscn.h); S, the
+// statistics, the exported aggregation A_hat x (an accumulator output) and every gradient stay float.
+int hscn_scn_resident_fwd_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                              const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                              const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
+                              const float* b_mlp, int max_n, int max_e, float* S, hscn_half* y, float* stats,
+                              float* ss, float* losses, int32_t* ticket, int32_t* ex_rowptr_d, int32_t* ex_col_d,
+                              int32_t* ex_rowptr_s, int32_t* ex_col_s, float* ex_agg, float* ex_dout, int32_t* flag,
+                              void* stream_) {
+  return scn_fwd_impl(1, (const float*)x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_rel, b_rel, W_root, W_mlp,
+                      b_mlp, max_n, max_e, S, (float*)y, stats, ss, losses, ticket, ex_rowptr_d, ex_col_d, ex_rowptr_s,
+                      ex_col_s, ex_agg, ex_dout, flag, stream_);
+}
+int hscn_scn_resident_bwd_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                              const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                              const float* W_mlp, const float* S, const hscn_half* y, const float* stats,
+                              const float* ss, const float* g_mc, const float* g_o, const int32_t* ex_rowptr_d,
+                              const int32_t* ex_col_d, const int32_t* ex_rowptr_s, const int32_t* ex_col_s,
+                              const float* ex_agg, const float* ex_dout, int max_n, int max_e, float* partials,
+                              float* grads, int32_t* flag, void* stream_) {
+  return scn_bwd_impl(1, (const float*)x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_mlp, S, (const float*)y,
+                      stats, ss, g_mc, g_o, ex_rowptr_d, ex_col_d, ex_rowptr_s, ex_col_s, ex_agg, ex_dout, max_n,
+                      max_e, partials, grads, flag, stream_);
 }
 
 }  // extern "C"

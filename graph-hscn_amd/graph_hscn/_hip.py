@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -75,6 +75,10 @@ _SIGNATURES = {
     "hscn_resident_bwd_with_virtual": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                                c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P]),
 }
+# IEEE-half storage twins (include/hscn.h: hscn_resident_*_f16): same argument lists
+for _n in ("hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual", "hscn_resident_bwd_with_virtual",
+           "hscn_scn_resident_fwd", "hscn_scn_resident_bwd"):
+    _SIGNATURES[_n + "_f16"] = _SIGNATURES[_n]
 
 
 class HipExtensionMissing(RuntimeError):

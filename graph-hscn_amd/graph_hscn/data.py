@@ -212,6 +212,24 @@ class HeteroBatch(HeteroData):
     def batch_size(self) -> int:
         return int(self.num_graphs)
 
+    def with_feature_dtype(self, dtype) -> "HeteroBatch":
+        """The same batch with the node features of every type stored as ``dtype`` (``torch.float16``: the
+        half-storage mode of the graph-resident engine, BASELINE.json configs[4]; integer-valued atom features
+        below 2048 are exact in half).  Everything else is shared, not copied."""
+        out = self.__class__()
+        out._nodes = {}
+        for k, st in self._nodes.items():
+            ns = Store()
+            ns._d.update(st._d)
+            if "x" in st:
+                ns._d["x"] = st.x.to(dtype)
+            out._nodes[k] = ns
+        out._edges = self._edges
+        for k, v in self.__dict__.items():
+            if k not in ("_nodes", "_edges", "_resident_meta"):
+                out.__dict__[k] = v
+        return out
+
 
 class DataLoader:
     """List-backed mini-batch iterator (reference: loader/loader.py:48-60 wraps the

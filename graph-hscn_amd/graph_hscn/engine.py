@@ -74,8 +74,17 @@ def meta_from_batch(batch, device) -> Optional[ResidentMeta]:
     return meta
 
 
-def supported(F: int, H: int, L: int, C: int, meta: ResidentMeta) -> bool:
+def supported(F: int, H: int, L: int, C: int, meta: ResidentMeta, dtype=torch.float32) -> bool:
+    if dtype == torch.float16 and H > 32:
+        return False                 # half storage: H in {16, 32} (csrc/resident_f16.hip)
+    if dtype not in (torch.float32, torch.float16):
+        return False
     return bool(_hip.lib().hscn_resident_supported(F, H, L, C, meta.max_n, meta.max_v, meta.max_ell, meta.max_evv))
+
+
+def storage_suffix(dtype) -> str:
+    """Entry-point suffix for the storage type of node features / activations (include/hscn.h)."""
+    return "_f16" if dtype == torch.float16 else ""
 
 
 def _ptr_table(ts: List[Optional[Tensor]]):
@@ -137,6 +146,10 @@ class HSCNResidentFn(Function):
         H, C = W1.shape[0], W2.shape[0]
         x_local = x_local.contiguous()
         x_virtual = x_virtual.contiguous()
+        sdt = x_local.dtype                       # storage type of features and activations: float32 or float16
+        if x_virtual.dtype != sdt:
+            raise TypeError("local and virtual node features must share one storage dtype")
+        sfx = storage_suffix(sdt)
         N, F = x_local.shape
         V = x_virtual.shape[0]
         B = meta.num_graphs
@@ -145,13 +158,13 @@ class HSCNResidentFn(Function):
         # (the extra workgroups pay only while they land on CUs the batch leaves idle: 2B <= number of CUs)
         defer = bool(compute_virtual and overlap and V > 0 and need_bwd and not keep_virtual and L >= 2
                      and 2 * B <= _cu_count(dev))
-        acts = torch.empty(L, N, H, dtype=torch.float32, device=dev)
+        acts = torch.empty(L, N, H, dtype=sdt, device=dev)
         pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
         z = torch.empty(B, H, dtype=torch.float32, device=dev)
         pred = torch.empty(B, C, dtype=torch.float32, device=dev)
         # sigmoid(pred) costs the head ten more stores; with it the loss tail can ride on the backward launch
         score = torch.empty(B, C, dtype=torch.float32, device=dev) if need_bwd else None
-        xv_out = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev) if (compute_virtual and keep_virtual) else None
+        xv_out = torch.empty(max(V, 1), H, dtype=sdt, device=dev) if (compute_virtual and keep_virtual) else None
         # source-keyed CSR + degree norm: built in LDS by the forward launch, reused by the backward launch
         E_ll = ei_ll.size(1)
         csr_rp = torch.empty(N + B, dtype=torch.int32, device=dev) if need_bwd else None
@@ -163,24 +176,25 @@ class HSCNResidentFn(Function):
             E_lv, E_vv = ei_lv.size(1), ei_vv.size(1)
             state = (torch.empty(V + B, dtype=torch.int32, device=dev), torch.empty(max(E_lv, 1), dtype=torch.int32, device=dev),
                      torch.empty(V + B, dtype=torch.int32, device=dev), torch.empty(max(E_vv, 1), dtype=torch.int32, device=dev),
-                     torch.empty(V, dtype=torch.float32, device=dev), torch.empty(V, H, dtype=torch.float32, device=dev))
+                     torch.empty(V, dtype=torch.float32, device=dev), torch.empty(V, H, dtype=sdt, device=dev))
             job = _VirtualJob(ptr(x_virtual), ptr(ei_vv), E_vv, ptr(ei_lv), E_lv, ptr(meta.vptr), ptr(meta.eptr_vv),
                               ptr(meta.eptr_lv), ctypes.cast(table, ctypes.c_void_p), None, V, meta.max_v,
                               meta.max_evv, float(slope), *[ptr(t) for t in state])
-            call("hscn_resident_fwd_with_virtual", ptr(x_local), ptr(ei_ll), E_ll, ptr(meta.lptr), ptr(meta.eptr_ll),
+            call("hscn_resident_fwd_with_virtual" + sfx, ptr(x_local), ptr(ei_ll), E_ll, ptr(meta.lptr), ptr(meta.eptr_ll),
                  N, B, F, H, L, C, head_act, table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_ell,
                  ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(score), ptr(csr_rp), ptr(csr_col), ptr(dinv),
                  ptr(meta.flag), ctypes.byref(job), stream())
             # what the backward launch needs to run the rest of the virtual branch beside itself
             ctx.virtual = (x_virtual, ei_vv, ei_lv, params[: 9 * L], table, float(slope), state)
         else:
-            call("hscn_resident_fwd", ptr(x_local), ptr(x_virtual), ptr(ei_ll), ei_ll.size(1), ptr(ei_vv),
+            call("hscn_resident_fwd" + sfx, ptr(x_local), ptr(x_virtual), ptr(ei_ll), ei_ll.size(1), ptr(ei_vv),
                  ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll),
                  ptr(meta.eptr_vv), ptr(meta.eptr_lv), N, V, B, F, H, L, C, head_act, float(slope), table,
                  ptr(W1), ptr(b1), ptr(W2), ptr(b2), meta.max_n, meta.max_v, meta.max_ell, meta.max_evv,
                  int(bool(compute_virtual)), ptr(acts), ptr(pooled), ptr(z), ptr(pred), ptr(score), ptr(xv_out),
                  ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(meta.flag), stream())
         ctx.meta, ctx.head_act, ctx.dims = meta, head_act, (N, F, H, L, C, B)
+        ctx.sfx = sfx
         ctx.csr = (csr_rp, csr_col, dinv)
         ctx.save_for_backward(x_local, ei_ll, acts, pooled, z, W1, W2, *[params[9 * l] for l in range(L)])
         ret_xv = xv_out if keep_virtual else None
@@ -224,15 +238,15 @@ class HSCNResidentFn(Function):
             global last_deferred_virtual
             x_virtual, ei_vv, ei_lv, _keep, vtable, slope, state = ctx.virtual
             V = x_virtual.shape[0]
-            xv = torch.empty(max(V, 1), H, dtype=torch.float32, device=dev)
+            xv = torch.empty(max(V, 1), H, dtype=x_virtual.dtype, device=dev)
             job = _VirtualJob(ptr(x_virtual), ptr(ei_vv), ei_vv.size(1), ptr(ei_lv), ei_lv.size(1), ptr(meta.vptr),
                               ptr(meta.eptr_vv), ptr(meta.eptr_lv), ctypes.cast(vtable, ctypes.c_void_p), ptr(xv),
                               V, meta.max_v, meta.max_evv, slope, *[ptr(t) for t in state])
-            call("hscn_resident_bwd_with_virtual", *args, ctypes.byref(job), stream())
+            call("hscn_resident_bwd_with_virtual" + ctx.sfx, *args, ctypes.byref(job), stream())
             last_deferred_virtual = xv
             ctx.virtual = None
         else:
-            call("hscn_resident_bwd", *args, stream())
+            call("hscn_resident_bwd" + ctx.sfx, *args, stream())
         out: List[Optional[Tensor]] = [None] * (7 + 9 * L + 4)
         off = 0
         for l in range(L):
@@ -307,8 +321,11 @@ class SCNResidentFn(Function):
         H, K = W_rel.shape[0], W_mlp.shape[0]
         B = meta.num_graphs
         dev = x.device
+        if x.dtype not in (torch.float32, torch.float16):
+            raise TypeError("node features must be float32 or float16")
+        ctx.sfx = storage_suffix(x.dtype)
         S = torch.empty(N, K, dtype=torch.float32, device=dev)
-        y = torch.empty(N, H, dtype=torch.float32, device=dev)
+        y = torch.empty(N, H, dtype=x.dtype, device=dev)        # saved hidden activation: the features' storage type
         stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
         ss = torch.empty(B, K, K, dtype=torch.float32, device=dev)
         losses = torch.empty(3, dtype=torch.float32, device=dev)
@@ -322,7 +339,7 @@ class SCNResidentFn(Function):
             ex = (torch.empty(N + B, dtype=torch.int32, device=dev), torch.empty(max(E, 1), dtype=torch.int32, device=dev),
                   torch.empty(N + B, dtype=torch.int32, device=dev), torch.empty(max(E, 1), dtype=torch.int32, device=dev),
                   torch.empty(max(N, 1), 16, dtype=torch.float32, device=dev), torch.empty(max(N, 1), dtype=torch.float32, device=dev))
-        call("hscn_scn_resident_fwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
+        call("hscn_scn_resident_fwd" + ctx.sfx, ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
              F, H, K, act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), meta.max_n, meta.max_e,
              ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(losses), ptr(meta.ticket), *([ptr(t) for t in ex] if ex else [None] * 6),
              ptr(meta.flag), stream())
@@ -347,7 +364,7 @@ class SCNResidentFn(Function):
             g_o = g_total if g_o is None else g_o + g_total
         g_mc = None if g_mc is None else g_mc.reshape(1).contiguous()
         g_o = None if g_o is None else g_o.reshape(1).contiguous()
-        call("hscn_scn_resident_bwd", ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
+        call("hscn_scn_resident_bwd" + ctx.sfx, ptr(x), ptr(edge_index) if E else None, E, ptr(meta.nptr), ptr(meta.eptr), N, B,
              F, H, K, ctx.act, ptr(W_mlp), ptr(S), ptr(y), ptr(stats), ptr(ss), ptr(g_mc), ptr(g_o), *[ptr(t) for t in ctx.ex], meta.max_n, meta.max_e,
              ptr(partials), ptr(grads), ptr(meta.flag), stream())
         o = 0

@@ -103,13 +103,18 @@ class SCN(nn.Module):
             meta = _engine.scn_meta(data, dev)
             x = data.x if data.x.is_cuda else data.x.to(dev)
             ei = data.edge_index if data.edge_index.is_cuda else data.edge_index.to(dev)
-            S, mc, o, total = _engine.SCNResidentFn.apply(x.float(), ei, meta, _engine.ACT[self.mp.act],
+            if x.dtype != torch.float16:      # (half features stay half: include/hscn.h, hscn_scn_resident_*_f16)
+                x = x.float()
+            S, mc, o, total = _engine.SCNResidentFn.apply(x, ei, meta, _engine.ACT[self.mp.act],
                                                           conv.lin_rel.weight, conv.lin_rel.bias, conv.lin_root.weight,
                                                           lin.weight, lin.bias)
             self.last_engine = "resident"
             return (S, mc, o, total) if with_total else (S, mc, o)
         from ..nn.pool import gcn_norm
         self.last_engine = "layered"
+        if data.x.dtype == torch.float16:
+            raise RuntimeError("half-precision feature storage runs on the fused stage-A launch only (mp_units=[H], "
+                               "mlp_units=[], graphs that fit one CU's LDS)")
         ei, ew = gcn_norm(data.edge_index.to(dev), None, int(data.num_nodes), add_self_loops=True)
         node_ptr = data.ptr.to(dev).to(torch.int32) if "ptr" in data and data.ptr is not None else None
         S, mc, o, _ = self.forward(data.x.to(dev).float(), ei, ew, node_ptr=node_ptr)
@@ -178,7 +183,8 @@ class HSCN(nn.Module):
         ok = ok and self._resident_params() is not None
         meta = _engine.meta_from_batch(batch, x_dict["local"].device) if ok else None
         H, C = self.lin_1.out_channels, self.lin_2.out_channels
-        if meta is None or not _engine.supported(x_dict["local"].size(1), H, len(self.convs), C, meta):
+        if meta is None or not _engine.supported(x_dict["local"].size(1), H, len(self.convs), C, meta,
+                                                 x_dict["local"].dtype):
             if self.engine == "resident":
                 raise RuntimeError("engine='resident' requested but the batch/model does not qualify "
                                    "(needs a graph_hscn HeteroBatch, GAT/GCN/GCN relations, H in {16,32,64}, "
@@ -230,6 +236,9 @@ class HSCN(nn.Module):
             self.last_engine = "resident"
             return self._forward_resident(x_dict, edge_index_dict, *plan)
         self.last_engine = "layered"
+        if x_dict["local"].dtype == torch.float16:
+            raise RuntimeError("half-precision feature storage runs on the graph-resident engine only (H in {16, 32}, "
+                               "a graph_hscn HeteroBatch, graphs that fit one CU's LDS)")
         relu = ACT_DICT["relu"]
         for conv in self.convs:
             x_dict = conv(x_dict, edge_index_dict)

@@ -35,7 +35,11 @@ class StaticHeteroBatch:
     All fields are views of ONE flat byte buffer, so a batch that was ``pack``-ed ahead of time (on the
     device or in pinned host memory) is loaded by a single copy."""
 
-    def __init__(self, batches: Iterable[HeteroBatch], device, num_classes: Optional[int] = None):
+    def __init__(self, batches: Iterable[HeteroBatch], device, num_classes: Optional[int] = None,
+                 feature_dtype=torch.float32):
+        """``feature_dtype``: storage type of the node features in the static buffers (``torch.float16``: the
+        half-storage mode of the graph-resident engine; ``load`` converts)."""
+        self.feature_dtype = feature_dtype
         batches = list(batches)
         if not batches:
             raise ValueError("need at least one batch to size the buffers")
@@ -57,6 +61,7 @@ class StaticHeteroBatch:
         """Buffers for batches of ``num_graphs`` graphs with at most the given totals (nodes, virtual nodes,
         edges per relation) and per-graph maxima (what sizes the LDS of the graph-resident launches)."""
         self = cls.__new__(cls)
+        self.feature_dtype = torch.float32
         self._allocate(num_graphs, device, num_nodes, num_virtual, num_edges, max_nodes, max_edges, num_features,
                        num_classes)
         return self
@@ -68,7 +73,8 @@ class StaticHeteroBatch:
         self.E = {et: max(int(E[et]), 1) for et in (LL, VV, LV)}
         self.max_nodes = {k: int(v) for k, v in max_nodes.items()}
         self.max_edges = {et: int(max_edges[et]) for et in (LL, VV, LV)}
-        fields = [("x_local", torch.float32, (self.N, F)), ("x_virtual", torch.float32, (self.V, F))]
+        fdt = getattr(self, "feature_dtype", torch.float32)
+        fields = [("x_local", fdt, (self.N, F)), ("x_virtual", fdt, (self.V, F))]
         for nt, n in (("local", self.N), ("virtual", self.V)):
             fields += [(f"ptr_{nt}", torch.int64, (G + 1,)), (f"ptr32_{nt}", torch.int32, (G + 1,)),
                        (f"batch_{nt}", torch.int64, (n,))]

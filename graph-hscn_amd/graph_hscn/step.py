@@ -74,8 +74,11 @@ class ResidentTrainStep:
         H, C = W1.shape[0], W2.shape[0]
         self.x_local = x_dict["local"].contiguous()
         self.x_virtual = x_dict["virtual"].contiguous()
-        if self.x_local.dtype != torch.float32:
-            raise TypeError("node features must be float32 (train/train.py:79 casts them)")
+        sdt = self.x_local.dtype        # storage type of features and activations (include/hscn.h: *_f16 twins)
+        if sdt not in (torch.float32, torch.float16) or self.x_virtual.dtype != sdt:
+            raise TypeError("node features must be float32 (train/train.py:79 casts them) or float16, local and "
+                            "virtual alike")
+        self._sfx = _engine.storage_suffix(sdt)
         self.ei = {k: ei_dict[k].contiguous() for k in (LL, VV, LV)}
         N, F = self.x_local.shape
         V = self.x_virtual.shape[0]
@@ -93,21 +96,21 @@ class ResidentTrainStep:
         self._wll_table = _engine._ptr_table([params[9 * l] for l in range(L)])
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        self.acts = torch.empty(L, N, H, **f32)
+        self.acts = torch.empty(L, N, H, dtype=sdt, device=dev)
         self.pooled = torch.empty(B, H, **f32)
         self.z = torch.empty(B, H, **f32)
         self.pred = torch.empty(B, C, **f32)
         self.score = torch.empty(B, C, **f32)
         E_ll, E_vv, E_lv = (self.ei[k].size(1) for k in (LL, VV, LV))
         self.csr = (torch.empty(N + B, **i32), torch.empty(max(E_ll, 1), **i32), torch.empty(max(N, 1), **f32))
-        self.virtual = torch.empty(max(V, 1), H, **f32) if model.compute_virtual else None
+        self.virtual = torch.empty(max(V, 1), H, dtype=sdt, device=dev) if model.compute_virtual else None
         # the virtual branch rides on the two launches as extra workgroups while they land on idle CUs
         self.defer = bool(model.compute_virtual and model.overlap_virtual and V > 0 and L >= 2
                           and 2 * B <= _engine._cu_count(dev))
         self._state = None
         if self.defer:
             self._state = (torch.empty(V + B, **i32), torch.empty(max(E_lv, 1), **i32), torch.empty(V + B, **i32),
-                           torch.empty(max(E_vv, 1), **i32), torch.empty(V, **f32), torch.empty(V, H, **f32))
+                           torch.empty(max(E_vv, 1), **i32), torch.empty(V, **f32), torch.empty(V, H, dtype=sdt, device=dev))
         P = int(_hip.lib().hscn_resident_param_count(F, H, L, C))
         self.P = P
         self.partials = torch.empty(B, P + 1, **f32)
@@ -157,20 +160,20 @@ class ResidentTrainStep:
                     None, None, ptr(csr_rp), ptr(csr_col), ptr(dinv), m.max_n, m.max_ell, ptr(self.partials),
                     ptr(self.grads), ptr(m.flag), ctypes.byref(self._tail))
         if self.defer:
-            call("hscn_resident_fwd_with_virtual", ptr(self.x_local), ptr(ei_ll), E_ll, ptr(m.lptr), ptr(m.eptr_ll),
+            call("hscn_resident_fwd_with_virtual" + self._sfx, ptr(self.x_local), ptr(ei_ll), E_ll, ptr(m.lptr), ptr(m.eptr_ll),
                  N, B, F, H, L, C, self.head_act, self._table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), m.max_n,
                  m.max_ell, ptr(self.acts), ptr(self.pooled), ptr(self.z), ptr(self.pred), ptr(self.score),
                  ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(m.flag), ctypes.byref(self._job(None)), st)
-            call("hscn_resident_bwd_with_virtual", *bwd_args, ctypes.byref(self._job(self.virtual)), st)
+            call("hscn_resident_bwd_with_virtual" + self._sfx, *bwd_args, ctypes.byref(self._job(self.virtual)), st)
         else:
             cv = int(bool(self.model.compute_virtual))
-            call("hscn_resident_fwd", ptr(self.x_local), ptr(self.x_virtual), ptr(ei_ll), E_ll, ptr(self.ei[VV]),
+            call("hscn_resident_fwd" + self._sfx, ptr(self.x_local), ptr(self.x_virtual), ptr(ei_ll), E_ll, ptr(self.ei[VV]),
                  self.ei[VV].size(1), ptr(self.ei[LV]), self.ei[LV].size(1), ptr(m.lptr), ptr(m.vptr),
                  ptr(m.eptr_ll), ptr(m.eptr_vv), ptr(m.eptr_lv), N, V, B, F, H, L, C, self.head_act, self.slope,
                  self._table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), m.max_n, m.max_v, m.max_ell, m.max_evv, cv,
                  ptr(self.acts), ptr(self.pooled), ptr(self.z), ptr(self.pred), ptr(self.score),
                  ptr(self.virtual) if cv else None, ptr(csr_rp), ptr(csr_col), ptr(dinv), ptr(m.flag), st)
-            call("hscn_resident_bwd", *bwd_args, st)
+            call("hscn_resident_bwd" + self._sfx, *bwd_args, st)
         return self.loss
 
     def check(self) -> None:
@@ -197,7 +200,9 @@ class ScnTrainStep:
         dev = conv.lin_rel.weight.device
         self.model = model
         self.meta = meta = _engine.scn_meta(data, dev)
-        self.x = (data.x if data.x.is_cuda else data.x.to(dev)).float().contiguous()
+        x = data.x if data.x.is_cuda else data.x.to(dev)
+        self.x = (x if x.dtype == torch.float16 else x.float()).contiguous()
+        self._sfx = _engine.storage_suffix(self.x.dtype)
         self.ei = (data.edge_index if data.edge_index.is_cuda else data.edge_index.to(dev)).contiguous()
         self.act = _engine.ACT[model.mp.act]
         self._mp = [conv.lin_rel.weight, conv.lin_rel.bias, conv.lin_root.weight, lin.weight, lin.bias]
@@ -208,7 +213,7 @@ class ScnTrainStep:
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.S = torch.empty(N, K, **f32)
-        self.y = torch.empty(N, H, **f32)
+        self.y = torch.empty(N, H, dtype=self.x.dtype, device=dev)
         self.stats = torch.empty(B, 4, **f32)
         self.ss = torch.empty(B, K, K, **f32)
         self.losses = torch.empty(3, **f32)
@@ -241,10 +246,10 @@ class ScnTrainStep:
         W_rel, b_rel, W_root, W_mlp, b_mlp = (p.contiguous() for p in self._mp)
         st = stream()
         eip = ptr(self.ei) if E else None
-        call("hscn_scn_resident_fwd", ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
+        call("hscn_scn_resident_fwd" + self._sfx, ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
              ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), m.max_n, m.max_e, ptr(self.S), ptr(self.y),
              ptr(self.stats), ptr(self.ss), ptr(self.losses), ptr(m.ticket), *[ptr(t) for t in self.ex], ptr(m.flag), st)
-        call("hscn_scn_resident_bwd", ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
+        call("hscn_scn_resident_bwd" + self._sfx, ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
              ptr(W_mlp), ptr(self.S), ptr(self.y), ptr(self.stats), ptr(self.ss), ptr(self.one), ptr(self.one),
              *[ptr(t) for t in self.ex], m.max_n, m.max_e, ptr(self.partials), ptr(self.grads), ptr(m.flag), st)
         return self.losses[2]

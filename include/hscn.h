@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 3
+#define HSCN_ABI_VERSION 4
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -428,6 +428,50 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const hscn_loss_tail* tail /*or NULL*/, const hscn_virtual_job* job, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * BASELINE.json configs[4] ("fp16 feat + bf16 accum", PCQM-Contact): the four launches above with IEEE-half
+ * STORAGE of node features and inter-layer activations.  The reference has no reduced-precision mode (no
+ * autocast / half anywhere); these entry points replace the same call sites as their float
+ * twins (model/hscn.py:102-114, train/train.py:76-87) for a caller that keeps `x` in half.
+ *   half (hscn_half = the 16 bits of an IEEE binary16): x_local, x_virtual, acts, xv_out, and in `job`:
+ *   x_virtual, xv_out, st_xv (declared float* there; they point to half arrays for these entry points);
+ *   float: parameters, pooled, z, pred, score, degree norms, partials, grads.  Every sum accumulates in float
+ *   registers (a superset of bf16 accumulation); an activation is rounded to half once, where it is produced.
+ *   H in {16, 32}; everything else as documented for the float entry points.
+ * ------------------------------------------------------------------------- */
+typedef uint16_t hscn_half;
+int hscn_resident_fwd_f16(const hscn_half* x_local, const hscn_half* x_virtual, const int64_t* ei_ll, int64_t E_ll,
+                          const int64_t* ei_vv, int64_t E_vv, const int64_t* ei_lv, int64_t E_lv,
+                          const int32_t* lptr, const int32_t* vptr, const int32_t* eptr_ll, const int32_t* eptr_vv,
+                          const int32_t* eptr_lv, int64_t N, int64_t V, int64_t B, int F, int H, int L, int C,
+                          int head_act, float slope, const void* const* layer_params_host /* L x 9 */,
+                          const float* W1, const float* b1, const float* W2, const float* b2, int max_n, int max_v,
+                          int max_ell, int max_evv, int compute_virtual, hscn_half* acts, float* pooled, float* z,
+                          float* pred, float* score, hscn_half* xv_out, int32_t* csr_rowptr_t, int32_t* csr_col_t,
+                          float* dinv_out, int32_t* flag, void* stream);
+int hscn_resident_bwd_f16(const hscn_half* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                          const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
+                          const void* const* W_ll_host /* L */, const float* W1, const float* W2,
+                          const hscn_half* acts, const float* pooled, const float* z, const float* g_pred,
+                          const float* g_scale, const int32_t* csr_rowptr_t, const int32_t* csr_col_t,
+                          const float* dinv, int max_n, int max_ell, float* partials /*[B][P]*/,
+                          float* grads /*[P]*/, int32_t* flag, const hscn_loss_tail* tail, void* stream);
+int hscn_resident_fwd_with_virtual_f16(const hscn_half* x_local, const int64_t* ei_ll, int64_t E_ll,
+                                       const int32_t* lptr, const int32_t* eptr_ll, int64_t N, int64_t B, int F,
+                                       int H, int L, int C, int head_act, const void* const* layer_params_host,
+                                       const float* W1, const float* b1, const float* W2, const float* b2, int max_n,
+                                       int max_ell, hscn_half* acts, float* pooled, float* z, float* pred,
+                                       float* score, int32_t* csr_rowptr_t, int32_t* csr_col_t, float* dinv,
+                                       int32_t* flag, const hscn_virtual_job* job, void* stream);
+int hscn_resident_bwd_with_virtual_f16(const hscn_half* x_local, const int64_t* ei_ll, int64_t E_ll,
+                                       const int32_t* lptr, const int32_t* eptr_ll, int64_t N, int64_t B, int F,
+                                       int H, int L, int C, int head_act, const void* const* W_ll_host,
+                                       const float* W1, const float* W2, const hscn_half* acts, const float* pooled,
+                                       const float* z, const float* g_pred, const float* g_scale,
+                                       const int32_t* csr_rowptr_t, const int32_t* csr_col_t, const float* dinv,
+                                       int max_n, int max_ell, float* partials, float* grads, int32_t* flag,
+                                       const hscn_loss_tail* tail, const hscn_virtual_job* job, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * a2/a4/a6  stage A, graph-resident engine: the body of the reference's clustering loop
  * (train/train_clustering.py:37-47) for a batch of RAW graphs in one launch --
  * gcn_norm(add_self_loops=True) folded into the CSR walk, SCN.forward for
@@ -466,6 +510,24 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
                           const int32_t* ex_rowptr_d, const int32_t* ex_col_d, const int32_t* ex_rowptr_s,
                           const int32_t* ex_col_s, const float* ex_agg, const float* ex_dout, int max_n, int max_e,
                           float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+
+/* IEEE-half storage twins of the two stage-A launches (BASELINE.json configs[4]): x [N,F] and the saved hidden
+ * activation y [N,H] are half (y rounded once, where it is produced); S, stats, ss, losses, the exported
+ * aggregation ex_agg and all gradients stay float.  Same call sites as the float twins. */
+int hscn_scn_resident_fwd_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                              const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                              const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
+                              const float* b_mlp, int max_n, int max_e, float* S, hscn_half* y, float* stats,
+                              float* ss, float* losses /*[3]*/, int32_t* ticket, int32_t* ex_rowptr_d,
+                              int32_t* ex_col_d, int32_t* ex_rowptr_s, int32_t* ex_col_s, float* ex_agg,
+                              float* ex_dout, int32_t* flag, void* stream);
+int hscn_scn_resident_bwd_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                              const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                              const float* W_mlp, const float* S, const hscn_half* y, const float* stats,
+                              const float* ss, const float* g_mc, const float* g_o, const int32_t* ex_rowptr_d,
+                              const int32_t* ex_col_d, const int32_t* ex_rowptr_s, const int32_t* ex_col_s,
+                              const float* ex_agg, const float* ex_dout, int max_n, int max_e,
+                              float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,8 +76,14 @@ class SCN(nn.Module):
             x = self._mlp_act(x) if isinstance(m, nn.Identity) else m(x)
         return x
 
-    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor]):
+    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], store: Optional[Callable] = None):
+        """``store``: reduced-precision storage emulation (see ``HSCN.forward``): applied to the input features
+        and to the message-passing stack's output (the hidden activation the backward re-reads)."""
+        if store is not None:
+            x = store(x)
         x = self.mp(x, edge_index, edge_weight)
+        if store is not None:
+            x = store(x)
         s = self._run_mlp(x)
         adj = P.to_dense_adj(edge_index)
         _, _, mc_loss, o_loss = P.dense_mincut_pool(x, adj, s)
@@ -117,10 +123,21 @@ class HSCN(nn.Module):
         self.lin_1 = P.PygLinear(hidden_channels, hidden_channels)
         self.lin_2 = P.PygLinear(hidden_channels, num_classes)
 
-    def forward(self, x_dict: dict, edge_index_dict: dict, batch_local: Tensor, num_graphs: Optional[int] = None) -> Tensor:
+    def forward(self, x_dict: dict, edge_index_dict: dict, batch_local: Tensor, num_graphs: Optional[int] = None,
+                store: Optional[Callable] = None, keep: Optional[dict] = None) -> Tensor:
+        """``store``: emulation of a reduced-precision STORAGE type for node features and inter-layer activations
+        (BASELINE.json configs[4]; the reference itself has no such mode): applied to the input features and to
+        every layer's output of both node types -- the points at which the HIP kernels round -- with float32
+        arithmetic in between (``half_storage`` below).  ``keep``: a dict that receives the final ``x_dict``."""
+        if store is not None:
+            x_dict = {k: store(v) for k, v in x_dict.items()}
         for conv in self.convs:
             x_dict = conv(x_dict, edge_index_dict)
             x_dict = {k: v.relu() for k, v in x_dict.items()}
+            if store is not None:
+                x_dict = {k: store(v) for k, v in x_dict.items()}
+        if keep is not None:
+            keep.update(x_dict)
         x = P.global_mean_pool(x_dict["local"], batch_local, num_graphs)
         x = self.activation(self.lin_1(x))
         return self.lin_2(x)
@@ -168,6 +185,12 @@ def criterion(loss_fn: str, pred: Tensor, true: Tensor):
         true = true.float()
         return F.binary_cross_entropy_with_logits(pred, true, reduction="mean"), torch.sigmoid(pred)
     return F.l1_loss(pred, true), torch.sigmoid(pred)
+
+
+def half_storage(t: Tensor) -> Tensor:
+    """Round to IEEE half and widen again; the gradient passes straight through (the HIP backward treats the
+    stored value as the activation)."""
+    return t + (t.half().float() - t).detach()
 
 
 def scn_step_single_graph(model: SCN, x: Tensor, edge_index: Tensor):

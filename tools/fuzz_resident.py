@@ -115,7 +115,11 @@ def run(cases, seed, verbose=True):
                 msgs.append(f"score maxdiff {d:.2e}")
             xv = engine.last_deferred_virtual if (overlap and L >= 2 and xo["virtual"].size(0) > 0 and 2 * B <= 256) else pm.last_virtual
             if xv is not None and xo["virtual"].size(0) > 0:
-                ok, d = close(xv[: xo["virtual"].size(0)], xo["virtual"], 5e-5, 1e-4)
+                # 1e-5 relative to the magnitude of the features (tests/helpers.py::scale_close; HIP is shown to be as
+                # close to float64 as the float32 oracle in tests/test_gpu_resident.py)
+                ref_v = xo["virtual"]
+                d = float((xv[: ref_v.size(0)].detach().cpu() - ref_v).abs().max())
+                ok = d <= 1e-5 * max(1.0, float(ref_v.abs().max()))
                 if not ok:
                     msgs.append(f"virtual overlap={overlap} maxdiff {d:.2e}")
             for (n_, po), (_, pd) in zip(om.named_parameters(), pm.named_parameters()):
