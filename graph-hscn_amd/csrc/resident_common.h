@@ -270,12 +270,34 @@ __device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float
 }
 
 
+// consumer side: one lane polls (relaxed, agent scope) until the producer's counter reaches `want`, the wave then
+// acquires once; bounded.  Returns false on timeout.
+__device__ __forceinline__ bool wait_published(const uint32_t* word, uint32_t want, int32_t* flag) {
+  bool ok = true;
+  if ((threadIdx.x & 63) == 0) {
+    unsigned spins = 0;
+    while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { ok = false; break; }   // ~ seconds: the producer is not coming
+    }
+    if (!ok && flag) atomicOr(flag, 8);
+  }
+  ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
+
 // out[p] = sum_g partials[g][p]: a block owns 32 parameters x 8 contiguous graph slices (coalesced
 // over p), each slice summed in graph order, slices folded in slice order -> fixed summation tree
 // (column p_scaled, if any, is multiplied by `scale`: the loss column of a step whose loss tail rode
 // on the backward launch -- sum of the per-graph loss terms times 1/count)
+// epoch (optional): the step counter of the one-launch training step (resident_step.h), advanced here -- after every
+// workgroup of that launch has finished, before the next step's launch starts
 __global__ void __launch_bounds__(256) k_param_reduce(const float* __restrict__ partials, float* __restrict__ out,
-                                                      int B, int P, int p_scaled, float scale) {
+                                                      int B, int P, int p_scaled, float scale,
+                                                      uint32_t* epoch = nullptr) {
+  if (epoch && blockIdx.x == 0 && threadIdx.x == 0) epoch[0] = epoch[0] + 1u;
   __shared__ float red[8][32];
   const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int p = blockIdx.x * 32 + pl;

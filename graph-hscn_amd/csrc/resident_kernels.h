@@ -75,6 +75,10 @@ struct FwdArgs {
   float *vs_dinv_v, *vs_xv;
   int spec;  // 1: ll path and virtual branch run concurrently on two wave groups (needs a 3rd n x H buffer)
   int exp;   // 1: this launch also builds + exports the source-keyed ll CSR (needs LDS for it)
+  // one-launch step (resident_step.h): the local activations this virtual-only workgroup reads are published by the
+  // local workgroup of the same launch; ready[g] counts them (epoch * 8 + count), NULL: they come from an earlier launch
+  const uint32_t* ready;
+  const uint32_t* epoch;
   int db;        // 1: two weight buffers in LDS (the next layer's weights land under this layer's math)
   int exp_dinv;  // 1: this launch exports the ll degree norm (the workgroup that builds ll keyed by target has it)
   float slope;
@@ -1027,6 +1031,9 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         // the rows travel under group B's transforms (inline, not a lambda: they stay in registers)
         constexpr int PF = 8;
         float pf[PF][4];
+        // one-launch step: a_{l+1} comes from the local workgroup of THIS launch -- every loading wave polls the
+        // graph's publish counter, acquires once, then loads (bounded; see resident_step.h)
+        if (more && A.ready) wait_published(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
         const TS* nsrc = acts_g + ((size_t)l * A.N + n0) * H;
         const int ncnt = more ? n * (H / 4) : 0;
 #pragma unroll
@@ -1074,6 +1081,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       lds_barrier();
       STAMP(5 + 4 * l);
       if (vonly || !FUSE) {
+        if (vonly && more && A.ready) wait_published(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
         if (vonly) load_next_local(ALL, xa); else reduce_ll(ALL);
         STAMP_T(43 + 4 * l, 0);
         lds_barrier();
@@ -1790,6 +1798,7 @@ int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, cons
   A.max_n = max_n; A.max_v = max_v; A.max_ell = vonly ? 0 : max_ell; A.max_evv = max_evv;
   A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0; A.exp_dinv = 0; A.db = 0;
   A.l_begin = 0; A.l_end = L;
+  A.ready = nullptr; A.epoch = nullptr;
   A.vs_rowptr_lv = A.vs_col_lv = A.vs_rowptr_vv = A.vs_col_vv = nullptr;
   A.vs_dinv_v = A.vs_xv = nullptr;
   return 0;
@@ -1893,6 +1902,8 @@ int attach_tail(BwdArgs& A, const hscn_loss_tail* tail, int64_t B) {
   return 0;
 }
 
+
+#include "resident_step.h"
 
 // ---- the C entry points, generic in the storage type (resident.hip: float, resident_f16.hip: half) ----
 template <typename TS>
@@ -2039,5 +2050,63 @@ int impl_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
   return HSCN_E_UNSUPPORTED;
 }
 
+
+// one-launch training step (resident_step.h).  sync: [0] = epoch word, [32 .. 32 + B) = per-graph publish counters.
+template <typename TS>
+int impl_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                             const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
+                             const void* const* layer_params_host, const float* W1, const float* b1, const float* W2,
+                             const float* b2, int max_n, int max_ell, const float* target, int loss_kind, float* pred,
+                             float* score, float* partials, float* grads, float* acts, uint32_t* sync, int32_t* flag,
+                             const hscn_virtual_job* job, void* stream_) {
+  if (B < 0 || N < 0) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (!(H == 16 || H == 32) || F < 1 || F > H || L < 1 || L > MAXL || C < 1 || C > 4096 || max_n < 0 || max_ell < 0)
+    return HSCN_E_UNSUPPORTED;
+  if (!x_local || !lptr || !eptr_ll || !layer_params_host || !W1 || !b1 || !W2 || !b2 || !target || !pred ||
+      !partials || !grads || (E_ll > 0 && !ei_ll) || (loss_kind != 0 && loss_kind != 1))
+    return HSCN_E_BADARG;
+  if (job && (!acts || !sync || !job->xv_out)) return HSCN_E_BADARG;
+  StepArgs S;
+  S.x_local = x_local; S.ll_src = ei_ll; S.ll_dst = ei_ll ? ei_ll + E_ll : nullptr; S.lptr = lptr; S.eptr_ll = eptr_ll;
+  for (int l = 0; l < L; ++l) {
+    const void* const* q = layer_params_host + (size_t)l * 9;
+    if (!q[0] || !q[1]) return HSCN_E_BADARG;
+    S.W_ll[l] = (const float*)q[0];
+    S.b_ll[l] = (const float*)q[1];
+  }
+  S.W1 = W1; S.b1 = b1; S.W2 = W2; S.b2 = b2; S.target = target; S.pred = pred; S.score = score;
+  S.partials = partials; S.flag = flag; S.N = N; S.F = F; S.L = L; S.C = C; S.head_act = head_act;
+  S.max_n = max_n; S.max_ell = max_ell; S.Pn = (int)hscn_resident_param_count(F, H, L, C); S.P = S.Pn + 1;
+  S.loss_kind = loss_kind; S.inv_count = 1.0f / (float)(B * (int64_t)C); S.B = (int)B;
+  S.acts = (acts && L >= 2) ? acts : nullptr;
+  S.ready = (job && S.acts) ? sync + 32 : nullptr;
+  S.epoch = sync;
+  FwdArgs V;
+  if (job) {
+    if (int rc1 = fill_fwd_args(V, x_local, job->x_virtual, nullptr, 0, job->ei_vv, job->E_vv, job->ei_lv, job->E_lv,
+                                lptr, job->vptr, eptr_ll, job->eptr_vv, job->eptr_lv, N, job->V, F, H, L, C, head_act,
+                                job->slope, job->layer_params_host, nullptr, nullptr, nullptr, nullptr, max_n,
+                                job->max_v, max_ell, job->max_evv, 2, acts, nullptr, nullptr, nullptr, job->xv_out,
+                                nullptr, nullptr, nullptr, flag))
+      return rc1;
+    V.ready = S.ready; V.epoch = sync;
+  }
+  hipStream_t st = hscn_stream(stream_);
+  int rc = H == 16 ? launch_step<16, TS>(S, job ? &V : nullptr, st) : launch_step<32, TS>(S, job ? &V : nullptr, st);
+  if (rc) return rc;
+  k_param_reduce<<<hscn_blocks(S.P, 32), 256, 0, st>>>(partials, grads, (int)B, S.P, S.Pn, S.inv_count,
+                                                       S.ready ? sync : nullptr);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+inline int step_supported(int F, int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv) {
+  if (!(H == 16 || H == 32) || F < 1 || F > H || L < 1 || L > MAXL || C < 1 || C > 4096) return 0;
+  if (max_n < 0 || max_ell < 0 || max_v < 0 || max_evv < 0) return 0;
+  if (step_lds_bytes(H, L, C, max_n, max_ell) > 160 * 1024) return 0;
+  if (max_v > 0 && fwd_lds_bytes(H, C, max_n, max_v, 0, max_evv, 0, 0) > 160 * 1024) return 0;
+  return 1;
+}
 
 }  // namespace

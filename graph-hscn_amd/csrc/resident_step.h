@@ -1,0 +1,628 @@
+// One-launch training step of stage C (reference train/train.py:73-95: pred = model(...); loss = criterion(...);
+// loss.backward()): workgroup g runs the forward of graph g, its own row of d loss / d pred, and the backward,
+// with the graph's structure AND every layer's activation resident in LDS from the first load to the last
+// gradient partial.  Included by resident_kernels.h (inside its anonymous namespace).
+//
+// What disappears against the two-launch route (k_hscn_fwd_pair + k_hscn_bwd_virtual):
+//   * one launch boundary and one replay gap;
+//   * the backward's prologue (segment tables, exported CSR, degree norm, last activation, head weights, pooled, z:
+//     two dependent HBM round trips) -- everything it loaded is still in LDS;
+//   * the export + re-import of the source-keyed CSR, the degree norm and L x n x H activations (~8 of the ~17 MB
+//     a step moved);
+//   * the per-layer weight re-fetch of the backward: the forward's transposed W_ll stay in LDS and the backward
+//     reads them transposed again.
+// The per-graph loss gradient needs no other graph: d(mean loss)/d pred_g = criterion'(pred_g, y_g) / (B C); the
+// mean loss itself is one more column of the per-graph partials that k_param_reduce sums anyway.
+//
+// LDS: NB = max(L + 1, 3) buffers of n x H floats: A[0] = input features, A[l + 1] = output of layer l.  In the
+// backward the gradient G lives in A[L] (masked in place), GH = A_hat^T G in A[0] (the features are re-read from
+// HBM for layer 0's weight gradient into A[1], dead by then; L = 1 keeps them and uses A[2]).  H = 16: a 444-node
+// graph (Peptides' maximum) fits; H = 32 up to ~290 nodes; beyond that the caller takes the two-launch route.
+//
+// The virtual branch (which cannot reach the prediction: DESIGN.md section 2) runs as B more workgroups of the same
+// launch (blocks B .. 2B-1, hscn_fwd_body MODE 2 over all layers).  Its layer l >= 1 reads the local activation
+// a_l, so the local workgroup publishes a_1 .. a_{L-1}: write-through (sc1) 16-byte stores from LDS at the top of
+// the following layer, every wave drains (s_waitcnt vmcnt(0)) in front of that layer's barrier, then ONE lane stores
+// the per-graph flag (agent-scope atomic) -- no release fence, nothing on the local critical path but the store
+// issue.  The virtual workgroup's loading waves poll the flag relaxed, acquire once (agent scope) and load
+// (cdna_hip_programming.md Guideline 16, R1).  Local workgroups never wait for anyone; the grid puts them first;
+// every spin is bounded (flag bit 8 on timeout -- the virtual features are then invalid, prediction and gradients
+// are not affected).  Flags are compared against a per-step epoch kept in device memory and advanced by
+// k_param_reduce, so no per-step memset is needed and nothing is frozen under hipGraph replay.
+
+struct StepArgs {
+  const float* x_local;  // TS [N][F]
+  const int64_t *ll_src, *ll_dst;
+  const int32_t *lptr, *eptr_ll;
+  const float* W_ll[MAXL];
+  const float* b_ll[MAXL];
+  const float *W1, *b1, *W2, *b2;
+  const float* target;   // [B][C]
+  float *pred, *score;   // [B][C]
+  float* partials;       // [B][P], P = Pn + 1 (last column: the graph's summed loss terms)
+  float* acts;           // TS [L-1][N][H]: a_1 .. a_{L-1} for the virtual workgroups (NULL: not published)
+  uint32_t* ready;       // [B] per-graph publish counters (epoch * 8 + number of published activations)
+  const uint32_t* epoch; // device word, advanced once per step by k_param_reduce
+  int32_t* flag;
+  int64_t N;
+  int F, L, C, head_act, max_n, max_ell, P, Pn, loss_kind;
+  float inv_count;
+  int B;
+};
+
+struct StepLayout {
+  size_t A, dinv, wt, headw, part, vec, red, rowptr, col, rowptr_t, col_t, wsum, total;
+  size_t ek, eo, cursorA, tmpA, cursorT, tmpT;
+  int NB;
+  size_t bufw;  // words per n x H buffer
+};
+__host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n, int max_ell) {
+  StepLayout Y;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+  auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+  Y.NB = L + 1 > 3 ? L + 1 : 3;
+  // staged COO slices live in A[1], the CSR builds' counters / slot lists in A[2] (both dead until layers 0 / 1 write
+  // them); a buffer is widened if a dense graph needs more than n x H words for either
+  size_t bufw = up4((size_t)max_n * H);
+  const size_t stage = 2 * up4(max_ell);
+  const size_t scratch = 2 * up4((size_t)max_n + 1) + 2 * up4(max_ell);
+  if (stage > bufw) bufw = stage;
+  if (scratch > bufw) bufw = scratch;
+  Y.bufw = bufw;
+  Y.A = take(bufw * Y.NB);
+  Y.ek = Y.A + bufw;
+  Y.eo = Y.ek + up4(max_ell);
+  Y.cursorA = Y.A + 2 * bufw;
+  Y.tmpA = Y.cursorA + up4((size_t)max_n + 1);
+  Y.cursorT = Y.tmpA + up4(max_ell);
+  Y.tmpT = Y.cursorT + up4((size_t)max_n + 1);
+  Y.dinv = take(max_n);
+  Y.wt = take((size_t)L * (H * H + H));                            // per layer: Wt[k][o] (rows k >= fin zero) | b[H]
+  Y.headw = take((size_t)H * H + H + (size_t)C * H + 4 * (size_t)C);  // W1 | b1 | W2 | b2 | target row | g_pred row | loss terms
+  Y.part = take((size_t)(RT_MAX / 64) * H);                        // pool partials, later bias-gradient partials
+  Y.vec = take(320);
+  Y.red = take((size_t)(RT_MAX / 64) * 256);
+  Y.rowptr = take((size_t)max_n + 1);
+  Y.col = take(max_ell);
+  Y.rowptr_t = take((size_t)max_n + 1);
+  Y.col_t = take(max_ell);
+  Y.wsum = take(32);
+  Y.total = o;
+  return Y;
+}
+
+// 16-byte (float) / 8-byte (half) write-through stores of n x H activations from LDS to the hand-off buffer
+template <typename TS, int H, int RT>
+__device__ __forceinline__ void publish_rows(const float* A, TS* dst, int n) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const int cnt = n * (H / 4);
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(dst, 0, cnt * 4 * (int)sizeof(TS), 0x00020000);
+  for (int i = threadIdx.x; i < cnt; i += RT) {
+    const float4 v = reinterpret_cast<const float4*>(A)[i];
+    if constexpr (sizeof(TS) == 4) {
+      u32x4 w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(w, rs, i * 16, 0, 16 /* sc1 */);
+    } else {
+      half4_t h;
+      h.x = (half_t)v.x; h.y = (half_t)v.y; h.z = (half_t)v.z; h.w = (half_t)v.w;   // exact: the values are half already
+      u32x2 w;
+      __builtin_memcpy(&w, &h, 8);
+      __builtin_amdgcn_raw_buffer_store_b64(w, rs, i * 8, 0, 16 /* sc1 */);
+    }
+  }
+}
+
+// Y[n][H] = mask(M) .* (X[n][H] * W), W given TRANSPOSED in LDS (Wt[k][o] = W[o][k], the forward's layout):
+// the backward's input gradient on the matrix cores without a second copy of the weights.
+template <int H>
+__device__ void lin_mfma_wt_masked(const float* X, const float* Wt, float* Y, int n, const float* M, const Grp& G) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int TD = H / 16, KS = H / 4;
+  const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int ntile = (n + 15) >> 4;
+  if (G.w >= ntile) return;
+  float b[TD][KS];
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[ct][s] = Wt[(ct * 16 + li) * H + 4 * s + lj];   // = W[4s+lj][ct*16+li]
+  for (int rt = G.w; rt < ntile; rt += G.nw) {
+    const int r0 = rt * 16;
+    const bool ok = r0 + li < n;
+    const float* xr = X + (r0 + li) * H + lj;
+    f32x4 acc[TD];
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float a = ok ? xr[4 * s] : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < TD; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[ct][s], acc[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + lj * 4 + r;
+        if (row < n) {
+          const int idx = row * H + ct * 16 + li;
+          Y[idx] = M[idx] > 0.f ? acc[ct][r] : 0.f;
+        }
+      }
+  }
+}
+
+template <int H, int RT, typename TS>
+__device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) {
+  static_assert(H <= 32, "the one-launch step uses the fused local layer (H <= 32)");
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NW = RT / 64;
+  const TS* const xl_g = reinterpret_cast<const TS*>(A.x_local);
+  TS* const acts_g = reinterpret_cast<TS*>(A.acts);
+  const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
+  const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
+  float* part = A.partials + (size_t)g * A.P;
+  const int F = A.F, L = A.L, C = A.C;
+  const uint32_t ep8 = A.ready ? A.epoch[0] * 8u : 0u;
+  if ((n > A.max_n) | (ne > A.max_ell) | (n < 0) | (ne < 0)) {
+    if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    for (int i = threadIdx.x; i < A.P; i += RT) part[i] = 0.f;
+    // the virtual workgroup of this graph must not wait for activations that will never come
+    if (threadIdx.x == 0 && A.ready) __hip_atomic_store(A.ready + g, ep8 + 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const StepLayout Y = step_layout(H, L, C, A.max_n, A.max_ell);
+  float* fb = reinterpret_cast<float*>(smem);
+  int* ib = reinterpret_cast<int*>(smem);
+  float* Abuf = fb + Y.A;
+  auto buf = [&](int k) { return Abuf + (size_t)k * Y.bufw; };
+  float *dinv = fb + Y.dinv, *wt = fb + Y.wt, *headw = fb + Y.headw, *partp = fb + Y.part, *vec = fb + Y.vec;
+  float* red = fb + Y.red;
+  int *rowptr = ib + Y.rowptr, *col = ib + Y.col, *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Grp ALL{(int)threadIdx.x, RT, wave, NW};
+  constexpr int WL = H * H + H;   // words per layer in wt
+
+  // ---- prologue: every global input of the graph is requested before anything is consumed ----------------
+  STAMP(0);
+  constexpr int EPT = 2, XPT = 8;
+  constexpr int WPT = (MAXL * WL + RT - 1) / RT > 4 ? 4 : (MAXL * WL + RT - 1) / RT;   // weight words per thread in registers
+  const int64_t* dummy = reinterpret_cast<const int64_t*>(A.lptr);
+  const int64_t *pld = A.ll_dst ? A.ll_dst : dummy, *pls = A.ll_src ? A.ll_src : dummy;
+  long long rld[EPT], rls[EPT];
+  float xr[XPT];
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = threadIdx.x + i * RT;
+    const bool o1 = e < ne && A.ll_dst;
+    rld[i] = 0; rls[i] = 0;
+    if (wbase + i * RT < ne) { rld[i] = pld[o1 ? e0 + e : 0]; rls[i] = pls[o1 ? e0 + e : 0]; }
+  }
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * RT;
+    const int r = idx / H, k = idx - r * H;
+    const bool ok = idx < n * H && k < F;
+    xr[i] = 0.f;
+    if (wbase + i * RT < n * H) {
+      const float t = ldf(xl_g, ok ? (size_t)(n0 + r) * F + k : 0);
+      xr[i] = ok ? t : 0.f;
+    }
+  }
+  // all layers' local->local weights, transposed on the way in: slot d = l*WL + k*H + o  <-  W_l[o][k]; bias behind
+  float wr[WPT];
+  const int WTOT = L * WL;
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int d = threadIdx.x + i * RT;
+    const int l = d / WL, q = d - l * WL;
+    const int fin = l == 0 ? F : H;
+    wr[i] = 0.f;
+    if (wbase + i * RT < WTOT) {
+      const bool inb = d < WTOT;
+      const int ll = inb ? l : 0;
+      const bool isb = q >= H * H;
+      const int k = q / H, o = q - k * H;
+      const bool ok = inb && (isb || k < fin);
+      const float* src = isb ? A.b_ll[ll] + (q - H * H) : A.W_ll[ll] + (ok ? o * fin + k : 0);
+      const float t = *(ok ? src : A.b_ll[0]);
+      wr[i] = ok ? t : 0.f;
+    }
+  }
+  // head weights W1 [H][H] | b1 [H] | W2 [C][H] | b2 [C] (natural layout), then this graph's target row
+  const int HT = H * H + H + C * H + C;
+  auto haddr = [&](int idx) -> const float* {
+    if (idx < H * H) return A.W1 + idx;
+    idx -= H * H;
+    if (idx < H) return A.b1 + idx;
+    idx -= H;
+    if (idx < C * H) return A.W2 + idx;
+    idx -= C * H;
+    if (idx < C) return A.b2 + idx;
+    idx -= C;
+    return A.target + (size_t)g * C + (idx < C ? idx : 0);
+  };
+  const int HTT = HT + C;
+  float hw0 = *haddr((int)threadIdx.x < HTT ? (int)threadIdx.x : 0);
+  float hw1 = *haddr((int)threadIdx.x + RT < HTT ? (int)threadIdx.x + RT : 0);
+  // ---- consume: validate + stage the edges, park features and weights -------------------------------------
+  {
+    int *ek = ib + Y.ek, *eo = ib + Y.eo;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * RT;
+      if (e < ne) {
+        int k = (int)(rld[i] - n0), o_ = (int)(rls[i] - n0);
+        if (k < 0 || k >= n || o_ < 0 || o_ >= n) { bad = true; k = -1; o_ = -1; }
+        ek[e] = k; eo[e] = o_;
+      }
+    }
+    for (int e = threadIdx.x + EPT * RT; e < ne; e += RT) {
+      int k = (int)(A.ll_dst[e0 + e] - n0), o_ = (int)(A.ll_src[e0 + e] - n0);
+      if (k < 0 || k >= n || o_ < 0 || o_ >= n) { bad = true; k = -1; o_ = -1; }
+      ek[e] = k; eo[e] = o_;
+    }
+    if (bad && A.flag) atomicOr(A.flag, 2);
+  }
+  for (int i = threadIdx.x; i <= n; i += RT) { (ib + Y.cursorA)[i] = 0; (ib + Y.cursorT)[i] = 0; }
+  {
+    float* x0 = buf(0);
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int idx = threadIdx.x + i * RT;
+      if (idx < n * H) x0[idx] = xr[i];
+    }
+    for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) {
+      const int r = idx / H, k = idx - r * H;
+      x0[idx] = k < F ? ldf(xl_g, (size_t)(n0 + r) * F + k) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int d = threadIdx.x + i * RT;
+      if (d < WTOT) wt[d] = wr[i];
+    }
+    for (int d = threadIdx.x + WPT * RT; d < WTOT; d += RT) {
+      const int l = d / WL, q = d - l * WL;
+      const int fin = l == 0 ? F : H;
+      const int k = q / H, o = q - k * H;
+      wt[d] = q >= H * H ? A.b_ll[l][q - H * H] : (k < fin ? A.W_ll[l][o * fin + k] : 0.f);
+    }
+    if ((int)threadIdx.x < HTT) headw[threadIdx.x] = hw0;
+    if ((int)threadIdx.x + RT < HTT) headw[threadIdx.x + RT] = hw1;
+    for (int idx = threadIdx.x + 2 * RT; idx < HTT; idx += RT) headw[idx] = *haddr(idx);
+  }
+  lds_barrier();
+  STAMP(1);
+  // ---- structure: the two CSRs of the local->local relation side by side (four barriers each) -------------
+  {
+    const int NA = NW / 2 > 0 ? NW / 2 : 1;
+    const bool inB = wave >= NA && NW > 1;
+    if (NW == 1) {
+      build_csr_lds(ib + Y.ek, ib + Y.eo, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, ALL, false);
+      build_csr_lds(ib + Y.eo, ib + Y.ek, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, ALL, false);
+      dinv_from_rowptr(rowptr, n, dinv, ALL);
+    } else if (!inB) {
+      const Grp GA{(int)threadIdx.x, NA * 64, wave, NA};
+      build_csr_lds(ib + Y.ek, ib + Y.eo, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, GA, false);
+      dinv_from_rowptr(rowptr, n, dinv, GA);
+    } else {
+      const Grp GB{(int)threadIdx.x - NA * 64, (NW - NA) * 64, wave - NA, NW - NA};
+      build_csr_lds(ib + Y.eo, ib + Y.ek, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, GB, false);
+    }
+  }
+  lds_barrier();
+  STAMP(3);
+  // ---- forward layers: A[l] -> A[l + 1], one barrier each ----------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    if (acts_g && l >= 1)   // a_l is complete (previous barrier): hand it to the virtual workgroup, write-through
+      publish_rows<TS, H, RT>(buf(l), acts_g + ((size_t)(l - 1) * A.N + n0) * H, n);
+    STAMP(4 + 4 * l);
+    gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, ALL);
+    if (acts_g && l >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (R1)
+    lds_barrier();
+    if (acts_g && A.ready && l >= 1 && threadIdx.x == 0)
+      __hip_atomic_store(A.ready + g, ep8 + (uint32_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  STAMP(62);
+  // ---- global_mean_pool + head + this graph's row of the loss tail --------------------------------------------
+  float* aL = buf(L);
+  {
+    constexpr int LPR = H / 4;
+    constexpr int S = 64 / LPR;
+    const int slot = lane / LPR, f = (lane % LPR) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = wave * S + slot; i < n; i += NW * S) {
+      const float4 v = *reinterpret_cast<const float4*>(aL + i * H + f);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= LPR; off >>= 1) {
+      acc.x += __shfl_xor(acc.x, off, 64);
+      acc.y += __shfl_xor(acc.y, off, 64);
+      acc.z += __shfl_xor(acc.z, off, 64);
+      acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (slot == 0) *reinterpret_cast<float4*>(partp + wave * H + f) = acc;
+  }
+  lds_barrier();
+  float* pol = vec;          // pooled
+  float* zz = vec + 64;      // z = act(lin_1(pooled))
+  float* gz = vec + 128;     // dL/d(lin_1 output, pre-activation)
+  float* gpool = vec + 192;
+  const float* W1l = headw;
+  const float* b1l = headw + H * H;
+  const float* W2l = b1l + H;
+  const float* b2l = W2l + C * H;
+  const float* tgl = b2l + C;
+  float* gpl = headw + HT + C;       // g_pred row
+  float* ltl = gpl + C;              // loss terms
+  if (threadIdx.x < 64) {
+    const float cnt = (float)(n > 0 ? n : 1);
+    if (lane < H) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += partp[w * H + lane];
+      s = s / cnt;
+      pol[lane] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < H) {
+      float a1 = 0.f;
+      const float4* wrow = reinterpret_cast<const float4*>(W1l + lane * H);
+#pragma unroll
+      for (int k4 = 0; k4 < H / 4; ++k4) {
+        const float4 w4 = wrow[k4];
+        const float4 p4 = *reinterpret_cast<const float4*>(pol + 4 * k4);
+        a1 = fmaf(p4.x, w4.x, a1);
+        a1 = fmaf(p4.y, w4.y, a1);
+        a1 = fmaf(p4.z, w4.z, a1);
+        a1 = fmaf(p4.w, w4.w, a1);
+      }
+      a1 += b1l[lane];
+      a1 = apply_act(a1, A.head_act);
+      zz[lane] = a1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int c = lane; c < C; c += 64) {
+      float a2 = 0.f;
+      const float4* wrow = reinterpret_cast<const float4*>(W2l + c * H);
+#pragma unroll
+      for (int k4 = 0; k4 < H / 4; ++k4) {
+        const float4 w4 = wrow[k4];
+        const float4 z4 = *reinterpret_cast<const float4*>(zz + 4 * k4);
+        a2 = fmaf(z4.x, w4.x, a2);
+        a2 = fmaf(z4.y, w4.y, a2);
+        a2 = fmaf(z4.z, w4.z, a2);
+        a2 = fmaf(z4.w, w4.w, a2);
+      }
+      const float pc = a2 + b2l[c];
+      float lt, sg, gg;
+      criterion_elem(A.loss_kind, pc, tgl[c], A.inv_count, lt, sg, gg);   // same element code as k_criterion
+      gpl[c] = gg;
+      ltl[c] = lt;
+      A.pred[(size_t)g * C + c] = pc;
+      if (A.score) A.score[(size_t)g * C + c] = 1.0f / (1.0f + expf(-pc));
+    }
+    // ---- head backward, first half (same wave: no barrier needed up to gz) ----
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < H) {
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) acc = fmaf(gpl[c], W2l[c * H + lane], acc);
+      gz[lane] = acc * act_grad_from_output(zz[lane], A.head_act);
+    }
+  }
+  lds_barrier();
+  STAMP(63);
+
+  // ================================ backward ======================================================
+  // partial layout: per layer {W_ll [H*fin], b_ll [H]}, then W1 [H*H], b1 [H], W2 [C*H], b2 [C], loss column
+  int off_head = 0;
+  for (int l = 0; l < L; ++l) off_head += H * (l == 0 ? F : H) + H;
+  const int oW1 = off_head, ob1 = oW1 + H * H, oW2 = ob1 + H, ob2 = oW2 + C * H;
+  for (int idx = threadIdx.x; idx < C * H; idx += RT) {
+    const int c = idx / H, k = idx - c * H;
+    part[oW2 + idx] = gpl[c] * zz[k];
+  }
+  for (int c = threadIdx.x; c < C; c += RT) part[ob2 + c] = gpl[c];
+  if (threadIdx.x == RT - 64) {   // the graph's loss terms, summed in class order
+    float sl = 0.f;
+    for (int c = 0; c < C; ++c) sl += ltl[c];
+    part[A.Pn] = sl;
+  }
+  for (int idx = threadIdx.x; idx < H * H; idx += RT) {
+    const int o = idx / H, k = idx - o * H;
+    part[oW1 + idx] = gz[o] * pol[k];
+  }
+  if (threadIdx.x < H) {
+    part[ob1 + threadIdx.x] = gz[threadIdx.x];
+    float acc = 0.f;
+#pragma unroll
+    for (int o = 0; o < H; ++o) acc = fmaf(gz[o], W1l[o * H + threadIdx.x], acc);
+    gpool[threadIdx.x] = acc;
+  }
+  lds_barrier();
+  float* G = aL;                  // gradient of the current layer's output, masked in place
+  float* GH = L >= 2 ? buf(0) : buf(2);
+  {
+    const float cnt = (float)(n > 0 ? n : 1);
+    for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = G[idx] > 0.f ? gpool[idx % H] / cnt : 0.f;
+  }
+  float* bred = partp;
+  constexpr int GW_TD = H / 16, GW_NT = GW_TD * GW_TD;
+  constexpr int GW_TPP = GW_NT < NW ? GW_NT : NW, GW_RG = NW / GW_TPP;
+  constexpr bool GW1 = GW_NT <= NW;
+  auto fold_gw = [&](int t0, int oW_, int fin_) {
+    for (int idx = threadIdx.x; idx < GW_TPP * 256; idx += RT) {
+      const int t_ = t0 + idx / 256, e_ = idx & 255;
+      if (t_ < GW_NT) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < GW_RG; ++r) s_ += red[(r * GW_TPP + idx / 256) * 256 + e_];
+        const int oo = (t_ / GW_TD) * 16 + (e_ >> 4), kk = (t_ % GW_TD) * 16 + (e_ & 15);
+        if (kk < fin_) part[oW_ + oo * fin_ + kk] = s_;
+      }
+    }
+  };
+  int pend_oW = -1, pend_fin = 0;
+  int off = off_head;
+  for (int l = L - 1; l >= 0; --l) {
+    const int fin = l == 0 ? F : H;
+    off -= H * fin + H;
+    const int oW = off, ob = off + H * fin;
+    lds_barrier();  // G (masked) complete
+    if (GW1 && pend_oW >= 0) fold_gw(0, pend_oW, pend_fin);
+    // layer input: A[l] is still in LDS for l >= 1 (and for l = 0 when L = 1); with L >= 2 the features were
+    // overwritten by GH: re-read them (requested here, parked in A[1] -- dead by now -- after the gather-reduce)
+    const bool reload = l == 0 && L >= 2;
+    float* X = reload ? buf(1) : buf(l);
+    float xq[XPT];
+    if (reload) {
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int idx = threadIdx.x + i * RT;
+        const int r = idx / H, k = idx - r * H;
+        xq[i] = (idx < n * H && k < fin) ? ldf(xl_g, (size_t)(n0 + r) * fin + k) : 0.f;
+      }
+    }
+    {   // bias gradient = column sums of G
+      constexpr int LQ = H / 4;
+      constexpr int SQ = 64 / LQ;
+      const int slot = lane / LQ, f = (lane % LQ) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = wave * SQ + slot; i < n; i += NW * SQ) {
+        const float4 v = *reinterpret_cast<const float4*>(G + i * H + f);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+#pragma unroll
+      for (int o_ = 32; o_ >= 16 && o_ >= LQ; o_ >>= 1) {
+        acc.x += __shfl_xor(acc.x, o_, 64);
+        acc.y += __shfl_xor(acc.y, o_, 64);
+        acc.z += __shfl_xor(acc.z, o_, 64);
+        acc.w += __shfl_xor(acc.w, o_, 64);
+      }
+      if (LQ <= 8) {
+        acc.x = row_ror_add<8>(acc.x); acc.y = row_ror_add<8>(acc.y);
+        acc.z = row_ror_add<8>(acc.z); acc.w = row_ror_add<8>(acc.w);
+      }
+      if (LQ <= 4) {
+        acc.x = row_ror_add<4>(acc.x); acc.y = row_ror_add<4>(acc.y);
+        acc.z = row_ror_add<4>(acc.z); acc.w = row_ror_add<4>(acc.w);
+      }
+      if (slot == 0) *reinterpret_cast<float4*>(bred + wave * H + f) = acc;
+    }
+    // dL/d(transform output) = A_hat^T G  (source-keyed CSR, edge order)
+    agg_gcn_lds<H, float>(rowptr_t, col_t, dinv, dinv, G, nullptr, GH, n, 0, (float*)nullptr, ALL);
+    if (reload) {
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int idx = threadIdx.x + i * RT;
+        if (idx < n * H) X[idx] = xq[i];
+      }
+      for (int idx = threadIdx.x + XPT * RT; idx < n * H; idx += RT) {
+        const int r = idx / H, k = idx - r * H;
+        X[idx] = k < fin ? ldf(xl_g, (size_t)(n0 + r) * fin + k) : 0.f;
+      }
+    }
+    lds_barrier();
+    STAMP(4 + 4 * l);
+    if (threadIdx.x < H) {   // bias gradient: fold the waves' column sums in wave order
+      float sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sb += bred[w * H + threadIdx.x];
+      part[ob + threadIdx.x] = sb;
+    }
+    {   // weight gradient gW[o][k] = sum_j GH[j][o] X[j][k] on the matrix cores
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      constexpr int TD = GW_TD, NT = GW_NT, TPP = GW_TPP, RG = GW_RG;
+      const int li = lane & 15, lj = lane >> 4;
+      for (int t0 = 0; t0 < NT; t0 += TPP) {
+        const int tl = wave % TPP, rg = wave / TPP;
+        const int tile = t0 + tl;
+        const bool live = tile < NT && rg < RG;
+        const int o0 = live ? (tile / TD) * 16 : 0, k0 = live ? (tile % TD) * 16 : 0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+          for (int j0 = rg * 4; j0 < n; j0 += 4 * RG) {
+            const int j = j0 + lj;
+            const bool ok = j < n;
+            const float av = ok ? GH[j * H + o0 + li] : 0.f;
+            const float bv = ok ? X[j * H + k0 + li] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(rg * TPP + tl) * 256 + (lj * 4 + r) * 16 + li] = acc[r];
+        }
+        if (GW1) {
+          pend_oW = oW;
+          pend_fin = fin;
+        } else {
+          lds_barrier();
+          fold_gw(t0, oW, fin);
+          if (t0 + TPP < NT) lds_barrier();
+        }
+      }
+    }
+    STAMP(5 + 4 * l);
+    // input gradient: G[j][k] = relu'(a_l[j][k]) * sum_o GH[j][o] W_l[o][k]; the forward's transposed W_l is read
+    // transposed again (a_l = X doubles as the mask; the old G is dead: GH holds what is needed of it)
+    if (l > 0) lin_mfma_wt_masked<H>(GH, wt + l * WL, G, n, X, ALL);
+    STAMP(6 + 4 * l);
+  }
+  if (GW1 && pend_oW >= 0) {
+    lds_barrier();
+    fold_gw(0, pend_oW, pend_fin);
+  }
+  STAMP(61);
+}
+
+// grid = B (no virtual branch) or 2B: blocks [0, B) run the local program, blocks [B, 2B) the virtual branch
+template <int H, int RT, typename TS>
+__global__ void __launch_bounds__(RT) k_hscn_step(const StepArgs S, const FwdArgs V) {
+  if ((int)blockIdx.x < S.B) hscn_step_local<H, RT, TS>(S, blockIdx.x);
+  else hscn_fwd_body<H, RT, 2, TS>(V, (int)blockIdx.x - S.B);
+}
+template <int H, int RT, typename TS>
+__global__ void __launch_bounds__(RT) k_hscn_step_local(const StepArgs S) {
+  hscn_step_local<H, RT, TS>(S, blockIdx.x);
+}
+
+inline size_t step_lds_bytes(int H, int L, int C, int max_n, int max_ell) {
+  return step_layout(H, L, C, max_n, max_ell).total * 4;
+}
+
+template <int H, int RT, typename TS>
+int launch_step_rt(const StepArgs& S, const FwdArgs* V, size_t lds, hipStream_t st) {
+  if (V) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_hscn_step<H, RT, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_hscn_step<H, RT, TS><<<(unsigned)(2 * S.B), RT, lds, st>>>(S, *V);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_hscn_step_local<H, RT, TS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    k_hscn_step_local<H, RT, TS><<<(unsigned)S.B, RT, lds, st>>>(S);
+  }
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+template <int H, typename TS>
+int launch_step(StepArgs& S, FwdArgs* V, hipStream_t st) {
+  size_t lds = step_lds_bytes(H, S.L, S.C, S.max_n, S.max_ell);
+  if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  if (V) {
+    V->spec = 1; V->exp = 0; V->exp_dinv = 0;
+    const size_t lv = pick_fwd_lds(*V, H);
+    if (lv > 160 * 1024) return HSCN_E_UNSUPPORTED;
+    if (lv > lds) lds = lv;
+    // the hand-off protocol is measured for one workgroup per CU: ask for more than half of a CU's LDS
+    if (lds < 81 * 1024) lds = 81 * 1024;
+  }
+  if (S.max_n <= 64) return launch_step_rt<H, 256, TS>(S, V, lds, st);
+  return launch_step_rt<H, 1024, TS>(S, V, lds, st);
+}

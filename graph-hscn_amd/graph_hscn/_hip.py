@@ -74,10 +74,13 @@ _SIGNATURES = {
                                                c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_bwd_with_virtual": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                                c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P]),
+    "hscn_resident_train_step_supported": (c_int, [c_int] * 8),
+    "hscn_resident_train_step": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
+                                         P, P, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P]),
 }
 # IEEE-half storage twins (include/hscn.h: hscn_resident_*_f16): same argument lists
 for _n in ("hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual", "hscn_resident_bwd_with_virtual",
-           "hscn_scn_resident_fwd", "hscn_scn_resident_bwd"):
+           "hscn_scn_resident_fwd", "hscn_scn_resident_bwd", "hscn_resident_train_step"):
     _SIGNATURES[_n + "_f16"] = _SIGNATURES[_n]
 
 

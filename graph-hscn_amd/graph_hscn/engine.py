@@ -48,6 +48,10 @@ class ResidentMeta:
             raise IndexError("an edge connects nodes of different graphs: the batch is not block-diagonal")
         if f & 4:
             raise ValueError("a graph exceeds the sizes the resident launch was configured for")
+        if f & 8:
+            raise RuntimeError("a virtual-branch workgroup of the one-launch step gave up waiting for its graph's local "
+                               "activations (the virtual features of that step are invalid; prediction, loss and "
+                               "gradients are not affected)")
 
 
 def meta_from_batch(batch, device) -> Optional[ResidentMeta]:

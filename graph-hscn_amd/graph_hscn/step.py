@@ -52,7 +52,11 @@ class ResidentTrainStep:
     The batch may be a ``replay.StaticHeteroBatch.batch``: tensor shapes are capacities then, the
     kernels read the real per-graph ranges from the device-side segment tables."""
 
-    def __init__(self, model, batch, loss_fn: str, target: Optional[Tensor] = None):
+    def __init__(self, model, batch, loss_fn: str, target: Optional[Tensor] = None, one_launch: Optional[bool] = None):
+        """``one_launch``: None = take the one-launch step (include/hscn.h: hscn_resident_train_step -- forward, loss
+        tail and backward of a graph in one workgroup, nothing exported in between) whenever the graphs fit it,
+        else the forward + backward launch pair; False = always the pair; True = insist (raises if unsupported).
+        Both routes give bit-identical outputs (tests/test_gpu_step.py)."""
         from .model.hscn import HSCN, _act_name
         if not isinstance(model, HSCN):
             raise TypeError("ResidentTrainStep drives graph_hscn.model.hscn.HSCN")
@@ -105,12 +109,28 @@ class ResidentTrainStep:
         self.csr = (torch.empty(N + B, **i32), torch.empty(max(E_ll, 1), **i32), torch.empty(max(N, 1), **f32))
         self.virtual = torch.empty(max(V, 1), H, dtype=sdt, device=dev) if model.compute_virtual else None
         # the virtual branch rides on the two launches as extra workgroups while they land on idle CUs
-        self.defer = bool(model.compute_virtual and model.overlap_virtual and V > 0 and L >= 2
-                          and 2 * B <= _engine._cu_count(dev))
+        self.idle_cus = bool(model.compute_virtual and model.overlap_virtual and V > 0
+                             and 2 * B <= _engine._cu_count(dev))
+        self.defer = self.idle_cus and L >= 2      # (the launch PAIR splits the branch only when it has a layer 1)
         self._state = None
         if self.defer:
             self._state = (torch.empty(V + B, **i32), torch.empty(max(E_lv, 1), **i32), torch.empty(V + B, **i32),
                            torch.empty(max(E_vv, 1), **i32), torch.empty(V, **f32), torch.empty(V, H, dtype=sdt, device=dev))
+        # one-launch step: the virtual branch rides as B more workgroups of the same launch when they land on idle
+        # CUs (same condition as `defer`); a batch that fills the chip by itself keeps the launch pair (its virtual
+        # branch shares the local workgroups there)
+        import os
+        can = bool(_hip.lib().hscn_resident_train_step_supported(F, H, L, C, meta.max_n, meta.max_ell,
+                                                                 meta.max_v if model.compute_virtual else 0,
+                                                                 meta.max_evv if model.compute_virtual else 0))
+        can = can and (self.idle_cus or not model.compute_virtual or V == 0)
+        if one_launch is None:
+            one_launch = can and os.environ.get("HSCN_ONE_LAUNCH", "1") != "0"
+        elif one_launch and not can:
+            raise RuntimeError("the one-launch step does not take this batch / model (H in {16, 32}, graphs that fit "
+                               "its LDS layout, virtual branch on idle CUs only)")
+        self.one_launch = bool(one_launch)
+        self._sync = torch.zeros(32 + B, dtype=torch.int32, device=dev) if self.one_launch else None
         P = int(_hip.lib().hscn_resident_param_count(F, H, L, C))
         self.P = P
         self.partials = torch.empty(B, P + 1, **f32)
@@ -144,7 +164,7 @@ class ResidentTrainStep:
         return _engine._VirtualJob(ptr(self.x_virtual), ptr(self.ei[VV]), self.ei[VV].size(1), ptr(self.ei[LV]),
                                    self.ei[LV].size(1), ptr(m.vptr), ptr(m.eptr_vv), ptr(m.eptr_lv),
                                    ctypes.cast(self._table, ctypes.c_void_p), ptr(xv_out), V, m.max_v, m.max_evv,
-                                   self.slope, *[ptr(t) for t in self._state])
+                                   self.slope, *([ptr(t) for t in self._state] if self._state is not None else [None] * 6))
 
     def run(self) -> Tensor:
         """Issue the step on the current stream; returns ``loss`` (valid once the stream has run)."""
@@ -159,7 +179,15 @@ class ResidentTrainStep:
                     self.head_act, self._wll_table, ptr(W1), ptr(W2), ptr(self.acts), ptr(self.pooled), ptr(self.z),
                     None, None, ptr(csr_rp), ptr(csr_col), ptr(dinv), m.max_n, m.max_ell, ptr(self.partials),
                     ptr(self.grads), ptr(m.flag), ctypes.byref(self._tail))
-        if self.defer:
+        if self.one_launch:
+            with_v = self.idle_cus and self.virtual is not None
+            call("hscn_resident_train_step" + self._sfx, ptr(self.x_local), ptr(ei_ll), E_ll, ptr(m.lptr),
+                 ptr(m.eptr_ll), N, B, F, H, L, C, self.head_act, self._table, ptr(W1), ptr(b1), ptr(W2), ptr(b2),
+                 m.max_n, m.max_ell, ptr(self.target), int(self.kind), ptr(self.pred), ptr(self.score),
+                 ptr(self.partials), ptr(self.grads), ptr(self.acts) if with_v else None,
+                 ptr(self._sync) if with_v else None, ptr(m.flag),
+                 ctypes.byref(self._job(self.virtual)) if with_v else None, st)
+        elif self.defer:
             call("hscn_resident_fwd_with_virtual" + self._sfx, ptr(self.x_local), ptr(ei_ll), E_ll, ptr(m.lptr), ptr(m.eptr_ll),
                  N, B, F, H, L, C, self.head_act, self._table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), m.max_n,
                  m.max_ell, ptr(self.acts), ptr(self.pooled), ptr(self.z), ptr(self.pred), ptr(self.score),

@@ -428,6 +428,33 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const hscn_loss_tail* tail /*or NULL*/, const hscn_virtual_job* job, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * a10 + f3  the whole training iteration of stage C in ONE launch (+ the ordered parameter reduction):
+ * reference train/train.py:73-95 -- pred = model(x_dict, edge_index_dict, batch) (model/hscn.py:102-114);
+ * loss, score = criterion(loss_fn, pred, true) (loss.py:6-19); loss.backward().  Workgroup g runs forward, its row
+ * of d(mean loss)/d pred and backward of graph g with structure and every activation resident in LDS; nothing is
+ * exported between "forward" and "backward" (csrc/resident_step.h).  Results are bit-identical to
+ * hscn_resident_fwd_with_virtual + hscn_resident_bwd_with_virtual(tail).
+ *   target [B,C], loss_kind 0 = BCE-with-logits / 1 = L1 (mean over B*C); pred, score [B,C] outputs;
+ *   partials [B,P+1], grads [P+1], P = hscn_resident_param_count: grads[0..P) = parameter gradients in the order
+ *   {W_ll, b_ll} per layer, W1, b1, W2, b2; grads[P] = the mean loss.
+ *   job (or NULL = no virtual branch): the virtual branch runs as B more workgroups of the same launch; it needs
+ *   job->xv_out (final virtual features [V,H]), acts [max(L-1,1),N,H] (the local activations handed over inside
+ *   the launch) and sync: 32 + B uint32 words, ZERO when first used and never touched by the caller afterwards
+ *   ([0] = step epoch, advanced by the reduction; [32+g] = graph g's publish counter).  The job's st_* are unused.
+ *   H in {16, 32}; hscn_resident_train_step_supported says whether the graphs fit (H = 16: n <= ~450).
+ *   flag bit 8: a virtual workgroup gave up waiting for its local activations (virtual features invalid;
+ *   prediction, loss and gradients unaffected).
+ * ------------------------------------------------------------------------- */
+int hscn_resident_train_step_supported(int F, int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv);
+int hscn_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                             const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
+                             const void* const* layer_params_host /* L x 9 */, const float* W1, const float* b1,
+                             const float* W2, const float* b2, int max_n, int max_ell, const float* target,
+                             int loss_kind, float* pred, float* score /*or NULL*/, float* partials /*[B,P+1]*/,
+                             float* grads /*[P+1]*/, float* acts /*or NULL*/, uint32_t* sync /*or NULL*/,
+                             int32_t* flag, const hscn_virtual_job* job /*or NULL*/, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * BASELINE.json configs[4] ("fp16 feat + bf16 accum", PCQM-Contact): the four launches above with IEEE-half
  * STORAGE of node features and inter-layer activations.  The reference has no reduced-precision mode (no
  * autocast / half anywhere); these entry points replace the same call sites as their float
@@ -510,6 +537,14 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
                           const int32_t* ex_rowptr_d, const int32_t* ex_col_d, const int32_t* ex_rowptr_s,
                           const int32_t* ex_col_s, const float* ex_agg, const float* ex_dout, int max_n, int max_e,
                           float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+
+int hscn_resident_train_step_f16(const hscn_half* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
+                                 const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,
+                                 int head_act, const void* const* layer_params_host, const float* W1, const float* b1,
+                                 const float* W2, const float* b2, int max_n, int max_ell, const float* target,
+                                 int loss_kind, float* pred, float* score, float* partials, float* grads,
+                                 hscn_half* acts, uint32_t* sync, int32_t* flag, const hscn_virtual_job* job,
+                                 void* stream);
 
 /* IEEE-half storage twins of the two stage-A launches (BASELINE.json configs[4]): x [N,F] and the saved hidden
  * activation y [N,H] are half (y rounded once, where it is produced); S, stats, ss, losses, the exported

@@ -42,9 +42,15 @@ def _eager(model, d, loss_fn):
     return pred, loss, score, grads
 
 
+@pytest.mark.parametrize("one_launch", [False, True])
 @pytest.mark.parametrize("overlap,compute_virtual,loss_fn", [(True, True, "cross_entropy"), (False, True, "l1"),
                                                              (True, False, "cross_entropy")])
-def test_direct_step_is_the_autograd_step_bit_for_bit(overlap, compute_virtual, loss_fn):
+def test_direct_step_is_the_autograd_step_bit_for_bit(overlap, compute_virtual, loss_fn, one_launch):
+    """Both issue forms of the direct step -- the forward + backward launch pair and the ONE-launch step
+    (csrc/resident_step.h: forward, loss tail and backward of a graph in one workgroup, activations never leave
+    LDS, the virtual branch on its own workgroups fed through an in-launch hand-off) -- against the autograd path."""
+    if one_launch and compute_virtual and not overlap:
+        pytest.skip("the one-launch step carries the virtual branch only as extra workgroups (overlap)")
     import graph_hscn.engine as eng
     from graph_hscn.step import ResidentTrainStep
     dev = torch.device("cuda:0")
@@ -54,8 +60,8 @@ def test_direct_step_is_the_autograd_step_bit_for_bit(overlap, compute_virtual, 
     model.overlap_virtual, model.compute_virtual = overlap, compute_virtual
     pred, loss, score, grads = _eager(model, d, loss_fn)
     want_v = eng.last_deferred_virtual.clone() if (overlap and compute_virtual) else None
-    rs = ResidentTrainStep(model, d, loss_fn)
-    assert rs.defer == (overlap and compute_virtual)
+    rs = ResidentTrainStep(model, d, loss_fn, one_launch=one_launch)
+    assert rs.defer == (overlap and compute_virtual) and rs.one_launch == one_launch
     rs.bind_grads()
     rs.run()
     rs.run()                      # idempotent: buffers are rewritten, not accumulated into
@@ -175,3 +181,57 @@ def test_scn_direct_step_is_the_autograd_step_bit_for_bit():
     for p, w in zip(scn.parameters(), want):
         assert torch.equal(p.grad, w)
     del keep
+
+
+@pytest.mark.parametrize("name,B,K,H,L,C,dtype", [("peptides_func", 128, 16, 16, 3, 10, torch.float32),
+                                                  ("peptides_func", 100, 16, 16, 3, 10, torch.float16),
+                                                  ("peptides_struct", 32, 32, 16, 2, 11, torch.float32),
+                                                  ("pcqm_contact", 120, 16, 32, 3, 1, torch.float32),
+                                                  ("peptides_func", 24, 4, 16, 1, 10, torch.float32)])
+def test_one_launch_step_hand_off_under_uneven_load(name, B, K, H, L, C, dtype):
+    """The in-launch hand-off of the local activations to the virtual workgroups (sc1 stores -> drain -> flag;
+    poll -> acquire -> loads), exercised the way such protocols fail: graphs of very different sizes (8 .. 444
+    nodes: producers finish at very different times), every CU busy (2B workgroups on 256 CUs), consumer caches
+    warm (the same buffers are re-read replay after replay), and EVERY word of the result compared -- the final
+    virtual features must equal the launch pair's bit for bit on each of 40 replays, as must prediction, loss and
+    gradients; no workgroup may have timed out."""
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.data import HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import HSCN
+    from graph_hscn.step import ResidentTrainStep
+    dev = torch.device("cuda:0")
+    graphs = make_dataset(name, B, seed=B)
+    rng = np.random.default_rng(B)
+    hs = [hetero_from_clusters(g, rng.integers(0, K, g.num_nodes), K) for g in graphs]
+    for h in hs:
+        h["local"].y = torch.from_numpy((rng.random((1, C)) < 0.4).astype(np.float32))
+    d = HeteroBatch.from_data_list(hs).to(dev).with_feature_dtype(dtype)
+    torch.manual_seed(1)
+    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], d["local"].x.size(1), H, C, L).to(dev)
+    pair = ResidentTrainStep(model, d, "cross_entropy", one_launch=False)
+    pair.run()
+    one = ResidentTrainStep(model, d, "cross_entropy", one_launch=True)
+    assert one.idle_cus and one.one_launch
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        one.run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one.run()
+    for it in range(40):
+        one.virtual.fill_(-1.0)
+        one.grads.zero_()
+        if it % 2:
+            g.replay()
+        else:
+            one.run()
+        torch.cuda.synchronize()
+        assert torch.equal(one.virtual, pair.virtual), it
+        assert torch.equal(one.pred, pair.pred) and torch.equal(one.score, pair.score), it
+        assert torch.equal(one.grads, pair.grads), it
+    one.check()
