@@ -30,6 +30,36 @@ __device__ __forceinline__ void stf4(half_t* p, size_t i4, float4 v) {
   h.x = (half_t)v.x; h.y = (half_t)v.y; h.z = (half_t)v.z; h.w = (half_t)v.w;
   reinterpret_cast<half4_t*>(p)[i4] = h;
 }
+// write-through (sc1) forms for bytes that another workgroup of the SAME launch reads (resident_step.h): every store
+// of such bytes is one of these, every load of them one of the sc1 buffer loads below (cdna_hip_programming.md
+// Guideline 16: with both, the consumer needs no agent-scope acquire)
+__device__ __forceinline__ void stf_sc1(float* p, size_t i, float v) {
+  __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stf_sc1(half_t* p, size_t i, float v) {
+  const half_t h = (half_t)v;
+  unsigned short b;
+  __builtin_memcpy(&b, &h, 2);
+  __hip_atomic_store(reinterpret_cast<unsigned short*>(p) + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename TS>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const TS* p, int elems) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(p), 0, elems * (int)sizeof(TS), 0x00020000);
+}
+template <typename TS>
+__device__ __forceinline__ float4 ldf4_sc1(__amdgpu_buffer_rsrc_t rs, int i4) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (sizeof(TS) == 4) {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, i4 * 16, 0, 16 /* sc1 */);
+    return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+  } else {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, i4 * 8, 0, 16 /* sc1 */);
+    half4_t h;
+    __builtin_memcpy(&h, &w, 8);
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
+}
 // the value an activation has after it was stored as TS (round to nearest even; float: unchanged)
 template <typename TS> __device__ __forceinline__ float rnd(float v);
 template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
@@ -270,8 +300,12 @@ __device__ __forceinline__ void dinv_from_rowptr(const int* rowptr, int n, float
 }
 
 
-// consumer side: one lane polls (relaxed, agent scope) until the producer's counter reaches `want`, the wave then
-// acquires once; bounded.  Returns false on timeout.
+// consumer side: one lane polls (relaxed, agent scope: an sc1 load) until the producer's counter reaches `want`;
+// bounded.  The wave's loads of the published bytes follow the poll in program order and are sc1 buffer loads to
+// registers (ldf4_sc1), which bypass this CU's L1: no agent-scope acquire (its buffer_inv + wait cost ~1.7 us per
+// hand-off on the virtual branch's chain); ACQ = true issues one anyway, for consumers that use plain loads.
+// Returns false on timeout.
+template <bool ACQ>
 __device__ __forceinline__ bool wait_published(const uint32_t* word, uint32_t want, int32_t* flag) {
   bool ok = true;
   if ((threadIdx.x & 63) == 0) {
@@ -283,7 +317,8 @@ __device__ __forceinline__ bool wait_published(const uint32_t* word, uint32_t wa
     if (!ok && flag) atomicOr(flag, 8);
   }
   ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
   return ok;
 }
 

@@ -373,6 +373,97 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
   }
 }
 
+// The same layer for the one-launch step (resident_step.h), whose output rows are handed to ANOTHER workgroup of
+// the same launch: the rows go out as write-through (sc1) stores, and they are issued at the END of the phase, from
+// registers, behind one s_waitcnt vmcnt(0) -- at that point the only stores this wave can still have in flight are
+// the previous layer's, a whole layer old, so the wait is free and exact, and after the phase barrier that follows
+// one lane may raise the previous layer's publish counter.  A wave keeps up to two tiles' outputs in registers
+// (n <= 512 at 16 waves); further tiles store at once and are simply covered by the wait.
+template <int H, typename TS>
+__device__ void gcn_fused_pub(const int* rowptr, const int* col, const float* dinv, const float* X, const float* Wt,
+                              const float* bias, float* Y, TS* __restrict__ gout, int n, const Grp& G, bool drain) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int TD = H / 16, KS = H / 4;
+  const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int ntile = (n + 15) >> 4;
+  float b[TD][KS], bia[TD];
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct) {
+    bia[ct] = bias[ct * 16 + li];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[ct][s] = Wt[(KS * lj + s) * H + ct * 16 + li];
+  }
+  auto tile = [&](int rt, float (&out)[TD][4]) {
+    const int r0 = rt * 16, i = r0 + li;
+    float z[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) z[s] = 0.f;
+    if (i < n) {
+      const int s0 = rowptr[i], t0 = rowptr[i + 1];
+      const float di = dinv[i];
+      const float* xq = X + KS * lj;
+      for (int p = s0; p < t0; p += 4) {
+        int j[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = col[p + u < t0 ? p + u : t0 - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = p + u < t0 ? dinv[j[u]] * di : 0.f;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xq + j[u] * H + 4 * q);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            z[4 * q + 0] = fmaf(w[u], v[u].x, z[4 * q + 0]);
+            z[4 * q + 1] = fmaf(w[u], v[u].y, z[4 * q + 1]);
+            z[4 * q + 2] = fmaf(w[u], v[u].z, z[4 * q + 2]);
+            z[4 * q + 3] = fmaf(w[u], v[u].w, z[4 * q + 3]);
+          }
+        }
+      }
+    }
+    f32x4 acc[TD];
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int ct = 0; ct < TD; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[s], b[ct][s], acc[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + lj * 4 + r;
+        const float v = rnd<TS>(fmaxf(acc[ct][r] + bia[ct], 0.f));
+        out[ct][r] = v;
+        if (row < n) Y[row * H + ct * 16 + li] = v;
+      }
+  };
+  auto store = [&](int rt, const float (&out)[TD][4]) {
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + lj * 4 + r;
+        if (row < n) stf_sc1(gout, (size_t)row * H + ct * 16 + li, out[ct][r]);
+      }
+  };
+  float o0[TD][4], o1[TD][4];
+  const int t0 = G.w, t1 = G.w + G.nw;
+  if (t0 < ntile) tile(t0, o0);
+  if (t1 < ntile) tile(t1, o1);
+  for (int rt = G.w + 2 * G.nw; rt < ntile; rt += G.nw) {
+    float ox[TD][4];
+    tile(rt, ox);
+    store(rt, ox);
+  }
+  if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (t0 < ntile) store(t0, o0);
+  if (t1 < ntile) store(t1, o1);
+}
+
 template <int H>
 struct Blk {  // outputs per lane in lin_blk: W columns (OPT*H floats) must stay in registers at 16 waves/CU
   static constexpr int OPT = H <= 16 ? 2 : 1;
@@ -1032,15 +1123,26 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         constexpr int PF = 8;
         float pf[PF][4];
         // one-launch step: a_{l+1} comes from the local workgroup of THIS launch -- every loading wave polls the
-        // graph's publish counter, acquires once, then loads (bounded; see resident_step.h)
-        if (more && A.ready) wait_published(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
+        // graph's publish counter itself, then loads with sc1 buffer loads (bounded; see resident_step.h)
+        const bool hand = more && A.ready != nullptr;
         const TS* nsrc = acts_g + ((size_t)l * A.N + n0) * H;
         const int ncnt = more ? n * (H / 4) : 0;
+        const __amdgpu_buffer_rsrc_t nrs = rsrc_of<TS>(nsrc, ncnt * 4);
+        if (hand) {
+          wait_published<false>(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          const int i = GA.t + u * GA.nt;
-          const float4 q = ldf4(nsrc, i < ncnt ? i : 0);
-          pf[u][0] = q.x; pf[u][1] = q.y; pf[u][2] = q.z; pf[u][3] = q.w;
+          for (int u = 0; u < PF; ++u) {
+            const int i = GA.t + u * GA.nt;
+            const float4 q = ldf4_sc1<TS>(nrs, i < ncnt ? i : 0);
+            pf[u][0] = q.x; pf[u][1] = q.y; pf[u][2] = q.z; pf[u][3] = q.w;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            const int i = GA.t + u * GA.nt;
+            const float4 q = ldf4(nsrc, i < ncnt ? i : 0);
+            pf[u][0] = q.x; pf[u][1] = q.y; pf[u][2] = q.z; pf[u][3] = q.w;
+          }
         }
         STAMP_T(41 + 4 * l, 0);              // group A done with its phase-1 work
         if (more && DB) ws.store(Wn);
@@ -1052,7 +1154,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
           const int i = GA.t + u * GA.nt;
           if (i < ncnt) ndst[i] = make_float4(pf[u][0], pf[u][1], pf[u][2], pf[u][3]);
         }
-        for (int i = GA.t + PF * GA.nt; i < ncnt; i += GA.nt) ndst[i] = ldf4(nsrc, i);
+        for (int i = GA.t + PF * GA.nt; i < ncnt; i += GA.nt) ndst[i] = hand ? ldf4_sc1<TS>(nrs, i) : ldf4(nsrc, i);
         STAMP_T(43 + 4 * l, 0);              // group A done with its phase-2 work
         lds_barrier();
       } else {
@@ -1081,7 +1183,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       lds_barrier();
       STAMP(5 + 4 * l);
       if (vonly || !FUSE) {
-        if (vonly && more && A.ready) wait_published(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
+        if (vonly && more && A.ready) wait_published<true>(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
         if (vonly) load_next_local(ALL, xa); else reduce_ll(ALL);
         STAMP_T(43 + 4 * l, 0);
         lds_barrier();

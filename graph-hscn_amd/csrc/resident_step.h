@@ -64,7 +64,7 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   Y.NB = L + 1 > 3 ? L + 1 : 3;
   // staged COO slices live in A[1], the CSR builds' counters / slot lists in A[2] (both dead until layers 0 / 1 write
   // them); a buffer is widened if a dense graph needs more than n x H words for either
-  size_t bufw = up4((size_t)max_n * H);
+  size_t bufw = (size_t)((max_n + 15) / 16 * 16) * H;   // whole 16-row tiles (A[0] doubles as per-wave tile scratch)
   const size_t stage = 2 * up4(max_ell);
   const size_t scratch = 2 * up4((size_t)max_n + 1) + 2 * up4(max_ell);
   if (stage > bufw) bufw = stage;
@@ -80,7 +80,7 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   Y.dinv = take(max_n);
   Y.wt = take((size_t)L * (H * H + H));                            // per layer: Wt[k][o] (rows k >= fin zero) | b[H]
   Y.headw = take((size_t)H * H + H + (size_t)C * H + 4 * (size_t)C);  // W1 | b1 | W2 | b2 | target row | g_pred row | loss terms
-  Y.part = take((size_t)(RT_MAX / 64) * H);                        // pool partials, later bias-gradient partials
+  Y.part = take((size_t)2 * (RT_MAX / 64) * H);                    // pool partials, later bias-gradient partials (x2: layer parity)
   Y.vec = take(320);
   Y.red = take((size_t)(RT_MAX / 64) * 256);
   Y.rowptr = take((size_t)max_n + 1);
@@ -90,29 +90,6 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   Y.wsum = take(32);
   Y.total = o;
   return Y;
-}
-
-// 16-byte (float) / 8-byte (half) write-through stores of n x H activations from LDS to the hand-off buffer
-template <typename TS, int H, int RT>
-__device__ __forceinline__ void publish_rows(const float* A, TS* dst, int n) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  const int cnt = n * (H / 4);
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(dst, 0, cnt * 4 * (int)sizeof(TS), 0x00020000);
-  for (int i = threadIdx.x; i < cnt; i += RT) {
-    const float4 v = reinterpret_cast<const float4*>(A)[i];
-    if constexpr (sizeof(TS) == 4) {
-      u32x4 w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-      __builtin_amdgcn_raw_buffer_store_b128(w, rs, i * 16, 0, 16 /* sc1 */);
-    } else {
-      half4_t h;
-      h.x = (half_t)v.x; h.y = (half_t)v.y; h.z = (half_t)v.z; h.w = (half_t)v.w;   // exact: the values are half already
-      u32x2 w;
-      __builtin_memcpy(&w, &h, 8);
-      __builtin_amdgcn_raw_buffer_store_b64(w, rs, i * 8, 0, 16 /* sc1 */);
-    }
-  }
 }
 
 // Y[n][H] = mask(M) .* (X[n][H] * W), W given TRANSPOSED in LDS (Wt[k][o] = W[o][k], the forward's layout):
@@ -270,6 +247,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     if (bad && A.flag) atomicOr(A.flag, 2);
   }
   for (int i = threadIdx.x; i <= n; i += RT) { (ib + Y.cursorA)[i] = 0; (ib + Y.cursorT)[i] = 0; }
+  if (threadIdx.x == 0) (ib + Y.wsum)[0] = 0;   // completed weight-gradient folds (H = 16 backward)
   {
     float* x0 = buf(0);
 #pragma unroll
@@ -318,17 +296,25 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   lds_barrier();
   STAMP(3);
   // ---- forward layers: A[l] -> A[l + 1], one barrier each ----------------------------------------------------
+  // Hand-off of a_1 .. a_{L-1} to the virtual workgroup (gcn_fused_pub): a layer's output rows leave as write-through
+  // (sc1) stores at the end of the layer; the wave's wait for the PREVIOUS layer's stores sits right in front of
+  // them (free: those are a whole layer old), the layer's barrier follows, then one lane raises the graph's publish
+  // counter for the previous layer's rows.  Nothing is re-read from LDS and nothing stalls.
   for (int l = 0; l < L; ++l) {
-    if (acts_g && l >= 1)   // a_l is complete (previous barrier): hand it to the virtual workgroup, write-through
-      publish_rows<TS, H, RT>(buf(l), acts_g + ((size_t)(l - 1) * A.N + n0) * H, n);
-    STAMP(4 + 4 * l);
-    gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, ALL);
-    if (acts_g && l >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (R1)
+    STAMP(4 + l);
+    const bool hand = acts_g != nullptr;
+    if (hand && l + 1 < L) {   // a_{l+1} is wanted by the virtual branch
+      gcn_fused_pub<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1),
+                           acts_g + ((size_t)l * A.N + n0) * H, n, ALL, l >= 1);
+    } else {
+      gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, ALL);
+      if (hand && l >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a_l's stores (a layer old) have completed
+    }
     lds_barrier();
-    if (acts_g && A.ready && l >= 1 && threadIdx.x == 0)
+    if (hand && A.ready && l >= 1 && threadIdx.x == 0)
       __hip_atomic_store(A.ready + g, ep8 + (uint32_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  STAMP(62);
+  STAMP(12);
   // ---- global_mean_pool + head + this graph's row of the loss tail --------------------------------------------
   float* aL = buf(L);
   {
@@ -415,9 +401,16 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       for (int c = 0; c < C; ++c) acc = fmaf(gpl[c], W2l[c * H + lane], acc);
       gz[lane] = acc * act_grad_from_output(zz[lane], A.head_act);
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < H) {   // d loss / d pooled
+      float acc = 0.f;
+#pragma unroll
+      for (int o = 0; o < H; ++o) acc = fmaf(gz[o], W1l[o * H + lane], acc);
+      gpool[lane] = acc;
+    }
   }
   lds_barrier();
-  STAMP(63);
+  STAMP(13);
 
   // ================================ backward ======================================================
   // partial layout: per layer {W_ll [H*fin], b_ll [H]}, then W1 [H*H], b1 [H], W2 [C*H], b2 [C], loss column
@@ -438,20 +431,14 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     const int o = idx / H, k = idx - o * H;
     part[oW1 + idx] = gz[o] * pol[k];
   }
-  if (threadIdx.x < H) {
-    part[ob1 + threadIdx.x] = gz[threadIdx.x];
-    float acc = 0.f;
-#pragma unroll
-    for (int o = 0; o < H; ++o) acc = fmaf(gz[o], W1l[o * H + threadIdx.x], acc);
-    gpool[threadIdx.x] = acc;
-  }
-  lds_barrier();
+  if (threadIdx.x < H) part[ob1 + threadIdx.x] = gz[threadIdx.x];
   float* G = aL;                  // gradient of the current layer's output, masked in place
   float* GH = L >= 2 ? buf(0) : buf(2);
   {
     const float cnt = (float)(n > 0 ? n : 1);
     for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = G[idx] > 0.f ? gpool[idx % H] / cnt : 0.f;
   }
+  STAMP(14);
   float* bred = partp;
   constexpr int GW_TD = H / 16, GW_NT = GW_TD * GW_TD;
   constexpr int GW_TPP = GW_NT < NW ? GW_NT : NW, GW_RG = NW / GW_TPP;
@@ -470,6 +457,158 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   };
   int pend_oW = -1, pend_fin = 0;
   int off = off_head;
+  if constexpr (H == 16) {
+    // ---- a backward layer in ONE phase (one barrier): a wave owns 16-row tiles.  For a tile it gathers its rows of
+    // GH = A_hat^T G (source-keyed CSR, edge order, separately rounded: the same values as the two-phase backward),
+    // takes the input gradient (GH W_l, masked) off the matrix cores and writes it over the tile's rows of the layer
+    // input a_l IN PLACE -- those rows are read by this wave alone (mask, weight-gradient operand), and nobody
+    // gathers from a_l's buffer before the next barrier -- and accumulates its part of the weight gradient
+    // GH^T a_l through a wave-private 16 x 16 transposition scratch.  The 16 partial weight-gradient tiles are
+    // folded after the barrier, as before; the folders sign off in an LDS counter that the next layer's writers
+    // of the partial-tile buffer check (it has always been reached by then: no wait in practice, no race in theory).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    int* fold_cnt = ib + Y.wsum;
+    constexpr int NFW = NW < 4 ? NW : 4;            // waves that take part in a fold (threads 0 .. 255)
+    float* ght = buf(0);                            // dead after forward layer 0 (the features are re-read from HBM)
+    float* Gc = aL;
+    const int li = lane & 15, lj = lane >> 4;
+    const int ntile = (n + 15) >> 4;
+    int pend_ob = 0;
+    for (int it = 0, l = L - 1; l >= 0; --l, ++it) {
+      const int fin = l == 0 ? F : H;
+      off -= H * fin + H;
+      const int oW = off, ob = off + H * fin;
+      float* bredw = bred + (it & 1) * NW * H;
+      lds_barrier();  // G complete; the previous layer's partial tiles and bias partials are in LDS
+      if (pend_oW >= 0) {
+        fold_gw(0, pend_oW, pend_fin);
+        if (threadIdx.x < H) {
+          const float* bp = bred + ((it - 1) & 1) * NW * H;
+          float sb = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) sb += bp[w * H + threadIdx.x];
+          part[pend_ob + threadIdx.x] = sb;
+        }
+        if (wave < NFW) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(fold_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      {   // bias gradient = column sums of G
+        const int slot = lane >> 2, f = (lane & 3) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = wave * 16 + slot; i < n; i += NW * 16) {
+          const float4 v = *reinterpret_cast<const float4*>(Gc + i * H + f);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+        acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+        acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+        acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+        acc.x = row_ror_add<8>(acc.x); acc.y = row_ror_add<8>(acc.y);
+        acc.z = row_ror_add<8>(acc.z); acc.w = row_ror_add<8>(acc.w);
+        acc.x = row_ror_add<4>(acc.x); acc.y = row_ror_add<4>(acc.y);
+        acc.z = row_ror_add<4>(acc.z); acc.w = row_ror_add<4>(acc.w);
+        if (slot == 0) *reinterpret_cast<float4*>(bredw + wave * H + f) = acc;
+      }
+      float* Xl = buf(l);                           // the layer input a_l (l >= 1); becomes G_l tile by tile
+      const float* Wl = wt + l * WL;
+      float bw[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bw[s] = l > 0 ? Wl[li * H + 4 * lj + s] : 0.f;   // W_l[4 lj + s][li]
+      f32x4 accw = {0.f, 0.f, 0.f, 0.f};
+      float* sc = ght + wave * 256;
+      for (int rt = wave; rt < ntile; rt += NW) {
+        const int r0 = rt * 16, i = r0 + li;
+        float bx[4];
+        if (l == 0) {   // the features, straight from HBM into the weight gradient's operand registers
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int row = r0 + 4 * c + lj;
+            const bool okx = row < n && li < fin;
+            const float tx = ldf(xl_g, okx ? (size_t)(n0 + row) * fin + li : 0);
+            bx[c] = okx ? tx : 0.f;
+          }
+        }
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+          const int s0 = rowptr_t[i], t0 = rowptr_t[i + 1];
+          const float di = dinv[i];
+          const float* gq = Gc + 4 * lj;
+          for (int p = s0; p < t0; p += 4) {
+            int jj[4];
+            float ww[4];
+            float4 vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = col_t[p + u < t0 ? p + u : t0 - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              ww[u] = mul_rn(dinv[jj[u]], di);
+              vv[u] = *reinterpret_cast<const float4*>(gq + jj[u] * H);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (p + u < t0) {
+                z.x = add_rn(z.x, mul_rn(ww[u], vv[u].x));
+                z.y = add_rn(z.y, mul_rn(ww[u], vv[u].y));
+                z.z = add_rn(z.z, mul_rn(ww[u], vv[u].z));
+                z.w = add_rn(z.w, mul_rn(ww[u], vv[u].w));
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the previous tile's reads of the scratch are done
+        *reinterpret_cast<float4*>(sc + li * 16 + 4 * lj) = z;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (l > 0) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(z.x, bw[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(z.y, bw[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(z.z, bw[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(z.w, bw[3], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the tile is in the scratch before it is read back
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int row = r0 + 4 * c + lj;
+          const float av = sc[(4 * c + lj) * 16 + li];                       // GH[row][o = li]
+          const float bv = l == 0 ? bx[c] : (row < n ? Xl[row * H + li] : 0.f);   // a_l[row][k = li]
+          accw = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accw, 0, 0, 0);
+        }
+        if (l > 0) {
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this tile's rows of a_l have been read: overwrite them
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = r0 + lj * 4 + r;
+            if (row < n) {
+              const int idx = row * H + li;
+              Xl[idx] = Xl[idx] > 0.f ? acc[r] : 0.f;
+            }
+          }
+        }
+      }
+      if (it > 0) {   // the folders of the previous layer's partial tiles have signed off (see above)
+        while (__hip_atomic_load(fold_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it * NFW)
+          __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave * 256 + (lj * 4 + r) * 16 + li] = accw[r];
+      pend_oW = oW; pend_fin = fin; pend_ob = ob;
+      Gc = Xl;
+      STAMP(16 + 3 * l);
+    }
+    lds_barrier();
+    fold_gw(0, pend_oW, pend_fin);
+    if (threadIdx.x < H) {
+      const float* bp = bred + ((L - 1) & 1) * NW * H;
+      float sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sb += bp[w * H + threadIdx.x];
+      part[pend_ob + threadIdx.x] = sb;
+    }
+    STAMP(61);
+    return;
+  }
   for (int l = L - 1; l >= 0; --l) {
     const int fin = l == 0 ? F : H;
     off -= H * fin + H;
@@ -529,7 +668,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       }
     }
     lds_barrier();
-    STAMP(4 + 4 * l);
+    STAMP(16 + 3 * l);
     if (threadIdx.x < H) {   // bias gradient: fold the waves' column sums in wave order
       float sb = 0.f;
 #pragma unroll
@@ -567,11 +706,11 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
         }
       }
     }
-    STAMP(5 + 4 * l);
+    STAMP(17 + 3 * l);
     // input gradient: G[j][k] = relu'(a_l[j][k]) * sum_o GH[j][o] W_l[o][k]; the forward's transposed W_l is read
     // transposed again (a_l = X doubles as the mask; the old G is dead: GH holds what is needed of it)
     if (l > 0) lin_mfma_wt_masked<H>(GH, wt + l * WL, G, n, X, ALL);
-    STAMP(6 + 4 * l);
+    STAMP(18 + 3 * l);
   }
   if (GW1 && pend_oW >= 0) {
     lds_barrier();

@@ -167,8 +167,11 @@ class CapturedStep:
     in the capture, live tensors of earlier eager steps and earlier ``CapturedStep`` objects on the same model
     cannot reach into it (tests/test_gpu_step.py)."""
 
-    def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None, pre=None):
-        """``pre``: a callable captured in front of the step that refreshes the static buffers from device-side
+    def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None, pre=None,
+                 one_launch: Optional[bool] = None):
+        """``one_launch``: passed to ``step.ResidentTrainStep`` (None: the one-launch step whenever the batch fits it;
+        False: the forward + backward launch pair, whose gradients are bit-identical to the eager autograd path).
+        ``pre``: a callable captured in front of the step that refreshes the static buffers from device-side
         state only (``DeviceHeteroDataset.gather_next``); note that the warm-up iterations and the capture call
         it too (rewind with ``new_epoch`` afterwards).
         ``optimizer``: a ``torch.optim`` optimizer built with ``capturable=True`` (``fused=True`` keeps it to one
@@ -188,7 +191,7 @@ class CapturedStep:
         if "y" not in hb["local"]:
             raise ValueError("the static batch carries no targets")
         try:
-            self.step = ResidentTrainStep(model, hb, loss_fn)
+            self.step = ResidentTrainStep(model, hb, loss_fn, one_launch=one_launch)
         except RuntimeError as e:
             raise RuntimeError("CapturedStep needs the graph-resident engine (the layered operators size their "
                                "work by tensor shapes, which a static-capacity batch does not carry): " + str(e)) from e

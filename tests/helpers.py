@@ -54,3 +54,16 @@ def scale_close(a, b, rel=1e-5):
     if d > lim:
         print("max abs diff", d, "limit", lim)
     return d <= lim
+
+
+def grads_close(a, b, rel=2e-6):
+    """Two float32 evaluations of the same gradient that group their partial sums differently (the one-launch step
+    sums a weight gradient per 16-row tile, the launch pair per strided row chunk): equal to a few ulp of the
+    gradient's magnitude."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    lim = rel * max(1e-6, float(b.abs().max()))
+    d = float((a - b).abs().max()) if a.numel() else 0.0
+    if d > lim:
+        print("max abs diff", d, "limit", lim)
+    return d <= lim

@@ -124,17 +124,23 @@ def test_captured_step_replays_on_different_batches():
     del pred, loss, d      # (tensors of an eager step keep autograd nodes tied to the stream they ran on)
     static = StaticHeteroBatch(batches, dev)
     static.load(batches[0])
-    step = CapturedStep(model, static, "cross_entropy")
+    from tests.helpers import grads_close
     packed = [static.pack(hb) for hb in batches]          # laid out like the static buffers: one copy per load
-    for k, i in enumerate((1, 2, 0, 2, 1)):
-        static.load(packed[i] if k % 2 else batches[i])
-        loss = step.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(step.pred, ref[i][0])
-        assert torch.equal(loss, ref[i][1])
-        for n, p in model.named_parameters():
-            if n in ref[i][2]:
-                assert torch.equal(p.grad, ref[i][2][n]), (i, n)
+    for one_launch in (False, None):      # the launch pair (bit-identical to eager), then the default one-launch step
+        step = CapturedStep(model, static, "cross_entropy", one_launch=one_launch)
+        assert step.step.one_launch == (one_launch is None)
+        for k, i in enumerate((1, 2, 0, 2, 1)):
+            static.load(packed[i] if k % 2 else batches[i])
+            loss = step.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(step.pred, ref[i][0])
+            assert torch.equal(loss, ref[i][1])
+            for n, p in model.named_parameters():
+                if n in ref[i][2]:
+                    if one_launch is False:
+                        assert torch.equal(p.grad, ref[i][2][n]), (i, n)
+                    else:
+                        assert grads_close(p.grad, ref[i][2][n]), (i, n)
     static.batch._resident_meta.check()
 
 

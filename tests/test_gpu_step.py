@@ -70,10 +70,13 @@ def test_direct_step_is_the_autograd_step_bit_for_bit(overlap, compute_virtual, 
     assert torch.equal(rs.pred, pred.detach())
     assert torch.equal(rs.score, score)
     assert torch.equal(rs.loss, loss.detach())
+    from tests.helpers import grads_close
     got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert got.keys() == grads.keys()
     for n in grads:
-        assert torch.equal(got[n], grads[n]), n
+        # the launch pair IS the autograd path's launches; the one-launch step groups the weight gradient's partial
+        # sums by row tile (same terms, another order)
+        assert (grads_close(got[n], grads[n]) if one_launch else torch.equal(got[n], grads[n])), n
     if want_v is not None:
         assert torch.equal(rs.virtual, want_v)
     if compute_virtual and not overlap:
@@ -99,8 +102,8 @@ def test_capture_is_immune_to_live_eager_tensors_and_earlier_captures():
         keep_alive.append((pred, loss, loss.detach(), d))       # autograd graphs of eager steps stay referenced
     static = StaticHeteroBatch(batches, dev)
     static.load(batches[0])
-    step1 = CapturedStep(model, static, "cross_entropy")
-    step2 = CapturedStep(model, static, "cross_entropy")          # an earlier capture on the same model is alive too
+    step1 = CapturedStep(model, static, "cross_entropy", one_launch=False)
+    step2 = CapturedStep(model, static, "cross_entropy", one_launch=False)   # an earlier capture on the same model is alive too
     for step in (step1, step2, step1):
         for i in (1, 0):
             static.load(batches[i])
@@ -188,13 +191,13 @@ def test_scn_direct_step_is_the_autograd_step_bit_for_bit():
                                                   ("peptides_struct", 32, 32, 16, 2, 11, torch.float32),
                                                   ("pcqm_contact", 120, 16, 32, 3, 1, torch.float32),
                                                   ("peptides_func", 24, 4, 16, 1, 10, torch.float32)])
-def test_one_launch_step_hand_off_under_uneven_load(name, B, K, H, L, C, dtype):
-    """The in-launch hand-off of the local activations to the virtual workgroups (sc1 stores -> drain -> flag;
-    poll -> acquire -> loads), exercised the way such protocols fail: graphs of very different sizes (8 .. 444
-    nodes: producers finish at very different times), every CU busy (2B workgroups on 256 CUs), consumer caches
-    warm (the same buffers are re-read replay after replay), and EVERY word of the result compared -- the final
-    virtual features must equal the launch pair's bit for bit on each of 40 replays, as must prediction, loss and
-    gradients; no workgroup may have timed out."""
+def test_one_launch_step_against_the_launch_pair_at_full_occupancy(name, B, K, H, L, C, dtype):
+    """The one-launch step with every CU busy (up to 2B = 256 workgroups: B local programs, B virtual-branch
+    programs that recompute the local chain they read) and graphs of very different sizes, eager and replayed,
+    40 times: prediction, score, loss and the final virtual features equal the launch pair's bit for bit every
+    time; the gradients equal them to float rounding (H = 16 groups the weight gradient's partial sums by row
+    tile) and are bitwise identical from run to run."""
+    from tests.helpers import grads_close
     from graph_hscn.config.config import ACT_DICT
     from graph_hscn.data import HeteroBatch
     from graph_hscn.loader.hetero_data import hetero_from_clusters
@@ -233,5 +236,8 @@ def test_one_launch_step_hand_off_under_uneven_load(name, B, K, H, L, C, dtype):
         torch.cuda.synchronize()
         assert torch.equal(one.virtual, pair.virtual), it
         assert torch.equal(one.pred, pair.pred) and torch.equal(one.score, pair.score), it
-        assert torch.equal(one.grads, pair.grads), it
+        if it == 0:
+            first = one.grads.clone()
+            assert grads_close(one.grads[:-1], pair.grads[:-1]) and torch.equal(one.grads[-1], pair.grads[-1])
+        assert torch.equal(one.grads, first), it          # bitwise reproducible
     one.check()
