@@ -47,15 +47,19 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default: the workload's)")
     ap.add_argument("--hidden", type=int, default=16)
     ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
-                    help="graph: the step (structure build + fwd + loss + bwd) is replayed as one hipGraph")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "eager-autograd"],
+                    help="graph: the step (structure build + fwd + loss + bwd) is replayed as one hipGraph; eager: the same "
+                         "direct C-ABI launches issued from Python every step (what the PMC passes profile); "
+                         "eager-autograd: model(...) -> criterion -> loss.backward() through torch autograd")
     ap.add_argument("--engine", default="auto", choices=["auto", "resident", "layered"],
                     help="resident: one workgroup per graph, all layers in LDS; layered: one kernel per operator")
     ap.add_argument("--structure", default="per-step", choices=["per-step", "cached"],
                     help="per-step: COO->CSR build is inside every timed step")
-    ap.add_argument("--steps-per-graph", type=int, default=1,
-                    help="graph mode, one GPU: capture this many consecutive steps in one hipGraph (the gap between two "
-                         "replays, ~4 us, is then paid once per group); the timed region is still exactly --steps steps")
+    ap.add_argument("--steps-per-graph", type=int, default=4,
+                    help="graph mode: capture this many consecutive steps (each with its gradient all-reduce) in one "
+                         "hipGraph -- the host's replay overhead (~4 us per graph launch) is then paid once per group, as "
+                         "in a training loop that captures several iterations per replay; the timed region is still "
+                         "exactly --steps steps, and the line carries the 1-step-per-graph figure beside it")
     ap.add_argument("--cluster-ids", default="scn_untrained", choices=["scn_untrained", "uniform"],
                     help="scn_untrained: argmax of a seeded random-weight SCN (SURVEY.md 8d; collapses to ~3 clusters per "
                          "graph); uniform: ids drawn uniformly from 0..K-1 (U ~ K virtual nodes per graph, what a trained "
@@ -64,6 +68,13 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f16: node features and inter-layer activations stored as IEEE half in HBM, float accumulation "
                          "(BASELINE.json configs[4]: PCQM-Contact, 'fp16 feat + bf16 accum'); graph-resident engine only")
+    ap.add_argument("--stage", default="c", choices=["c", "a"],
+                    help="c: the headline (HSCN fwd + loss + bwd); a: the MinCUT coarsening step alone (gcn_norm + SCN fwd + "
+                         "(mincut + ortho) bwd) as the headline line, with --route")
+    ap.add_argument("--route", default="sparse", choices=["sparse", "dense"],
+                    help="--stage a: sparse = fused graph-resident launches on the edge list; dense = to_dense_adj + "
+                         "dense_mincut_pool on the matrix cores (BASELINE.json configs[3]: PascalVOC-SP, 64 clusters; "
+                         "equally sized graphs, n = 479)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming-spmm", action="store_true")
     ap.add_argument("--no-stage-a", action="store_true")
@@ -186,6 +197,22 @@ def cpu_baseline(hb, args, C, loss_fn, seconds):
             "ms_per_step": 1e3 * dt / n}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator is created; rank 0's stdout must carry
+    one JSON line and nothing else (the driver parses it), so file descriptor 1 points at stderr while the process
+    group comes up and the first collective runs."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def capture(fn, warmup=3):
     """Warm ``fn`` up on a side stream, then capture it as one hipGraph."""
     side = torch.cuda.Stream()
@@ -204,7 +231,7 @@ def capture(fn, warmup=3):
 class TimedStep:
     """One training step of stage C in the form the run asks for.  ``run(n)`` issues exactly n steps."""
 
-    def __init__(self, args, model, hb, loss_fn, reducer, B, world):
+    def __init__(self, args, model, hb, loss_fn, reducer, B, world, spg_override=None):
         from graph_hscn import structure
         from graph_hscn.loss import criterion
         from graph_hscn.step import ResidentTrainStep
@@ -235,10 +262,22 @@ class TimedStep:
             return loss
 
         self.step_eager = step_eager
-        if args.mode == "eager":
+        self.in_graph_allreduce = False
+        if args.mode == "eager-autograd" or (args.mode == "eager" and args.engine == "layered"):
             self.loss = step_eager().detach()
             self.run = lambda n: [step_eager() for _ in range(n)] and None
-            self.in_graph_allreduce = False
+            return
+        if args.mode == "eager":
+            self.fused = ResidentTrainStep(model, hb, loss_fn)
+            self.fused.bind_grads()
+            model.last_engine = "resident"
+            self.loss = self.fused.loss
+
+            def run_direct(n):
+                for _ in range(n):
+                    self.fused.run()
+                    reduce()
+            self.run = run_direct
             return
         # graph mode.  The gradient all-reduce is captured INTO the step's hipGraph (RCCL kernels are capturable): one
         # replay per step on every rank, no eager collective launch between replays.  HSCN_BENCH_GRAPH_ALLREDUCE=0
@@ -271,9 +310,12 @@ class TimedStep:
         graph = capture(body)
         if self.loss is None:
             self.loss = holder["loss"].detach()
-        self.spg = args.steps_per_graph if (reducer is None and args.steps_per_graph > 1) else 1
+        # several steps per replay need the collective inside the graph (it sits between consecutive steps)
+        self.spg = args.steps_per_graph if (args.steps_per_graph > 1 and (reducer is None or self.in_graph_allreduce)) else 1
+        if spg_override is not None:
+            self.spg = spg_override
         if self.spg > 1:
-            self.multi = capture(lambda: [one() for _ in range(self.spg)], warmup=1)
+            self.multi = capture(lambda: [body() for _ in range(self.spg)], warmup=1)
 
         def run(n):
             if self.multi is not None:
@@ -296,8 +338,106 @@ def time_steps(ts, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
+def stage_a_main(args):
+    """--stage a: one MinCUT coarsening step (reference train/train_clustering.py:37-49 for a batch of graphs) as
+    the reported line.  --route dense is BASELINE.json configs[3]: to_dense_adj + dense_mincut_pool with A S,
+    S^T(A S), S^T S, S^T X on the matrix cores; the roofline is the MFMA one of the A S launch
+    (2 K n^2 + 2 n K^2 flops per graph against the fp32-MFMA peak of 157.3 TFLOP/s)."""
+    from graph_hscn import _hip
+    from graph_hscn.data import Batch
+    from graph_hscn.loader.synthetic import SHAPES, make_graph
+    from graph_hscn.model.hscn import SCN
+    from graph_hscn.step import ScnTrainStep
+    import graph_hscn.nn.functional as Fh
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    _hip.lib()
+    shape, B0, K, C, loss_fn = WORKLOADS[args.workload]
+    B = args.batch or B0
+    rng = np.random.default_rng(args.seed)
+    fixed_n = int(round(SHAPES[shape].n_mean)) if args.route == "dense" else None
+    graphs = [make_graph(rng, SHAPES[shape], n=fixed_n) for _ in range(B)]
+    F = graphs[0].x.size(1)
+    torch.manual_seed(1)
+    scn = SCN([16], "elu", F, K, mincut_route=args.route).to(dev)
+    big = Batch.from_data_list(graphs).to(dev)
+    big.x = big.x.float()
+    N, E = int(big.num_nodes), int(big.edge_index.size(1))
+    roofline = None
+    if args.route == "sparse" and scn.resident_ok(big):
+        st = ScnTrainStep(scn, big)
+        g = capture(st.run)
+        step = g.replay
+        issue = "hipGraph replay of the two fused launches (graph_hscn.step.ScnTrainStep)"
+    else:
+        one = torch.ones((), device=dev)
+
+        def step():
+            for p in scn.parameters():
+                p.grad = None
+            S, mc, o, total = scn.forward_graphs(big, with_total=True)
+            total.backward(one)
+        issue = ("eager (layered operators + csrc/dense.hip through autograd)" if args.route == "dense" else
+                 "eager (layered operators through autograd: the graphs do not fit the fused stage-A launch at this K)")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if args.route == "dense":
+        # the dominant launch: A S (a [n,n] x [n,K] product per graph) inside hscn_mincut_dense_fwd -- time the C call
+        n = fixed_n
+        timer = KernelTimer(["hscn_mincut_dense_fwd", "hscn_mincut_dense_bwd"])
+        orig = _hip.call
+        Fh.call = lambda name, *a: timer.wrap(name, lambda *b: orig(name, *b), *a)
+        for _ in range(5):
+            torch.cuda._sleep(400000)
+            step()
+        torch.cuda.synchronize()
+        Fh.call = orig
+
+        def avg(name):
+            hit = [(ev[4], ev[1]) for ev in timer.events if ev[0] == name][-1]
+            for _ in range(3):
+                orig(hit[0], *hit[1])
+            torch.cuda._sleep(400000)
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(20):
+                orig(hit[0], *hit[1])
+            e_.record()
+            torch.cuda.synchronize()
+            return s_.elapsed_time(e_) * 1e-3 / 20
+        t_f, t_b = avg("hscn_mincut_dense_fwd"), avg("hscn_mincut_dense_bwd")
+        fl_sas = B * (2.0 * K * n * n + 2.0 * n * K * K)               # SURVEY.md 8(d): S^T A S
+        fl_f = B * (2.0 * n * n * K + 2.0 * K * n * K + 2.0 * K * n * K + 2.0 * K * n * 16)   # + S^T S + S^T X
+        PEAK = 157.3
+        roofline = {"bound": "mfma", "kernel": "hscn_mincut_dense_fwd (softmax, k_bgemm A S, merged S^T(AS) | S^T S | S^T X, "
+                    "statistics: v_mfma_f32_16x16x4_f32)", "achieved": fl_sas / t_f / 1e12, "peak": PEAK, "unit": "TFLOP/s",
+                    "frac": fl_sas / t_f / 1e12 / PEAK, "traffic": None,
+                    "flops_per_launch_SAS": fl_sas, "flops_per_launch_all_contractions": fl_f,
+                    "frac_all_contractions": fl_f / t_f / 1e12 / PEAK, "avg_launch_us": t_f * 1e6,
+                    "bwd_launch_us": t_b * 1e6, "adjacency_bytes": B * n * n * 4,
+                    "adjacency_GBs_fwd": B * n * n * 4 / t_f / 1e9,
+                    "note": "the C call spans several launches (softmax, A S, the merged cluster-space contractions, "
+                            "statistics); MFMA-busy of the A S launch alone: profiles/*pmc_mfma_dense*.json"}
+    out = {"metric": f"graphs/sec (fwd+bwd) on {args.workload} stage A (MinCUT coarsening)", "value": B * args.steps / dt,
+           "unit": "graphs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Graph-HSCN stage A (gcn_norm + SCN fwd + (mincut+ortho) bwd) on {args.workload}-shaped graphs",
+                      "route": args.route, "graphs_per_gpu": B, "num_clusters": K, "nodes_per_gpu": N,
+                      "edges_per_gpu": E, "nodes_per_graph": fixed_n, "step_issue": issue, "parallelism": "dp1"},
+           "roofline": roofline, "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.stage == "a":
+        return stage_a_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -313,7 +453,10 @@ def main():
         if force_dist and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))          # creates the communicator (and prints the banner) now
+            torch.cuda.synchronize()
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -353,6 +496,15 @@ def main():
     spg = ts.spg
     if ts.fused is not None:
         ts.fused.check()
+
+    # ---- the same measurement with ONE step per hipGraph replay (what round 1 reported): the difference is the host's
+    # replay overhead per graph launch, not kernel time
+    single = None
+    if rank == 0 and world == 1 and not force_dist and args.mode == "graph" and spg > 1:
+        ts1 = TimedStep(args, model, hb, loss_fn, None, B, 1, spg_override=1)
+        dt1 = time_steps(ts1, args.steps, args.warmup, barrier)
+        single = {"steps_per_graph": 1, "ms_per_step": 1e3 * dt1 / args.steps, "graphs_per_s": B * args.steps / dt1}
+        del ts1
 
     # ---- the same step on the OTHER choice of cluster ids (one GPU only): the untrained SCN's argmax collapses to
     # ~3 clusters per graph, a trained assignment uses ~K -- the virtual branch's share of the step differs
@@ -513,6 +665,9 @@ def main():
                     roofline["traffic_source"] = (f"profiles/{fname}: a SEPARATE rocprofv3 --pmc run of this command "
                                                   f"(FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction), "
                                                   f"collected at commit {doc.get('_commit', 'unrecorded')}")
+                    roofline["rocprof_kernel_stats"] = ("profiles/r02_step_kernel_stats.csv (rocprofv3 --kernel-trace --stats "
+                                                        "of the default command): the C call timed here = k_hscn_step + "
+                                                        "k_param_reduce")
             if streaming and "traffic" not in streaming and "k_spmm_scaled_H128" in pmc:
                 streaming["traffic"] = pmc["k_spmm_scaled_H128"]["traffic_bytes"]
 
@@ -569,7 +724,7 @@ def main():
                        "allreduce": (None if reducer is None else
                                      ("captured in the step's hipGraph" if ts.in_graph_allreduce else "eager, after each replay")),
                        "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "other_cluster_ids": other_ids,
+            "roofline": roofline, "cpu_baseline": cpu, "one_step_per_graph": single, "other_cluster_ids": other_ids,
             "streaming_spmm_scaled": streaming, "stage_a": stage_a,
         }
         if cpu:

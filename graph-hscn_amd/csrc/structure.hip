@@ -213,6 +213,18 @@ __global__ void k_dense_adj(const int64_t* __restrict__ row, const int64_t* __re
   atomicAdd(&adj[r * n + c], 1.0f);  // exact: integer-valued, order independent
 }
 
+// block-diagonal batch of B graphs with n nodes each -> [B, n, n]; an edge that leaves its block is dropped
+__global__ void k_dense_adj_batched(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t E,
+                                    int64_t B, int64_t n, float* __restrict__ adj) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t r = row[e], c = col[e];
+  if (r < 0 || r >= B * n || c < 0 || c >= B * n) return;
+  const int64_t b = r / n;
+  if (c / n != b) return;
+  atomicAdd(&adj[(b * n + (r - b * n)) * n + (c - b * n)], 1.0f);
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -321,6 +333,15 @@ int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t E, int64_t
   if (E < 0 || n < 0 || (E > 0 && (!row || !col || !adj))) return HSCN_E_BADARG;
   if (E == 0) return 0;
   k_dense_adj<<<hscn_blocks(E, 256), 256, 0, hscn_stream(stream_)>>>(row, col, E, n, adj);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_to_dense_adj_batched(const int64_t* row, const int64_t* col, int64_t E, int64_t B, int64_t n, float* adj,
+                              void* stream_) {
+  if (E < 0 || n < 0 || B < 0 || (E > 0 && (!row || !col || !adj))) return HSCN_E_BADARG;
+  if (E == 0 || B == 0) return 0;
+  k_dense_adj_batched<<<hscn_blocks(E, 256), 256, 0, hscn_stream(stream_)>>>(row, col, E, B, n, adj);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

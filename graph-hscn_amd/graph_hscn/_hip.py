@@ -51,6 +51,7 @@ _SIGNATURES = {
     "hscn_mincut_dense_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, P, P, P, P, P]),
     "hscn_assign_argmax": (c_int, [P, P, c_int64, c_int, P]),
     "hscn_to_dense_adj": (c_int, [P, P, c_int64, c_int64, P, P]),
+    "hscn_to_dense_adj_batched": (c_int, [P, P, c_int64, c_int64, c_int64, P, P]),
     "hscn_build_hetero_count": (c_int, [P, c_int, P, P, c_int64, c_int, c_int, P, P, P, P, P]),
     "hscn_build_hetero_scan": (c_int, [P, c_int64, P, P, P, P, P, P, P]),
     "hscn_build_hetero_emit": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, c_int64, c_int64, P, P, P, P, P]),

@@ -26,7 +26,7 @@ from torch import Tensor
 from ..config.config import ACT_DICT, CONV_DICT, HSCNConfig
 from ..nn import GATConv, GCNConv, GraphConv, HeteroConv, Linear
 from ..nn import functional as Fh
-from ..nn.pool import global_mean_pool, mincut_pool_sparse, to_dense_adj
+from ..nn.pool import global_mean_pool, mincut_pool_sparse, to_dense_adj, to_dense_adj_batched
 from ..structure import Relation, relation_of
 from .. import engine as _engine
 
@@ -62,8 +62,19 @@ class _MessagePassingStack(nn.Module):
 
 class SCN(nn.Module):
     def __init__(self, mp_units: list, mp_act: str, num_features: int, num_clusters: int,
-                 mlp_units: list = [], mlp_act: str = "identity"):
+                 mlp_units: list = [], mlp_act: str = "identity", mincut_route: str = "sparse"):
+        """``mincut_route`` (extension): how ``dense_mincut_pool``'s contractions are evaluated.
+        "sparse" -- on the edge list, A never densified (tr(S^T A S) = sum over edges of s_i . s_j; the fused
+        graph-resident launch when the model has the reference's shape);
+        "dense"  -- the reference's literal sequence ``to_dense_adj`` -> ``dense_mincut_pool`` (model/hscn.py:61-63)
+        with the [B,n,n] adjacency materialised and A S, S^T (A S), S^T S, S^T X on the matrix cores (csrc/dense.hip,
+        exact-fp32 MFMA): BASELINE.json configs[3], PascalVOC-SP with 64 clusters;
+        "auto"   -- dense from 64 clusters on.  Same values either way (tests/test_gpu_models.py)."""
         super().__init__()
+        if mincut_route not in ("sparse", "dense", "auto"):
+            raise ValueError(f"mincut_route must be 'sparse', 'dense' or 'auto', not {mincut_route!r}")
+        self.mincut_route = mincut_route
+        self.num_clusters = int(num_clusters)
         if _act_name(mp_act) not in ACT_DICT or _act_name(mlp_act) not in ACT_DICT:
             raise KeyError(f"unknown activation {mp_act!r}/{mlp_act!r}")  # ACT_DICT[...] at hscn.py:34,53
         self.mp = _MessagePassingStack(num_features, mp_units, _act_name(mp_act))
@@ -77,8 +88,13 @@ class SCN(nn.Module):
             self.mlp.append(nn.Identity())
         self.mlp.append(Linear(out_channels, num_clusters))
 
+    def _dense(self) -> bool:
+        return self.mincut_route == "dense" or (self.mincut_route == "auto" and self.num_clusters >= 64)
+
     def resident_ok(self, data) -> bool:
         """Can ``forward_graphs`` take the fused graph-resident path for this input?"""
+        if self._dense():
+            return False          # the dense route is the layered operators + the MFMA contractions
         layers = list(self.mlp)
         if self.mp.num != 1 or len(layers) != 1:
             return False
@@ -117,11 +133,14 @@ class SCN(nn.Module):
                                "mlp_units=[], graphs that fit one CU's LDS)")
         ei, ew = gcn_norm(data.edge_index.to(dev), None, int(data.num_nodes), add_self_loops=True)
         node_ptr = data.ptr.to(dev).to(torch.int32) if "ptr" in data and data.ptr is not None else None
-        S, mc, o, _ = self.forward(data.x.to(dev).float(), ei, ew, node_ptr=node_ptr)
+        S, mc, o, _ = self.forward(data.x.to(dev).float(), ei, ew, node_ptr=node_ptr,
+                                   nodes_per_graph=getattr(data, "max_nodes", None) if node_ptr is not None else None)
         return (S, mc, o, mc + o) if with_total else (S, mc, o)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
-                node_ptr: Optional[Tensor] = None):
+                node_ptr: Optional[Tensor] = None, nodes_per_graph: Optional[int] = None):
+        """``nodes_per_graph`` (dense route on a batch): the common node count of the batch's graphs -- a dense
+        [B,n,n] adjacency needs equally sized graphs (the reference's own call is one graph at a time)."""
         n = x.size(0)
         rel = relation_of(edge_index, n, n)
         x = self.mp(x.float(), rel, edge_weight)
@@ -131,6 +150,21 @@ class SCN(nn.Module):
             if isinstance(m, Linear):
                 last = i == len(layers) - 1
                 s = m(s, act="identity" if last else self.mlp_act)
+        if self._dense():
+            # model/hscn.py:61-63 literally: adj = to_dense_adj(edge_index); dense_mincut_pool(x, adj, s)
+            if node_ptr is None:
+                Bg, ng = 1, n
+            else:
+                Bg = int(node_ptr.numel()) - 1
+                ng = int(nodes_per_graph) if nodes_per_graph else 0
+                if ng <= 0 or Bg * ng != n:
+                    raise ValueError("the dense MinCUT route takes one graph, or a batch of equally sized graphs with "
+                                     "nodes_per_graph given (a dense [B,n,n] adjacency has one n)")
+            adj = to_dense_adj_batched(edge_index, Bg, ng)
+            S, mc_loss, o_loss, _, _ = Fh.MinCutDenseFn.apply(s.view(Bg, ng, -1), x.view(Bg, ng, -1), adj)
+            self.last_route = "dense"
+            return S.view(n, -1), mc_loss, o_loss, (adj if node_ptr is None else None)
+        self.last_route = "sparse"
         S, _, _, mc_loss, o_loss = mincut_pool_sparse(x, rel, s, node_ptr)
         adj = to_dense_adj(edge_index, n) if node_ptr is None else None
         return S, mc_loss, o_loss, adj

@@ -36,6 +36,15 @@ def to_dense_adj(edge_index: Tensor, max_num_nodes: Optional[int] = None) -> Ten
     return adj.view(1, N, N)
 
 
+def to_dense_adj_batched(edge_index: Tensor, num_graphs: int, nodes_per_graph: int) -> Tensor:
+    """``to_dense_adj(edge_index, batch)`` for a block-diagonal batch of equally sized graphs: ``[B, n, n]``."""
+    B, n = int(num_graphs), int(nodes_per_graph)
+    adj = torch.zeros(B, n, n, dtype=torch.float32, device=edge_index.device)
+    call("hscn_to_dense_adj_batched", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()),
+         edge_index.size(1), B, n, ptr(adj), stream())
+    return adj
+
+
 def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor] = None, num_nodes: Optional[int] = None,
              improved: bool = False, add_self_loops: bool = True,
              dtype: torch.dtype = torch.float32) -> Tuple[Tensor, Tensor]:

@@ -168,9 +168,13 @@ class CapturedStep:
     cannot reach into it (tests/test_gpu_step.py)."""
 
     def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None, pre=None,
-                 one_launch: Optional[bool] = None):
+                 one_launch: Optional[bool] = None, reducer=None):
         """``one_launch``: passed to ``step.ResidentTrainStep`` (None: the one-launch step whenever the batch fits it;
         False: the forward + backward launch pair, whose gradients are bit-identical to the eager autograd path).
+        ``reducer``: a ``distributed.FlatGradReducer``; its all-reduce of the flat gradient buffer (RCCL kernels are
+        capturable) is captured between the backward and the optimizer step, so one replay per iteration is all a
+        rank issues -- no eager collective launch between replays.  Every rank must hold the same number of graphs
+        (``static.num_graphs``): the reduction is the mean over ranks.
         ``pre``: a callable captured in front of the step that refreshes the static buffers from device-side
         state only (``DeviceHeteroDataset.gather_next``); note that the warm-up iterations and the capture call
         it too (rewind with ``new_epoch`` afterwards).
@@ -202,6 +206,8 @@ class CapturedStep:
             if pre is not None:
                 pre()
             self.step.run()
+            if reducer is not None:
+                reducer.reduce(float(static.num_graphs), float(static.num_graphs * reducer.world_size))
             if optimizer is not None:
                 optimizer.step()
 

@@ -30,9 +30,10 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
 
     Data parallel: every rank calls this with ITS shard of the training graphs (``distributed.shard_list``; equal
     shard sizes, so that all ranks take the same number of steps) and a ``distributed.FlatGradReducer`` as
-    ``reducer`` (built with ``equal_weights=True`` it averages with no scaling launch).  The iteration is then two replays around one collective: forward + loss + backward, the RCCL
-    all-reduce of the flat gradient buffer where the backward left it, the optimizer step (captured on its own).
-    The eager tail batch is reduced the same way."""
+    ``reducer`` (built with ``equal_weights=True`` it averages with no scaling launch).
+    The iteration stays ONE replay: forward + loss + backward, the RCCL all-reduce of the flat gradient buffer where
+    the backward left it, the optimizer step -- all captured (an optimizer without a capturable step is stepped, and
+    the collective issued, outside the graph).  The eager tail batch is reduced the same way."""
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("fit_resident runs on the MI355X HIP path: move the model to 'cuda'")
@@ -54,17 +55,14 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
     except (TypeError, RuntimeError):          # (Adagrad has neither switch: its step stays outside the graph)
         optimizer = opt_cls(model.parameters(), **kw)
     capturable = bool(optimizer.defaults.get("capturable", False))
-    in_graph = capturable and reducer is None      # with a reducer the collective sits between backward and step
+    in_graph = capturable      # the whole iteration -- backward, gradient all-reduce (if any), optimizer step -- is one graph
     gen = torch.Generator(device=dev).manual_seed(seed)
     model.train()
     model.engine = "resident"
     ds.new_epoch(gen)
     # the gather of the next permutation slice is captured in front of the step: a replay = next batch + iteration
     step = CapturedStep(model, ds.static, training_cfg.loss_fn, optimizer=optimizer if in_graph else None,
-                        pre=ds.gather_next)
-    opt_graph = None
-    if reducer is not None and capturable:
-        opt_graph = _capture_optimizer_step(model, optimizer, step)
+                        pre=ds.gather_next, reducer=reducer if in_graph else None)
     steps, tail = G // B, G % B
     C = ds.C
     loss_log = torch.zeros(steps + (1 if tail else 0), dtype=torch.float32, device=dev)
@@ -79,11 +77,9 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
             step.bind_grads()                  # (the eager tail of the previous epoch re-pointed p.grad)
         for i in range(steps):
             step.replay()
-            if reducer is not None:
+            if reducer is not None and not in_graph:
                 reducer.reduce(float(B), float(B * reducer.world_size))
-            if opt_graph is not None:
-                opt_graph.replay()
-            elif not in_graph:
+            if not in_graph:
                 optimizer.step()
             loss_log[i].copy_(step.loss)
             if metric_fn:
@@ -130,31 +126,3 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
                         return history
     ds.check()
     return history
-
-
-def _capture_optimizer_step(model, optimizer, step: CapturedStep) -> torch.cuda.CUDAGraph:
-    """``optimizer.step()`` on the captured backward's gradient buffers as a graph of its own (a fused capturable
-    optimizer: one launch).  Parameters and optimizer state are put back in place after the warm-up steps."""
-    from torch import Tensor
-    step.bind_grads()
-    snap_p = [p.detach().clone() for p in model.parameters()]
-    snap_s = {id(p): {k: v.clone() for k, v in st.items() if isinstance(v, Tensor)} for p, st in optimizer.state.items()}
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            optimizer.step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        optimizer.step()
-    with torch.no_grad():
-        for p, s0 in zip(model.parameters(), snap_p):
-            p.copy_(s0)
-        for p, st in optimizer.state.items():
-            for k, v in st.items():
-                if isinstance(v, Tensor):
-                    old = snap_s.get(id(p), {}).get(k)
-                    v.copy_(old) if old is not None else v.zero_()
-    return g

@@ -266,6 +266,10 @@ int hscn_build_hetero_emit(const int32_t* U, const int64_t* vptr /*[B+1]*/, cons
  * zero-filled by the caller's stream order; adj[row_e*n + col_e] += 1. */
 int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t num_edges, int64_t n,
                       float* adj /*[n,n]*/, void* stream);
+/* the same for a block-diagonal batch of B graphs with n nodes each: adj [B,n,n] (zero on entry); what
+ * to_dense_adj(edge_index, batch) gives for equally sized graphs -- the input of the dense MinCUT route */
+int hscn_to_dense_adj_batched(const int64_t* row, const int64_t* col, int64_t E, int64_t B, int64_t n, float* adj,
+                              void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Collate on the device (reference: the PyG DataLoader collates HeteroData on the host for every step,

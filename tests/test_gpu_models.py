@@ -175,3 +175,55 @@ def test_hetero_container_batch_through_model():
         pred = model(batch.x_dict, batch.edge_index_dict, batch)
         assert pred.shape == (4, 10) and batch["local"].y.shape == (4, 10)
         pred.sum().backward()
+
+
+@pytest.mark.parametrize("route,K", [("dense", 64), ("auto", 64), ("dense", 16)])
+def test_scn_dense_mfma_route_matches_oracle_through_the_model(route, K):
+    """BASELINE.json configs[3]: ``SCN(..., mincut_route="dense")`` runs the reference's literal sequence
+    to_dense_adj -> dense_mincut_pool (model/hscn.py:61-63) with the contractions on the matrix cores.  Through the
+    MODEL, against the oracle (which is that sequence in plain torch): assignments, both losses, the returned dense
+    adjacency, every parameter gradient; cluster ids equal on every node whose top-2 margin exceeds 1e-5.  Then a
+    batch of equally sized graphs == the mean over single-graph calls."""
+    from graph_hscn.loader.synthetic import SHAPES, make_graph
+    from graph_hscn.model.hscn import SCN
+    from graph_hscn.nn import gcn_norm
+    torch.manual_seed(K)
+    rng = np.random.default_rng(K)
+    graphs = [make_graph(rng, SHAPES["pascalvoc_sp"], n=nn) for nn in (479, 401, 479, 479)]
+    F = graphs[0].x.size(1)
+    om = OM.SCN([16], "elu", F, K)
+    pm = SCN([16], "elu", F, K, mincut_route=route).to(DEV)
+    pm.load_state_dict(om.state_dict())
+    assert not pm.resident_ok(graphs[0])
+    singles = []
+    for g in graphs[:2]:
+        om.zero_grad(); pm.zero_grad()
+        S_o, mc_o, o_o, adj_o, _, _ = OM.scn_step_single_graph(om, g.x, g.edge_index)
+        (mc_o + o_o).backward()
+        ei, ew = gcn_norm(g.edge_index.to(DEV), None, g.num_nodes, add_self_loops=True)
+        S_d, mc_d, o_d, adj_d = pm(g.x.to(DEV).float(), ei, ew)
+        assert pm.last_route == "dense"
+        (mc_d + o_d).backward()
+        assert close(S_d, S_o)
+        assert abs(mc_d.item() - mc_o.item()) < ATOL and abs(o_d.item() - o_o.item()) < ATOL
+        assert torch.equal(adj_d.cpu(), adj_o)
+        top = S_o.topk(2, 1).values
+        sure = (top[:, 0] - top[:, 1]) > 1e-5
+        assert torch.equal(S_d.max(1)[1].cpu()[sure], S_o.max(1)[1][sure])
+        for (n_, po), (_, pp) in zip(om.named_parameters(), pm.named_parameters()):
+            assert close(pp.grad, po.grad, atol=1e-4, rtol=2e-3), n_
+    # equally sized graphs as one [B,n,n] batch through forward_graphs: losses = mean over the graphs
+    from graph_hscn.data import Batch
+    same = [graphs[0], graphs[2], graphs[3]]
+    with torch.no_grad():
+        for g in same:
+            ei, ew = gcn_norm(g.edge_index.to(DEV), None, g.num_nodes, add_self_loops=True)
+            S1, mc1, o1, _ = pm(g.x.to(DEV).float(), ei, ew)
+            singles.append((S1, float(mc1), float(o1)))
+        Sb, mcb, ob = pm.forward_graphs(Batch.from_data_list(same).to(DEV))
+    assert pm.last_route == "dense" and pm.last_engine == "layered"
+    assert close(Sb, torch.cat([s[0] for s in singles]), atol=1e-6)
+    assert abs(float(mcb) - np.mean([s[1] for s in singles])) < 1e-6
+    assert abs(float(ob) - np.mean([s[2] for s in singles])) < 1e-6
+    with pytest.raises(ValueError):
+        pm.forward_graphs(Batch.from_data_list(graphs[:2]).to(DEV))        # 479 and 401 nodes: no common n
