@@ -102,6 +102,53 @@ __global__ void __launch_bounds__(CT) k_collate_gather(const hscn_hetero_dataset
   }
 }
 
+// structure slices (include/hscn.h: hscn_structure; graph-local ids, so they are copied as they are) of the graphs
+// ids[0..B) into batch-level arrays: grid = (B, 4), part 0: ll by target + degree norm, 1: ll by source, 2: lv, 3: vv
+__global__ void __launch_bounds__(CT) k_collate_structure(const hscn_hetero_dataset D, const hscn_structure S,
+                                                          const int64_t* __restrict__ ids, int B,
+                                                          const hscn_hetero_batch_out O, const hscn_structure T,
+                                                          int32_t* __restrict__ flag, const int32_t* __restrict__ cursor) {
+  __shared__ long long red[CT / 64];
+  const int j = blockIdx.x, part = blockIdx.y;
+  if (cursor) ids += (int64_t)cursor[0] * B;
+  const int64_t g = ids[j];
+  if (g < 0 || g >= D.G) {
+    if (threadIdx.x == 0 && flag) atomicOr(flag, 8);
+    return;
+  }
+  long long on = 0, n = 0, ov = 0, nv = 0, oe = 0, ne = 0;
+  if (part <= 1) slot_range(D.nptr, ids, j, red, on, n);
+  if (part >= 2) slot_range(D.vptr, ids, j, red, ov, nv);
+  const int r = part <= 1 ? 0 : (part == 2 ? 2 : 1);          // relation order of the dataset: ll, vv, lv
+  slot_range(D.eptr[r], ids, j, red, oe, ne);
+  if (on + n > O.ncap || ov + nv > O.vcap || oe + ne > O.ecap[r]) {
+    if (threadIdx.x == 0 && flag) atomicOr(flag, 8);
+    return;
+  }
+  const int64_t e0 = D.eptr[r][g];
+  if (part <= 1) {
+    const int64_t rs = D.nptr[g] + g;
+    const int32_t* rp = (part == 0 ? S.ll_rowptr_d : S.ll_rowptr_s) + rs;
+    const int32_t* cl = (part == 0 ? S.ll_col_d : S.ll_col_s) + e0;
+    int32_t* rpo = (part == 0 ? T.ll_rowptr_d : T.ll_rowptr_s) + on + j;
+    int32_t* clo = (part == 0 ? T.ll_col_d : T.ll_col_s) + oe;
+    for (long long i = threadIdx.x; i <= n; i += CT) rpo[i] = rp[i];
+    for (long long i = threadIdx.x; i < ne; i += CT) clo[i] = cl[i];
+    if (part == 0)
+      for (long long i = threadIdx.x; i < n; i += CT) T.ll_dinv[on + i] = S.ll_dinv[D.nptr[g] + i];
+  } else {
+    const int64_t rs = D.vptr[g] + g;
+    const int32_t* rp = (part == 2 ? S.lv_rowptr : S.vv_rowptr) + rs;
+    const int32_t* cl = (part == 2 ? S.lv_col : S.vv_col) + e0;
+    int32_t* rpo = (part == 2 ? T.lv_rowptr : T.vv_rowptr) + ov + j;
+    int32_t* clo = (part == 2 ? T.lv_col : T.vv_col) + oe;
+    for (long long i = threadIdx.x; i <= nv; i += CT) rpo[i] = rp[i];
+    for (long long i = threadIdx.x; i < ne; i += CT) clo[i] = cl[i];
+    if (part == 3)
+      for (long long i = threadIdx.x; i < nv; i += CT) T.vv_dinv[ov + i] = S.vv_dinv[D.vptr[g] + i];
+  }
+}
+
 // after the gather of batch `cursor`: the next replay of the same captured launches takes the next slice.
 // (A launch of its own: letting the gather's last block advance the counter -- sign-off counter, device-scope
 // fence -- was measured at +23 us per step over 768 blocks; this costs ~3.)
@@ -126,5 +173,23 @@ extern "C" int hscn_collate_gather(const hscn_hetero_dataset* ds, const int64_t*
     k_cursor_advance<<<1, 1, 0, hscn_stream(stream_)>>>(cursor);
     HSCN_RETURN_IF_LAUNCH_FAILED();
   }
+  return 0;
+}
+
+extern "C" int hscn_collate_gather_structure(const hscn_hetero_dataset* ds, const hscn_structure* dss, const int64_t* ids,
+                                             int64_t B, const hscn_hetero_batch_out* out, const hscn_structure* outs,
+                                             int32_t* flag, const int32_t* cursor, void* stream_) {
+  if (!ds || !dss || !out || !outs || B < 0 || B > 65535) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (!ids || !ds->nptr || !ds->vptr || ds->G < 1) return HSCN_E_BADARG;
+  for (int r = 0; r < 3; ++r)
+    if (!ds->eptr[r] || out->ecap[r] < 1) return HSCN_E_BADARG;
+  const hscn_structure* both[2] = {dss, outs};
+  for (const hscn_structure* q : both)
+    if (!q->ll_rowptr_d || !q->ll_col_d || !q->ll_rowptr_s || !q->ll_col_s || !q->ll_dinv || !q->lv_rowptr ||
+        !q->lv_col || !q->vv_rowptr || !q->vv_col || !q->vv_dinv)
+      return HSCN_E_BADARG;
+  k_collate_structure<<<dim3((unsigned)B, 4), CT, 0, hscn_stream(stream_)>>>(*ds, *dss, ids, (int)B, *out, *outs, flag, cursor);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

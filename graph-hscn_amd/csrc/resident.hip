@@ -79,6 +79,15 @@ int hscn_resident_fwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                                pred, score, csr_rowptr_t, csr_col_t, dinv_out, flag, job, stream_);
 }
 
+int hscn_resident_structure(const int64_t* ei_ll, int64_t E_ll, const int64_t* ei_vv, int64_t E_vv,
+                            const int64_t* ei_lv, int64_t E_lv, const int32_t* lptr, const int32_t* vptr,
+                            const int32_t* eptr_ll, const int32_t* eptr_vv, const int32_t* eptr_lv, int64_t B,
+                            int max_n, int max_v, int max_ell, int max_evv, const hscn_structure* out,
+                            int32_t* flag, void* stream_) {
+  return impl_resident_structure(ei_ll, E_ll, ei_vv, E_vv, ei_lv, E_lv, lptr, vptr, eptr_ll, eptr_vv, eptr_lv, B, max_n,
+                                 max_v, max_ell, max_evv, out, flag, stream_);
+}
+
 int hscn_resident_train_step_supported(int F, int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv) {
   return step_supported(F, H, L, C, max_n, max_ell, max_v, max_evv);
 }
@@ -88,10 +97,10 @@ int hscn_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t
                              const void* const* layer_params_host, const float* W1, const float* b1, const float* W2,
                              const float* b2, int max_n, int max_ell, const float* target, int loss_kind, float* pred,
                              float* score, float* partials, float* grads, float* acts, uint32_t* sync, int32_t* flag,
-                             const hscn_virtual_job* job, void* stream_) {
+                             const hscn_virtual_job* job, const hscn_structure* structure, void* stream_) {
   return impl_resident_train_step<float>(x_local, ei_ll, E_ll, lptr, eptr_ll, N, B, F, H, L, C, head_act,
                                          layer_params_host, W1, b1, W2, b2, max_n, max_ell, target, loss_kind, pred,
-                                         score, partials, grads, acts, sync, flag, job, stream_);
+                                         score, partials, grads, acts, sync, flag, job, structure, stream_);
 }
 
 }  // extern "C"

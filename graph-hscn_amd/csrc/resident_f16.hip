@@ -74,11 +74,11 @@ int hscn_resident_train_step_f16(const hscn_half* x_local, const int64_t* ei_ll,
                                  const float* W2, const float* b2, int max_n, int max_ell, const float* target,
                                  int loss_kind, float* pred, float* score, float* partials, float* grads,
                                  hscn_half* acts, uint32_t* sync, int32_t* flag, const hscn_virtual_job* job,
-                                 void* stream_) {
+                                 const hscn_structure* structure, void* stream_) {
   return impl_resident_train_step<half_t>((const float*)x_local, ei_ll, E_ll, lptr, eptr_ll, N, B, F, H, L, C,
                                           head_act, layer_params_host, W1, b1, W2, b2, max_n, max_ell, target,
                                           loss_kind, pred, score, partials, grads, (float*)acts, sync, flag, job,
-                                          stream_);
+                                          structure, stream_);
 }
 
 }  // extern "C"

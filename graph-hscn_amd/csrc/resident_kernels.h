@@ -79,6 +79,11 @@ struct FwdArgs {
   // local workgroup of the same launch; ready[g] counts them (epoch * 8 + count), NULL: they come from an earlier launch
   const uint32_t* ready;
   const uint32_t* epoch;
+  // structure_build = "dataset-resident": the CSRs of the virtual relations and the virtual degree norm of every
+  // graph come from HBM (include/hscn.h: hscn_structure; built once per dataset, gathered with the batch) instead
+  // of being rebuilt from the COO slices every step.  Virtual-only workgroups from layer 0 (the one-launch step).
+  const int32_t *pre_rp_lv, *pre_col_lv, *pre_rp_vv, *pre_col_vv;
+  const float* pre_dinv_v;
   int db;        // 1: two weight buffers in LDS (the next layer's weights land under this layer's math)
   int exp_dinv;  // 1: this launch exports the ll degree norm (the workgroup that builds ll keyed by target has it)
   float slope;
@@ -669,7 +674,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   STAMP(0);
   WStage<H, RT> ws;
   const bool resume = MODE == 4 || (MODE == 0 && vonly && A.l_begin > 0);
-  if (!resume) {
+  const bool prestruct = vonly && A.pre_rp_lv != nullptr && A.l_begin == 0;
+  if (!resume && !prestruct) {
   constexpr int EPT = 2;   // edges per thread held in registers (covers RT*EPT edges per relation)
   constexpr int XPT = 8;   // feature words per thread held in registers
   // raw 64-bit ids first (clamped addresses, no arithmetic on the results yet): all requests of the
@@ -875,6 +881,29 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     if (A.exp_dinv)
       for (int i = threadIdx.x; i < n; i += RT) A.dinv_out[(size_t)n0 + i] = dinv[i];
   }
+  } else if (prestruct) {
+    // ---- virtual branch on dataset-resident structure: nothing is staged or built, the CSRs of the two virtual
+    // relations and the degree norm are loaded (graph-local ids, exactly what the builds below would produce)
+    ws.fetch(A.layer[0], false, true, F);
+    for (int idx = threadIdx.x; idx < n * H; idx += RT) {
+      const int r = idx / H, k = idx - r * H;
+      xa[idx] = k < F ? ldf(xl_g, (size_t)(n0 + r) * F + k) : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < nv * H; idx += RT) {
+      const int r = idx / H, k = idx - r * H;
+      xva[idx] = k < F ? ldf(xv_g, (size_t)(v0 + r) * F + k) : 0.f;
+    }
+    for (int i = threadIdx.x; i <= nv; i += RT) {
+      rowptr_lv[i] = A.pre_rp_lv[(size_t)v0 + g + i];
+      rowptr_vv[i] = A.pre_rp_vv[(size_t)v0 + g + i];
+    }
+    for (int i = threadIdx.x; i < nel; i += RT) col_lv[i] = A.pre_col_lv[(size_t)el0 + i];
+    for (int i = threadIdx.x; i < nev; i += RT) col_vv[i] = A.pre_col_vv[(size_t)ev0 + i];
+    for (int i = threadIdx.x; i < nv; i += RT) dinv_v[i] = A.pre_dinv_v[(size_t)v0 + i];
+    ws.store(wt);
+    lds_barrier();
+    if (wave == 0) build_chunk_table();
+    lds_barrier();
   } else {
     // ---- resumed virtual branch: the structure and the virtual features come from the state the
     // first part of this step exported, the local rows from the previous layer's activations
@@ -1786,6 +1815,96 @@ __global__ void __launch_bounds__(256) k_ll_csr_t(const FwdArgs A) {
   for (int p = threadIdx.x; p < cnt_t; p += 256) A.csr_col_t[(size_t)e0 + p] = col_t[p];
 }
 
+// ---- structure of every graph of a block-diagonal hetero batch (or of a whole dataset laid out as one), built once:
+// the four stable CSRs (graph-local int32 ids) and the two degree norms that the resident launches otherwise rebuild
+// from the COO slices in LDS every step -- with the SAME device functions, so a step that loads them computes bit
+// for bit what a step that builds them computes.  One 256-thread workgroup per graph, relations one after another.
+struct StructArgs {
+  const int64_t *ll_src, *ll_dst, *vv_src, *vv_dst, *lv_src, *lv_dst;
+  const int32_t *lptr, *vptr, *eptr_ll, *eptr_vv, *eptr_lv;
+  hscn_structure out;
+  int32_t* flag;
+  int max_n, max_v, max_ell, max_evv;
+};
+inline size_t struct_lds_words(int max_n, int max_v, int max_ell, int max_evv) {
+  const size_t me = (size_t)(max_ell > max_evv ? max_ell : max_evv) > (size_t)max_n ? (size_t)(max_ell > max_evv ? max_ell : max_evv) : (size_t)max_n;
+  const size_t mr = (size_t)(max_n > max_v ? max_n : max_v) + 1;
+  const size_t nchunk = ((size_t)max_n + 63) / 64;
+  size_t cnt = (size_t)max_v * nchunk;
+  if (cnt < mr) cnt = mr;
+  return 4 * me + 2 * mr + cnt + 64;
+}
+__global__ void __launch_bounds__(256) k_structure(const StructArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  int* ib = reinterpret_cast<int*>(smem);
+  const int g = blockIdx.x;
+  const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
+  const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
+  const int e0 = A.eptr_ll[g], ne = A.eptr_ll[g + 1] - e0;
+  const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
+  const int el0 = A.eptr_lv[g], nel = A.eptr_lv[g + 1] - el0;
+  if ((n > A.max_n) | (nv > A.max_v) | (ne > A.max_ell) | (nev > A.max_evv) | (nel > A.max_n) | (n < 0) | (nv < 0)) {
+    if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    return;
+  }
+  const size_t me = (size_t)(A.max_ell > A.max_evv ? A.max_ell : A.max_evv) > (size_t)A.max_n
+                        ? (size_t)(A.max_ell > A.max_evv ? A.max_ell : A.max_evv) : (size_t)A.max_n;
+  const size_t mr = (size_t)(A.max_n > A.max_v ? A.max_n : A.max_v) + 1;
+  int* ek = ib;
+  int* eo = ek + me;
+  int* colb = eo + me;
+  int* tmp = colb + me;
+  int* rowptr = tmp + me;
+  int* cursor = rowptr + mr;            // also the multisplit's counters
+  const size_t nchunk = ((size_t)A.max_n + 63) / 64;
+  size_t cnt = (size_t)A.max_v * nchunk;
+  if (cnt < mr) cnt = mr;
+  int* wsum = cursor + cnt;
+  const Grp ALL{(int)threadIdx.x, 256, (int)threadIdx.x >> 6, 4};
+  bool bad = false;
+  auto stage = [&](const int64_t* kp, const int64_t* op, int base, int cntE, int kb, int ob, int nk, int no) {
+    for (int e = threadIdx.x; e < cntE; e += 256) {
+      int k = (int)(kp[base + e] - kb), o = (int)(op[base + e] - ob);
+      if (k < 0 || k >= nk || o < 0 || o >= no) { bad = true; k = -1; o = -1; }
+      ek[e] = k; eo[e] = o;
+    }
+  };
+  auto put = [&](int32_t* rp_out, int32_t* col_out, size_t rbase, size_t cbase, int rows) {
+    for (int i = threadIdx.x; i <= rows; i += 256) rp_out[rbase + i] = rowptr[i];
+    const int c = rowptr[rows];
+    for (int p = threadIdx.x; p < c; p += 256) col_out[cbase + p] = colb[p];
+  };
+  // local -> local keyed by target (+ the degree norm), then keyed by source
+  stage(A.ll_dst, A.ll_src, e0, ne, n0, n0, n, n);
+  lds_barrier();
+  build_csr_lds(ek, eo, ne, n, rowptr, colb, cursor, tmp, ALL, true);
+  put(A.out.ll_rowptr_d, A.out.ll_col_d, (size_t)n0 + g, (size_t)e0, n);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int d = rowptr[i + 1] - rowptr[i];
+    A.out.ll_dinv[(size_t)n0 + i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
+  }
+  lds_barrier();
+  build_csr_lds(eo, ek, ne, n, rowptr, colb, cursor, tmp, ALL, true);
+  put(A.out.ll_rowptr_s, A.out.ll_col_s, (size_t)n0 + g, (size_t)e0, n);
+  lds_barrier();
+  // virtual -> virtual keyed by target (+ its degree norm)
+  stage(A.vv_dst, A.vv_src, ev0, nev, v0, v0, nv, nv);
+  lds_barrier();
+  build_csr_lds(ek, eo, nev, nv, rowptr, colb, cursor, tmp, ALL, true);
+  put(A.out.vv_rowptr, A.out.vv_col, (size_t)v0 + g, (size_t)ev0, nv);
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    const int d = rowptr[i + 1] - rowptr[i];
+    A.out.vv_dinv[(size_t)v0 + i] = d > 0 ? 1.0f / sqrtf((float)d) : 0.f;
+  }
+  lds_barrier();
+  // local -> virtual keyed by target (rows are clusters: the multisplit)
+  stage(A.lv_dst, A.lv_src, el0, nel, v0, n0, nv, n);
+  lds_barrier();
+  build_csr_multisplit_lds(ek, eo, nel, nv, rowptr, colb, cursor, tmp, wsum, ALL);
+  put(A.out.lv_rowptr, A.out.lv_col, (size_t)v0 + g, (size_t)el0, nv);
+  if (bad && A.flag) atomicOr(A.flag, 2);
+}
+
 template <int H, typename TS>
 int launch_fwd(FwdArgs& A, int64_t B, hipStream_t st) {
   // preference order: concurrent wave groups + CSR export, then dropping the third n x H buffer,
@@ -1901,6 +2020,7 @@ int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, cons
   A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0; A.exp_dinv = 0; A.db = 0;
   A.l_begin = 0; A.l_end = L;
   A.ready = nullptr; A.epoch = nullptr;
+  A.pre_rp_lv = A.pre_col_lv = A.pre_rp_vv = A.pre_col_vv = nullptr; A.pre_dinv_v = nullptr;
   A.vs_rowptr_lv = A.vs_col_lv = A.vs_rowptr_vv = A.vs_col_vv = nullptr;
   A.vs_dinv_v = A.vs_xv = nullptr;
   return 0;
@@ -2160,8 +2280,13 @@ int impl_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t
                              const void* const* layer_params_host, const float* W1, const float* b1, const float* W2,
                              const float* b2, int max_n, int max_ell, const float* target, int loss_kind, float* pred,
                              float* score, float* partials, float* grads, float* acts, uint32_t* sync, int32_t* flag,
-                             const hscn_virtual_job* job, void* stream_) {
+                             const hscn_virtual_job* job, const hscn_structure* pre, void* stream_) {
   if (B < 0 || N < 0) return HSCN_E_BADARG;
+  if (pre && (!pre->ll_rowptr_d || !pre->ll_rowptr_s || !pre->ll_dinv || (E_ll > 0 && (!pre->ll_col_d || !pre->ll_col_s))))
+    return HSCN_E_BADARG;
+  if (pre && job && (!pre->lv_rowptr || !pre->vv_rowptr || !pre->vv_dinv || (job->E_lv > 0 && !pre->lv_col) ||
+                     (job->E_vv > 0 && !pre->vv_col)))
+    return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!(H == 16 || H == 32) || F < 1 || F > H || L < 1 || L > MAXL || C < 1 || C > 4096 || max_n < 0 || max_ell < 0)
     return HSCN_E_UNSUPPORTED;
@@ -2181,6 +2306,9 @@ int impl_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t
   S.partials = partials; S.flag = flag; S.N = N; S.F = F; S.L = L; S.C = C; S.head_act = head_act;
   S.max_n = max_n; S.max_ell = max_ell; S.Pn = (int)hscn_resident_param_count(F, H, L, C); S.P = S.Pn + 1;
   S.loss_kind = loss_kind; S.inv_count = 1.0f / (float)(B * (int64_t)C); S.B = (int)B;
+  S.pre_rp_d = pre ? pre->ll_rowptr_d : nullptr; S.pre_col_d = pre ? pre->ll_col_d : nullptr;
+  S.pre_rp_s = pre ? pre->ll_rowptr_s : nullptr; S.pre_col_s = pre ? pre->ll_col_s : nullptr;
+  S.pre_dinv = pre ? pre->ll_dinv : nullptr;
   S.acts = (acts && L >= 2) ? acts : nullptr;
   S.ready = (job && S.acts) ? sync + 32 : nullptr;
   S.epoch = sync;
@@ -2193,12 +2321,44 @@ int impl_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t
                                 nullptr, nullptr, nullptr, flag))
       return rc1;
     V.ready = S.ready; V.epoch = sync;
+    if (pre) {
+      V.pre_rp_lv = pre->lv_rowptr; V.pre_col_lv = pre->lv_col; V.pre_rp_vv = pre->vv_rowptr;
+      V.pre_col_vv = pre->vv_col; V.pre_dinv_v = pre->vv_dinv;
+    }
   }
   hipStream_t st = hscn_stream(stream_);
   int rc = H == 16 ? launch_step<16, TS>(S, job ? &V : nullptr, st) : launch_step<32, TS>(S, job ? &V : nullptr, st);
   if (rc) return rc;
   k_param_reduce<<<hscn_blocks(S.P, 32), 256, 0, st>>>(partials, grads, (int)B, S.P, S.Pn, S.inv_count,
                                                        S.ready ? sync : nullptr);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+inline int impl_resident_structure(const int64_t* ei_ll, int64_t E_ll, const int64_t* ei_vv, int64_t E_vv,
+                                   const int64_t* ei_lv, int64_t E_lv, const int32_t* lptr, const int32_t* vptr,
+                                   const int32_t* eptr_ll, const int32_t* eptr_vv, const int32_t* eptr_lv, int64_t B,
+                                   int max_n, int max_v, int max_ell, int max_evv, const hscn_structure* out,
+                                   int32_t* flag, void* stream_) {
+  if (B < 0 || !out || max_n < 0 || max_v < 0 || max_ell < 0 || max_evv < 0) return HSCN_E_BADARG;
+  if (B == 0) return 0;
+  if (!lptr || !vptr || !eptr_ll || !eptr_vv || !eptr_lv || (E_ll > 0 && !ei_ll) || (E_vv > 0 && !ei_vv) ||
+      (E_lv > 0 && !ei_lv))
+    return HSCN_E_BADARG;
+  if (!out->ll_rowptr_d || !out->ll_rowptr_s || !out->ll_dinv || !out->lv_rowptr || !out->vv_rowptr || !out->vv_dinv ||
+      (E_ll > 0 && (!out->ll_col_d || !out->ll_col_s)) || (E_lv > 0 && !out->lv_col) || (E_vv > 0 && !out->vv_col))
+    return HSCN_E_BADARG;
+  StructArgs A;
+  A.ll_src = ei_ll; A.ll_dst = ei_ll ? ei_ll + E_ll : nullptr;
+  A.vv_src = ei_vv; A.vv_dst = ei_vv ? ei_vv + E_vv : nullptr;
+  A.lv_src = ei_lv; A.lv_dst = ei_lv ? ei_lv + E_lv : nullptr;
+  A.lptr = lptr; A.vptr = vptr; A.eptr_ll = eptr_ll; A.eptr_vv = eptr_vv; A.eptr_lv = eptr_lv;
+  A.out = *out; A.flag = flag; A.max_n = max_n; A.max_v = max_v; A.max_ell = max_ell; A.max_evv = max_evv;
+  const size_t lds = struct_lds_words(max_n, max_v, max_ell, max_evv) * 4;
+  if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_structure, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k_structure<<<(unsigned)B, 256, lds, hscn_stream(stream_)>>>(A);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -43,6 +43,10 @@ struct StepArgs {
   float* acts;           // TS [L-1][N][H]: a_1 .. a_{L-1} for the virtual workgroups (NULL: not published)
   uint32_t* ready;       // [B] per-graph publish counters (epoch * 8 + number of published activations)
   const uint32_t* epoch; // device word, advanced once per step by k_param_reduce
+  // structure_build = "dataset-resident" (include/hscn.h: hscn_structure): both CSRs of the local->local relation and
+  // the degree norm come from HBM instead of being rebuilt from the COO slice (NULL: build)
+  const int32_t *pre_rp_d, *pre_col_d, *pre_rp_s, *pre_col_s;
+  const float* pre_dinv;
   int32_t* flag;
   int64_t N;
   int F, L, C, head_act, max_n, max_ell, P, Pn, loss_kind;
@@ -172,12 +176,27 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   long long rld[EPT], rls[EPT];
   float xr[XPT];
   const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  const bool pre = A.pre_rp_d != nullptr;      // dataset-resident structure: loaded, not built
+  int prd[EPT], prs[EPT], pcd[EPT], pcs[EPT];
+  float pdv[EPT];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     const int e = threadIdx.x + i * RT;
     const bool o1 = e < ne && A.ll_dst;
-    rld[i] = 0; rls[i] = 0;
-    if (wbase + i * RT < ne) { rld[i] = pld[o1 ? e0 + e : 0]; rls[i] = pls[o1 ? e0 + e : 0]; }
+    rld[i] = 0; rls[i] = 0; prd[i] = 0; prs[i] = 0; pcd[i] = 0; pcs[i] = 0; pdv[i] = 0.f;
+    if (!pre) {
+      if (wbase + i * RT < ne) { rld[i] = pld[o1 ? e0 + e : 0]; rls[i] = pls[o1 ? e0 + e : 0]; }
+    } else {
+      if (wbase + i * RT <= n) {
+        prd[i] = A.pre_rp_d[(size_t)n0 + g + (e <= n ? e : 0)];
+        prs[i] = A.pre_rp_s[(size_t)n0 + g + (e <= n ? e : 0)];
+        pdv[i] = A.pre_dinv[(size_t)n0 + (e < n ? e : 0)];
+      }
+      if (wbase + i * RT < ne) {
+        pcd[i] = A.pre_col_d[(size_t)e0 + (e < ne ? e : 0)];
+        pcs[i] = A.pre_col_s[(size_t)e0 + (e < ne ? e : 0)];
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
@@ -227,7 +246,24 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   float hw0 = *haddr((int)threadIdx.x < HTT ? (int)threadIdx.x : 0);
   float hw1 = *haddr((int)threadIdx.x + RT < HTT ? (int)threadIdx.x + RT : 0);
   // ---- consume: validate + stage the edges, park features and weights -------------------------------------
-  {
+  if (pre) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * RT;
+      if (e <= n) { rowptr[e] = prd[i]; rowptr_t[e] = prs[i]; }
+      if (e < n) dinv[e] = pdv[i];
+      if (e < ne) { col[e] = pcd[i]; col_t[e] = pcs[i]; }
+    }
+    for (int e = threadIdx.x + EPT * RT; e <= n; e += RT) {
+      rowptr[e] = A.pre_rp_d[(size_t)n0 + g + e];
+      rowptr_t[e] = A.pre_rp_s[(size_t)n0 + g + e];
+      if (e < n) dinv[e] = A.pre_dinv[(size_t)n0 + e];
+    }
+    for (int e = threadIdx.x + EPT * RT; e < ne; e += RT) {
+      col[e] = A.pre_col_d[(size_t)e0 + e];
+      col_t[e] = A.pre_col_s[(size_t)e0 + e];
+    }
+  } else {
     int *ek = ib + Y.ek, *eo = ib + Y.eo;
     bool bad = false;
 #pragma unroll
@@ -277,7 +313,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   lds_barrier();
   STAMP(1);
   // ---- structure: the two CSRs of the local->local relation side by side (four barriers each) -------------
-  {
+  if (!pre) {
     const int NA = NW / 2 > 0 ? NW / 2 : 1;
     const bool inB = wave >= NA && NW > 1;
     if (NW == 1) {

@@ -108,6 +108,57 @@ class _VirtualJob(ctypes.Structure):
                 ("st_dinv_v", ctypes.c_void_p), ("st_xv", ctypes.c_void_p)]
 
 
+class _Structure(ctypes.Structure):
+    """include/hscn.h: hscn_structure."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("ll_rowptr_d", "ll_col_d", "ll_rowptr_s", "ll_col_s", "ll_dinv",
+                                               "lv_rowptr", "lv_col", "vv_rowptr", "vv_col", "vv_dinv")]
+
+
+class BatchStructure:
+    """The epoch-invariant structure of every graph of a block-diagonal hetero batch (or of a dataset laid out as
+    one): four stable CSRs with graph-local int32 ids and two degree norms (include/hscn.h: hscn_structure).  The
+    resident launches rebuild these in LDS every step unless they are handed one of these (structure_build =
+    "dataset-resident"); results are bit-identical either way."""
+
+    FIELDS = ("ll_rowptr_d", "ll_col_d", "ll_rowptr_s", "ll_col_s", "ll_dinv", "lv_rowptr", "lv_col", "vv_rowptr",
+              "vv_col", "vv_dinv")
+
+    def __init__(self, device, N: int, V: int, B: int, E_ll: int, E_lv: int, E_vv: int):
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.t = {"ll_rowptr_d": torch.zeros(N + B, **i32), "ll_col_d": torch.zeros(max(E_ll, 1), **i32),
+                  "ll_rowptr_s": torch.zeros(N + B, **i32), "ll_col_s": torch.zeros(max(E_ll, 1), **i32),
+                  "ll_dinv": torch.zeros(max(N, 1), **f32),
+                  "lv_rowptr": torch.zeros(V + B, **i32), "lv_col": torch.zeros(max(E_lv, 1), **i32),
+                  "vv_rowptr": torch.zeros(V + B, **i32), "vv_col": torch.zeros(max(E_vv, 1), **i32),
+                  "vv_dinv": torch.zeros(max(V, 1), **f32)}
+        self.c = _Structure(*[ptr(self.t[k]) for k in self.FIELDS])
+
+    @property
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+
+def build_structure(batch, meta: Optional["ResidentMeta"] = None) -> BatchStructure:
+    """``hscn_resident_structure`` on a ``graph_hscn.data.HeteroBatch`` that lives on the device: one launch, one
+    workgroup per graph.  The result is attached as ``batch.structure``."""
+    dev = batch["local"].x.device
+    meta = meta or meta_from_batch(batch, dev)
+    if meta is None:
+        raise TypeError("build_structure needs a graph_hscn HeteroBatch on the device")
+    ei = {k: batch[k].edge_index.contiguous() for k in (LL, VV, LV)}
+    N, V, B = int(batch["local"].x.size(0)), int(batch["virtual"].x.size(0)), meta.num_graphs
+    st = BatchStructure(dev, N, V, B, ei[LL].size(1), ei[LV].size(1), ei[VV].size(1))
+    call("hscn_resident_structure", ptr(ei[LL]), ei[LL].size(1), ptr(ei[VV]), ei[VV].size(1), ptr(ei[LV]),
+         ei[LV].size(1), ptr(meta.lptr), ptr(meta.vptr), ptr(meta.eptr_ll), ptr(meta.eptr_vv), ptr(meta.eptr_lv), B,
+         meta.max_n, meta.max_v, meta.max_ell, meta.max_evv, ctypes.byref(st.c), ptr(meta.flag), stream())
+    try:
+        batch.structure = st
+    except AttributeError:
+        pass
+    return st
+
+
 class _LossTail(ctypes.Structure):
     """include/hscn.h: hscn_loss_tail."""
     _fields_ = [("pred", ctypes.c_void_p), ("target", ctypes.c_void_p), ("kind", ctypes.c_int32)]

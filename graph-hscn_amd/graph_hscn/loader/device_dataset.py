@@ -49,7 +49,11 @@ class DeviceHeteroDataset:
     """``graphs``: the list ``generate_hetero_data`` returns (or any sequence of ``HeteroData`` with the
     local / virtual node types and the ll / vv / lv relations).  ``batch_size`` graphs per step."""
 
-    def __init__(self, graphs: Sequence[HeteroData], device, batch_size: int):
+    def __init__(self, graphs: Sequence[HeteroData], device, batch_size: int, resident_structure: bool = False):
+        """``resident_structure``: also keep every graph's CSRs (ll by target and by source, lv, vv; graph-local
+        ids) and degree norms in HBM -- built ONCE here by ``hscn_resident_structure`` over the dataset laid out as
+        one batch -- and gather them with every batch (``static.batch.structure``), so that a step can load its
+        structure instead of rebuilding it (``CapturedStep(..., structure="batch")``).  +~40 % dataset bytes."""
         if not graphs:
             raise ValueError("empty dataset")
         self.device = torch.device(device)
@@ -86,6 +90,14 @@ class DeviceHeteroDataset:
             {"local": int(sizes["local"].max()), "virtual": int(sizes["virtual"].max())},
             {et: int(esizes[et].max()) if esizes[et].numel() else 0 for et in _RELS}, self.F, self.C)
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.structure = None
+        if resident_structure:
+            from ..engine import BatchStructure, build_structure
+            self.structure = build_structure(whole.to(dev))              # one launch over all G graphs
+            st0 = self.static
+            self._out_structure = BatchStructure(dev, st0.N, st0.V, B, st0.E[LL], st0.E[LV], st0.E[VV])
+            st0.batch.structure = self._out_structure
+            torch.cuda.synchronize(dev)                                   # (the int64 COO copy of `whole` may go now)
         self._perm: Optional[Tensor] = None
         self._cursor: Optional[Tensor] = None
         t = self._t
@@ -112,7 +124,12 @@ class DeviceHeteroDataset:
         kept).  Asynchronous on the current stream, capturable; returns ``self.static.batch``."""
         if ids.dtype != torch.int64 or ids.device != self.device or ids.numel() != self.batch_size:
             raise ValueError(f"ids must be int64 [{self.batch_size}] on {self.device}")
-        _hip.call("hscn_collate_gather", ctypes.byref(self._ds), _hip.ptr(ids.contiguous()), self.batch_size,
+        ids = ids.contiguous()
+        if self.structure is not None:
+            _hip.call("hscn_collate_gather_structure", ctypes.byref(self._ds), ctypes.byref(self.structure.c),
+                      _hip.ptr(ids), self.batch_size, ctypes.byref(self._out), ctypes.byref(self._out_structure.c),
+                      _hip.ptr(self.flag), None, _hip.stream())
+        _hip.call("hscn_collate_gather", ctypes.byref(self._ds), _hip.ptr(ids), self.batch_size,
                   ctypes.byref(self._out), _hip.ptr(self.flag), None, _hip.stream())
         return self.static.batch
 
@@ -135,6 +152,10 @@ class DeviceHeteroDataset:
         training step (``CapturedStep(..., pre=ds.gather_next)``) -- a replay is then "next batch + iteration"."""
         if self._perm is None:
             raise RuntimeError("call new_epoch() first")
+        if self.structure is not None:        # (before the gather proper: that call advances the cursor)
+            _hip.call("hscn_collate_gather_structure", ctypes.byref(self._ds), ctypes.byref(self.structure.c),
+                      _hip.ptr(self._perm), self.batch_size, ctypes.byref(self._out),
+                      ctypes.byref(self._out_structure.c), _hip.ptr(self.flag), _hip.ptr(self._cursor), _hip.stream())
         _hip.call("hscn_collate_gather", ctypes.byref(self._ds), _hip.ptr(self._perm), self.batch_size,
                   ctypes.byref(self._out), _hip.ptr(self.flag), _hip.ptr(self._cursor), _hip.stream())
         return self.static.batch

@@ -168,13 +168,15 @@ class CapturedStep:
     cannot reach into it (tests/test_gpu_step.py)."""
 
     def __init__(self, model, static: StaticHeteroBatch, loss_fn: str, warmup: int = 3, optimizer=None, pre=None,
-                 one_launch: Optional[bool] = None, reducer=None):
+                 one_launch: Optional[bool] = None, reducer=None, structure=None):
         """``one_launch``: passed to ``step.ResidentTrainStep`` (None: the one-launch step whenever the batch fits it;
         False: the forward + backward launch pair, whose gradients are bit-identical to the eager autograd path).
         ``reducer``: a ``distributed.FlatGradReducer``; its all-reduce of the flat gradient buffer (RCCL kernels are
         capturable) is captured between the backward and the optimizer step, so one replay per iteration is all a
         rank issues -- no eager collective launch between replays.  Every rank must hold the same number of graphs
         (``static.num_graphs``): the reduction is the mean over ranks.
+        ``structure``: passed to ``step.ResidentTrainStep`` ("batch": the step loads the graphs' CSRs / degree norms
+        that ``DeviceHeteroDataset(resident_structure=True)`` gathers with every batch instead of rebuilding them).
         ``pre``: a callable captured in front of the step that refreshes the static buffers from device-side
         state only (``DeviceHeteroDataset.gather_next``); note that the warm-up iterations and the capture call
         it too (rewind with ``new_epoch`` afterwards).
@@ -195,7 +197,7 @@ class CapturedStep:
         if "y" not in hb["local"]:
             raise ValueError("the static batch carries no targets")
         try:
-            self.step = ResidentTrainStep(model, hb, loss_fn, one_launch=one_launch)
+            self.step = ResidentTrainStep(model, hb, loss_fn, one_launch=one_launch, structure=structure)
         except RuntimeError as e:
             raise RuntimeError("CapturedStep needs the graph-resident engine (the layered operators size their "
                                "work by tensor shapes, which a static-capacity batch does not carry): " + str(e)) from e

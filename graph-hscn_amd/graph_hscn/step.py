@@ -52,11 +52,15 @@ class ResidentTrainStep:
     The batch may be a ``replay.StaticHeteroBatch.batch``: tensor shapes are capacities then, the
     kernels read the real per-graph ranges from the device-side segment tables."""
 
-    def __init__(self, model, batch, loss_fn: str, target: Optional[Tensor] = None, one_launch: Optional[bool] = None):
+    def __init__(self, model, batch, loss_fn: str, target: Optional[Tensor] = None, one_launch: Optional[bool] = None,
+                 structure=None):
         """``one_launch``: None = take the one-launch step (include/hscn.h: hscn_resident_train_step -- forward, loss
         tail and backward of a graph in one workgroup, nothing exported in between) whenever the graphs fit it,
         else the forward + backward launch pair; False = always the pair; True = insist (raises if unsupported).
-        Both routes give bit-identical outputs (tests/test_gpu_step.py)."""
+        ``structure``: None = every step rebuilds the graphs' CSRs and degree norms in LDS from the COO slices
+        (structure_build "per-step"); an ``engine.BatchStructure`` (or "batch" = ``batch.structure``, which
+        ``engine.build_structure`` / ``DeviceHeteroDataset(resident_structure=True)`` attach) = the one-launch step
+        loads them (structure_build "dataset-resident": graph structure is epoch-invariant).  Same results."""
         from .model.hscn import HSCN, _act_name
         if not isinstance(model, HSCN):
             raise TypeError("ResidentTrainStep drives graph_hscn.model.hscn.HSCN")
@@ -130,6 +134,13 @@ class ResidentTrainStep:
             raise RuntimeError("the one-launch step does not take this batch / model (H in {16, 32}, graphs that fit "
                                "its LDS layout, virtual branch on idle CUs only)")
         self.one_launch = bool(one_launch)
+        if structure == "batch":
+            structure = getattr(batch, "structure", None)
+            if structure is None:
+                raise ValueError("the batch carries no structure (engine.build_structure(batch) attaches one)")
+        if structure is not None and not self.one_launch:
+            raise RuntimeError("dataset-resident structure is a mode of the one-launch step")
+        self.structure = structure
         self._sync = torch.zeros(32 + B, dtype=torch.int32, device=dev) if self.one_launch else None
         P = int(_hip.lib().hscn_resident_param_count(F, H, L, C))
         self.P = P
@@ -186,7 +197,8 @@ class ResidentTrainStep:
                  m.max_n, m.max_ell, ptr(self.target), int(self.kind), ptr(self.pred), ptr(self.score),
                  ptr(self.partials), ptr(self.grads), ptr(self.acts) if with_v else None,
                  ptr(self._sync) if with_v else None, ptr(m.flag),
-                 ctypes.byref(self._job(self.virtual)) if with_v else None, st)
+                 ctypes.byref(self._job(self.virtual)) if with_v else None,
+                 ctypes.byref(self.structure.c) if self.structure is not None else None, st)
         elif self.defer:
             call("hscn_resident_fwd_with_virtual" + self._sfx, ptr(self.x_local), ptr(ei_ll), E_ll, ptr(m.lptr), ptr(m.eptr_ll),
                  N, B, F, H, L, C, self.head_act, self._table, ptr(W1), ptr(b1), ptr(W2), ptr(b2), m.max_n,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 4
+#define HSCN_ABI_VERSION 5
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -432,6 +432,38 @@ int hscn_resident_bwd_with_virtual(const float* x_local, const int64_t* ei_ll, i
                                    const hscn_loss_tail* tail /*or NULL*/, const hscn_virtual_job* job, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * structure_build = "dataset-resident".  The reference rebuilds nothing because it has no structure to build
+ * (PyG scatters over the COO list every call, model/hscn.py:108-110); the resident launches build four stable CSRs
+ * and two degree norms per graph in LDS every step.  Graph structure is epoch-invariant, so it can be built ONCE:
+ * hscn_resident_structure fills an hscn_structure for every graph of a block-diagonal hetero batch -- or of a whole
+ * dataset laid out as one batch -- with the same device functions the launches use (graph-LOCAL int32 ids; rows keep
+ * ascending edge order), hscn_collate_gather_structure gathers the chosen graphs' slices next to hscn_collate_gather,
+ * and hscn_resident_train_step(structure != NULL) loads instead of building.  Bit-identical results either way.
+ *   graph g: ll_rowptr_* at lptr[g] + g (n+1 entries), ll_col_* at eptr_ll[g], ll_dinv at lptr[g];
+ *            lv_rowptr / vv_rowptr at vptr[g] + g (nv+1), lv_col at eptr_lv[g], vv_col at eptr_vv[g], vv_dinv at vptr[g].
+ * ------------------------------------------------------------------------- */
+typedef struct hscn_structure {
+  int32_t *ll_rowptr_d, *ll_col_d;   /* local->local keyed by target  [N+B] [E_ll] */
+  int32_t *ll_rowptr_s, *ll_col_s;   /* local->local keyed by source  [N+B] [E_ll] */
+  float* ll_dinv;                    /* in-degree^-1/2                [N]          */
+  int32_t *lv_rowptr, *lv_col;       /* local->virtual keyed by target (cluster)  [V+B] [E_lv] */
+  int32_t *vv_rowptr, *vv_col;       /* virtual->virtual keyed by target          [V+B] [E_vv] */
+  float* vv_dinv;                    /* [V] */
+} hscn_structure;
+int hscn_resident_structure(const int64_t* ei_ll, int64_t E_ll, const int64_t* ei_vv, int64_t E_vv,
+                            const int64_t* ei_lv, int64_t E_lv, const int32_t* lptr, const int32_t* vptr,
+                            const int32_t* eptr_ll, const int32_t* eptr_vv, const int32_t* eptr_lv, int64_t B,
+                            int max_n, int max_v, int max_ell, int max_evv, const hscn_structure* out,
+                            int32_t* flag, void* stream);
+/* gather of the structure slices of graphs ids[0..B) of a dataset (ds_structure built over the dataset as one batch
+ * of ds->G graphs) into batch-level arrays with the capacities of `out_batch`; same ids / cursor convention as
+ * hscn_collate_gather, which must be called AFTER it when a cursor is used (that call advances the cursor). */
+int hscn_collate_gather_structure(const hscn_hetero_dataset* dataset, const hscn_structure* ds_structure,
+                                  const int64_t* ids, int64_t B, const hscn_hetero_batch_out* out_batch,
+                                  const hscn_structure* out_structure, int32_t* flag, const int32_t* cursor,
+                                  void* stream);
+
+/* ------------------------------------------------------------------------- *
  * a10 + f3  the whole training iteration of stage C in ONE launch (+ the ordered parameter reduction):
  * reference train/train.py:73-95 -- pred = model(x_dict, edge_index_dict, batch) (model/hscn.py:102-114);
  * loss, score = criterion(loss_fn, pred, true) (loss.py:6-19); loss.backward().  Workgroup g runs forward, its row
@@ -456,7 +488,8 @@ int hscn_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t
                              const float* W2, const float* b2, int max_n, int max_ell, const float* target,
                              int loss_kind, float* pred, float* score /*or NULL*/, float* partials /*[B,P+1]*/,
                              float* grads /*[P+1]*/, float* acts /*or NULL*/, uint32_t* sync /*or NULL*/,
-                             int32_t* flag, const hscn_virtual_job* job /*or NULL*/, void* stream);
+                             int32_t* flag, const hscn_virtual_job* job /*or NULL*/,
+                             const hscn_structure* structure /*or NULL: build per step*/, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * BASELINE.json configs[4] ("fp16 feat + bf16 accum", PCQM-Contact): the four launches above with IEEE-half
@@ -548,7 +581,7 @@ int hscn_resident_train_step_f16(const hscn_half* x_local, const int64_t* ei_ll,
                                  const float* W2, const float* b2, int max_n, int max_ell, const float* target,
                                  int loss_kind, float* pred, float* score, float* partials, float* grads,
                                  hscn_half* acts, uint32_t* sync, int32_t* flag, const hscn_virtual_job* job,
-                                 void* stream);
+                                 const hscn_structure* structure, void* stream);
 
 /* IEEE-half storage twins of the two stage-A launches (BASELINE.json configs[4]): x [N,F] and the saved hidden
  * activation y [N,H] are half (y rounded once, where it is produced); S, stats, ss, losses, the exported
