@@ -323,39 +323,12 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
 #pragma unroll
     for (int s = 0; s < KS; ++s) b[ct][s] = Wt[(KS * lj + s) * H + ct * 16 + li];
   }
-  for (int rt = G.w; rt < ntile; rt += G.nw) {
-    const int r0 = rt * 16, i = r0 + li;
-    float z[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) z[s] = 0.f;
-    if (i < n) {
-      const int s0 = rowptr[i], t0 = rowptr[i + 1];
-      const float di = dinv[i];
-      const float* xq = X + KS * lj;
-      // four neighbours per trip (molecule-like graphs: one trip per row), clamped slots with weight 0 past the
-      // row's end: index, norm and row reads of a trip are independent, a row costs three LDS round trips
-      for (int p = s0; p < t0; p += 4) {
-        int j[4];
-        float w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) j[u] = col[p + u < t0 ? p + u : t0 - 1];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = p + u < t0 ? dinv[j[u]] * di : 0.f;
-#pragma unroll
-        for (int q = 0; q < KS / 4; ++q) {
-          float4 v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xq + j[u] * H + 4 * q);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            z[4 * q + 0] = fmaf(w[u], v[u].x, z[4 * q + 0]);
-            z[4 * q + 1] = fmaf(w[u], v[u].y, z[4 * q + 1]);
-            z[4 * q + 2] = fmaf(w[u], v[u].z, z[4 * q + 2]);
-            z[4 * q + 3] = fmaf(w[u], v[u].w, z[4 * q + 3]);
-          }
-        }
-      }
-    }
+  // (Walking a wave's two tiles' gathers jointly -- two independent chains of LDS round trips in one branch-free
+  // loop -- was built and measured: 31.8 us per step against 31.0; the wave with two tiles is not what a layer waits
+  // for.  One tile at a time.)
+  const float* xq = X + KS * lj;
+  auto finish = [&](int rt_, const float (&z)[KS]) {
+    const int r0 = rt_ * 16;
     f32x4 acc[TD];
 #pragma unroll
     for (int ct = 0; ct < TD; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -375,38 +348,15 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
           if (gout) stf(gout, (size_t)idx, v);
         }
       }
-  }
-}
-
-// The same layer for the one-launch step (resident_step.h), whose output rows are handed to ANOTHER workgroup of
-// the same launch: the rows go out as write-through (sc1) stores, and they are issued at the END of the phase, from
-// registers, behind one s_waitcnt vmcnt(0) -- at that point the only stores this wave can still have in flight are
-// the previous layer's, a whole layer old, so the wait is free and exact, and after the phase barrier that follows
-// one lane may raise the previous layer's publish counter.  A wave keeps up to two tiles' outputs in registers
-// (n <= 512 at 16 waves); further tiles store at once and are simply covered by the wait.
-template <int H, typename TS>
-__device__ void gcn_fused_pub(const int* rowptr, const int* col, const float* dinv, const float* X, const float* Wt,
-                              const float* bias, float* Y, TS* __restrict__ gout, int n, const Grp& G, bool drain) {
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  constexpr int TD = H / 16, KS = H / 4;
-  const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
-  const int ntile = (n + 15) >> 4;
-  float b[TD][KS], bia[TD];
-#pragma unroll
-  for (int ct = 0; ct < TD; ++ct) {
-    bia[ct] = bias[ct * 16 + li];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) b[ct][s] = Wt[(KS * lj + s) * H + ct * 16 + li];
-  }
-  auto tile = [&](int rt, float (&out)[TD][4]) {
-    const int r0 = rt * 16, i = r0 + li;
+  };
+  for (int rt = G.w; rt < ntile; rt += G.nw) {
+    const int i = rt * 16 + li;
     float z[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) z[s] = 0.f;
     if (i < n) {
       const int s0 = rowptr[i], t0 = rowptr[i + 1];
       const float di = dinv[i];
-      const float* xq = X + KS * lj;
       for (int p = s0; p < t0; p += 4) {
         int j[4];
         float w[4];
@@ -429,44 +379,8 @@ __device__ void gcn_fused_pub(const int* rowptr, const int* col, const float* di
         }
       }
     }
-    f32x4 acc[TD];
-#pragma unroll
-    for (int ct = 0; ct < TD; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int ct = 0; ct < TD; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[s], b[ct][s], acc[ct], 0, 0, 0);
-#pragma unroll
-    for (int ct = 0; ct < TD; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + lj * 4 + r;
-        const float v = rnd<TS>(fmaxf(acc[ct][r] + bia[ct], 0.f));
-        out[ct][r] = v;
-        if (row < n) Y[row * H + ct * 16 + li] = v;
-      }
-  };
-  auto store = [&](int rt, const float (&out)[TD][4]) {
-#pragma unroll
-    for (int ct = 0; ct < TD; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + lj * 4 + r;
-        if (row < n) stf_sc1(gout, (size_t)row * H + ct * 16 + li, out[ct][r]);
-      }
-  };
-  float o0[TD][4], o1[TD][4];
-  const int t0 = G.w, t1 = G.w + G.nw;
-  if (t0 < ntile) tile(t0, o0);
-  if (t1 < ntile) tile(t1, o1);
-  for (int rt = G.w + 2 * G.nw; rt < ntile; rt += G.nw) {
-    float ox[TD][4];
-    tile(rt, ox);
-    store(rt, ox);
+    finish(rt, z);
   }
-  if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (t0 < ntile) store(t0, o0);
-  if (t1 < ntile) store(t1, o1);
 }
 
 template <int H>
@@ -1158,13 +1072,10 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         const int ncnt = more ? n * (H / 4) : 0;
         const __amdgpu_buffer_rsrc_t nrs = rsrc_of<TS>(nsrc, ncnt * 4);
         if (hand) {
-          wait_published<false>(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
+          // (the rows are fetched in phase 2, beside group B's long reduce: polling here -- the local workgroup
+          // raises the counter about a layer after this point -- held the phase barrier for ~5 k cycles)
 #pragma unroll
-          for (int u = 0; u < PF; ++u) {
-            const int i = GA.t + u * GA.nt;
-            const float4 q = ldf4_sc1<TS>(nrs, i < ncnt ? i : 0);
-            pf[u][0] = q.x; pf[u][1] = q.y; pf[u][2] = q.z; pf[u][3] = q.w;
-          }
+          for (int u = 0; u < PF; ++u) pf[u][0] = pf[u][1] = pf[u][2] = pf[u][3] = 0.f;
         } else {
 #pragma unroll
           for (int u = 0; u < PF; ++u) {
@@ -1178,6 +1089,15 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         lds_barrier();
         STAMP(5 + 4 * l);
         float4* ndst = reinterpret_cast<float4*>(bh);
+        if (hand) {
+          wait_published<false>(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            const int i = GA.t + u * GA.nt;
+            const float4 q = ldf4_sc1<TS>(nrs, i < ncnt ? i : 0);
+            pf[u][0] = q.x; pf[u][1] = q.y; pf[u][2] = q.z; pf[u][3] = q.w;
+          }
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
           const int i = GA.t + u * GA.nt;

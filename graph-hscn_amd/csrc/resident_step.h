@@ -283,7 +283,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     if (bad && A.flag) atomicOr(A.flag, 2);
   }
   for (int i = threadIdx.x; i <= n; i += RT) { (ib + Y.cursorA)[i] = 0; (ib + Y.cursorT)[i] = 0; }
-  if (threadIdx.x == 0) (ib + Y.wsum)[0] = 0;   // completed weight-gradient folds (H = 16 backward)
+  if (threadIdx.x == 0) { (ib + Y.wsum)[0] = 0; (ib + Y.wsum)[1] = 0; }   // fold sign-offs (H = 16 backward), export sign-offs
   {
     float* x0 = buf(0);
 #pragma unroll
@@ -332,23 +332,76 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   lds_barrier();
   STAMP(3);
   // ---- forward layers: A[l] -> A[l + 1], one barrier each ----------------------------------------------------
-  // Hand-off of a_1 .. a_{L-1} to the virtual workgroup (gcn_fused_pub): a layer's output rows leave as write-through
-  // (sc1) stores at the end of the layer; the wave's wait for the PREVIOUS layer's stores sits right in front of
-  // them (free: those are a whole layer old), the layer's barrier follows, then one lane raises the graph's publish
-  // counter for the previous layer's rows.  Nothing is re-read from LDS and nothing stalls.
+  // Hand-off of a_1 .. a_{L-1} to the virtual workgroup.  Write-through (sc1) stores need > 2 us to complete, and
+  // the publish counter may only be raised behind a wait for them: a wait that every wave performs (between a layer's
+  // work and its barrier) stalled the whole workgroup for that long (measured: +3.5 k cycles on layer 1).  So ONE
+  // wave of the workgroup does nothing but export while a hand-off is on: in phase l it first waits for the stores
+  // it issued in phase l-1 (by then they are a layer old) and raises the counter for them, then copies a_l -- complete
+  // since the previous barrier -- from LDS to HBM with 16-byte sc1 stores, then joins the phase's barrier.  Its
+  // waiting overlaps the other waves' layer; the compute waves never wait for a store.  (A graph of 354 nodes is 23
+  // row tiles: 15 compute waves need the same two rounds as 16.)
+  const bool hand = acts_g != nullptr && L >= 2;
+  constexpr int NE = NW >= 16 ? 2 : 1;                         // export waves (the last NE of the workgroup)
+  const int NC = hand && NW > 1 ? NW - NE : NW;                // compute waves of the forward layers
+  const Grp GC{(int)threadIdx.x, NC * 64, wave, NC};
+  auto export_rows = [&](const float* src, TS* dst) {          // (one wave)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const int cnt = n * (H / 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, cnt * 4 * (int)sizeof(TS), 0x00020000);
+    const int ew = NW > 1 ? wave - NC : 0, nes = NW > 1 ? NE : 1;      // this export wave's share
+    for (int i0 = ew * 64 + lane; i0 < cnt; i0 += 4 * nes * 64) {   // four LDS reads in flight, then their stores
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * nes * 64;
+        v[u] = reinterpret_cast<const float4*>(src)[i < cnt ? i : i0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * nes * 64;
+        if (i >= cnt) continue;
+        if constexpr (sizeof(TS) == 4) {
+          u32x4 w = {__float_as_uint(v[u].x), __float_as_uint(v[u].y), __float_as_uint(v[u].z), __float_as_uint(v[u].w)};
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs, i * 16, 0, 16 /* sc1 */);
+        } else {
+          half4_t h;
+          h.x = (half_t)v[u].x; h.y = (half_t)v[u].y; h.z = (half_t)v[u].z; h.w = (half_t)v[u].w;   // exact: half already
+          u32x2 w;
+          __builtin_memcpy(&w, &h, 8);
+          __builtin_amdgcn_raw_buffer_store_b64(w, rs, i * 8, 0, 16 /* sc1 */);
+        }
+      }
+    }
+  };
+  // every export wave waits for ITS stores; the counter is raised by one lane once all of them have (they count
+  // themselves off in LDS: the last one to arrive raises)
+  int* exp_cnt = ib + Y.wsum + 1;
+  auto raise = [&](int upto) {   // the stores of a_1 .. a_upto have completed: tell the virtual workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 1;
+    if (NE > 1 && NW > 1) {
+      int arrived = 0;
+      if (lane == 0) arrived = __hip_atomic_fetch_add(exp_cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      arrived = __builtin_amdgcn_readfirstlane(arrived);
+      last = (arrived % NE) == NE - 1;
+    }
+    if (last && A.ready && lane == 0)
+      __hip_atomic_store(A.ready + g, ep8 + (uint32_t)upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   for (int l = 0; l < L; ++l) {
     STAMP(4 + l);
-    const bool hand = acts_g != nullptr;
-    if (hand && l + 1 < L) {   // a_{l+1} is wanted by the virtual branch
-      gcn_fused_pub<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1),
-                           acts_g + ((size_t)l * A.N + n0) * H, n, ALL, l >= 1);
-    } else {
-      gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, ALL);
-      if (hand && l >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a_l's stores (a layer old) have completed
+    if (wave < NC) {
+      gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC);
+    } else if (hand) {
+      if (l >= 2) raise(l - 1);
+      if (l >= 1) export_rows(buf(l), acts_g + ((size_t)(l - 1) * A.N + n0) * H);
     }
     lds_barrier();
-    if (hand && A.ready && l >= 1 && threadIdx.x == 0)
-      __hip_atomic_store(A.ready + g, ep8 + (uint32_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (hand && NW == 1) {                                 // a one-wave workgroup exports after its layers
+    for (int l = 1; l < L; ++l) export_rows(buf(l), acts_g + ((size_t)(l - 1) * A.N + n0) * H);
+    raise(L - 1);
   }
   STAMP(12);
   // ---- global_mean_pool + head + this graph's row of the loss tail --------------------------------------------
@@ -372,6 +425,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     if (slot == 0) *reinterpret_cast<float4*>(partp + wave * H + f) = acc;
   }
   lds_barrier();
+  if (hand && wave >= NC && NW > 1) raise(L - 1);       // the last hand-off signs off beside the head (wave 0's chain)
   float* pol = vec;          // pooled
   float* zz = vec + 64;      // z = act(lin_1(pooled))
   float* gz = vec + 128;     // dL/d(lin_1 output, pre-activation)
@@ -470,7 +524,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   if (threadIdx.x < H) part[ob1 + threadIdx.x] = gz[threadIdx.x];
   float* G = aL;                  // gradient of the current layer's output, masked in place
   float* GH = L >= 2 ? buf(0) : buf(2);
-  {
+  if constexpr (H != 16) {
     const float cnt = (float)(n > 0 ? n : 1);
     for (int idx = threadIdx.x; idx < n * H; idx += RT) G[idx] = G[idx] > 0.f ? gpool[idx % H] / cnt : 0.f;
   }
@@ -510,6 +564,16 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     const int li = lane & 15, lj = lane >> 4;
     const int ntile = (n + 15) >> 4;
     int pend_ob = 0;
+    // The gradient of the last layer's output is never materialised: G_L[j][k] = a_L[j][k] > 0 ? gpool[k] / n : 0 is
+    // applied where the first backward layer reads it (the same values as the masking pass of the launch pair).
+    const float ncnt = (float)(n > 0 ? n : 1);
+    const float4 gq4 = make_float4(gpool[4 * lj + 0] / ncnt, gpool[4 * lj + 1] / ncnt, gpool[4 * lj + 2] / ncnt,
+                                   gpool[4 * lj + 3] / ncnt);       // this lane's feature quarter (tile gather)
+    const float4 gb4 = make_float4(gpool[4 * (lane & 3) + 0] / ncnt, gpool[4 * (lane & 3) + 1] / ncnt,
+                                   gpool[4 * (lane & 3) + 2] / ncnt, gpool[4 * (lane & 3) + 3] / ncnt);   // (bias sums)
+    auto gl4 = [](const float4 a, const float4 q) {
+      return make_float4(a.x > 0.f ? q.x : 0.f, a.y > 0.f ? q.y : 0.f, a.z > 0.f ? q.z : 0.f, a.w > 0.f ? q.w : 0.f);
+    };
     for (int it = 0, l = L - 1; l >= 0; --l, ++it) {
       const int fin = l == 0 ? F : H;
       off -= H * fin + H;
@@ -517,15 +581,26 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       float* bredw = bred + (it & 1) * NW * H;
       lds_barrier();  // G complete; the previous layer's partial tiles and bias partials are in LDS
       if (pend_oW >= 0) {
-        fold_gw(0, pend_oW, pend_fin);
-        if (threadIdx.x < H) {
+        // (the folding threads are the workgroup's LAST ones: with 23 row tiles on 16 waves the first seven waves own
+        // two tiles, the last ones one)
+        const int ft = (int)threadIdx.x - (RT - NFW * 64);
+        if (ft >= 0) {
+          const int e_ = ft & 255;
+          float s_ = 0.f;
+#pragma unroll
+          for (int r = 0; r < NW; ++r) s_ += red[r * 256 + e_];
+          const int oo = e_ >> 4, kk = e_ & 15;
+          if (kk < pend_fin) part[pend_oW + oo * pend_fin + kk] = s_;
+        }
+        if ((int)threadIdx.x >= RT - H) {
+          const int c_ = (int)threadIdx.x - (RT - H);
           const float* bp = bred + ((it - 1) & 1) * NW * H;
           float sb = 0.f;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) sb += bp[w * H + threadIdx.x];
-          part[pend_ob + threadIdx.x] = sb;
+          for (int w = 0; w < NW; ++w) sb += bp[w * H + c_];
+          part[pend_ob + c_] = sb;
         }
-        if (wave < NFW) {
+        if (wave >= NW - NFW) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) __hip_atomic_fetch_add(fold_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -534,7 +609,8 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
         const int slot = lane >> 2, f = (lane & 3) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = wave * 16 + slot; i < n; i += NW * 16) {
-          const float4 v = *reinterpret_cast<const float4*>(Gc + i * H + f);
+          float4 v = *reinterpret_cast<const float4*>(Gc + i * H + f);
+          if (it == 0) v = gl4(v, gb4);
           acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
@@ -554,45 +630,18 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       for (int s = 0; s < 4; ++s) bw[s] = l > 0 ? Wl[li * H + 4 * lj + s] : 0.f;   // W_l[4 lj + s][li]
       f32x4 accw = {0.f, 0.f, 0.f, 0.f};
       float* sc = ght + wave * 256;
-      for (int rt = wave; rt < ntile; rt += NW) {
-        const int r0 = rt * 16, i = r0 + li;
-        float bx[4];
-        if (l == 0) {   // the features, straight from HBM into the weight gradient's operand registers
+      const float* gq = Gc + 4 * lj;
+      auto xrows = [&](int rt_, float (&bx)[4]) {   // l == 0: the features, straight from HBM into the operand registers
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int row = r0 + 4 * c + lj;
-            const bool okx = row < n && li < fin;
-            const float tx = ldf(xl_g, okx ? (size_t)(n0 + row) * fin + li : 0);
-            bx[c] = okx ? tx : 0.f;
-          }
+        for (int c = 0; c < 4; ++c) {
+          const int row = rt_ * 16 + 4 * c + lj;
+          const bool okx = row < n && li < fin;
+          const float tx = ldf(xl_g, okx ? (size_t)(n0 + row) * fin + li : 0);
+          bx[c] = okx ? tx : 0.f;
         }
-        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n) {
-          const int s0 = rowptr_t[i], t0 = rowptr_t[i + 1];
-          const float di = dinv[i];
-          const float* gq = Gc + 4 * lj;
-          for (int p = s0; p < t0; p += 4) {
-            int jj[4];
-            float ww[4];
-            float4 vv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) jj[u] = col_t[p + u < t0 ? p + u : t0 - 1];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              ww[u] = mul_rn(dinv[jj[u]], di);
-              vv[u] = *reinterpret_cast<const float4*>(gq + jj[u] * H);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (p + u < t0) {
-                z.x = add_rn(z.x, mul_rn(ww[u], vv[u].x));
-                z.y = add_rn(z.y, mul_rn(ww[u], vv[u].y));
-                z.z = add_rn(z.z, mul_rn(ww[u], vv[u].z));
-                z.w = add_rn(z.w, mul_rn(ww[u], vv[u].w));
-              }
-            }
-          }
-        }
+      };
+      auto finish = [&](int rt_, const float4 z, const float (&bx)[4]) {
+        const int r0 = rt_ * 16;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the previous tile's reads of the scratch are done
         *reinterpret_cast<float4*>(sc + li * 16 + 4 * lj) = z;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -621,6 +670,39 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
             }
           }
         }
+      };
+      for (int rt = wave; rt < ntile; rt += NW) {
+        float bxA[4] = {0.f, 0.f, 0.f, 0.f};
+        if (l == 0) xrows(rt, bxA);
+        const int i = rt * 16 + li;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+          const int s0 = rowptr_t[i], t0 = rowptr_t[i + 1];
+          const float di = dinv[i];
+          for (int p = s0; p < t0; p += 4) {
+            int jj[4];
+            float ww[4];
+            float4 vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = col_t[p + u < t0 ? p + u : t0 - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              ww[u] = mul_rn(dinv[jj[u]], di);
+              vv[u] = *reinterpret_cast<const float4*>(gq + jj[u] * H);
+              if (it == 0) vv[u] = gl4(vv[u], gq4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (p + u < t0) {
+                z.x = add_rn(z.x, mul_rn(ww[u], vv[u].x));
+                z.y = add_rn(z.y, mul_rn(ww[u], vv[u].y));
+                z.z = add_rn(z.z, mul_rn(ww[u], vv[u].z));
+                z.w = add_rn(z.w, mul_rn(ww[u], vv[u].w));
+              }
+            }
+          }
+        }
+        finish(rt, z, bxA);
       }
       if (it > 0) {   // the folders of the previous layer's partial tiles have signed off (see above)
         while (__hip_atomic_load(fold_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it * NFW)

@@ -26,7 +26,7 @@ from graph_hscn.step import ResidentTrainStep
 def main():
     dev = torch.device("cuda:0")
     lib = _hip.lib()
-    ids = sys.argv[1] if len(sys.argv) > 1 else "scn_untrained"
+    ids = "uniform" if "uniform" in sys.argv[1:] else "scn_untrained"
     hb_host, graphs, _ = bench.build_hetero_batch("peptides_func", 128, 16, 0, dev, ids)
     hb = hb_host.to(dev)
     torch.manual_seed(0)
@@ -37,7 +37,11 @@ def main():
     lib.hscn_diag_set_stamp_buffer.argtypes = [ctypes.c_void_p]
     assert lib.hscn_diag_set_stamp_buffer(buf.data_ptr()) == 0
     sizes = np.diff(hb_host["local"].ptr.numpy())
-    rs = ResidentTrainStep(model, hb, "cross_entropy", one_launch=True)
+    structure = None
+    if "resident" in sys.argv[1:]:
+        from graph_hscn.engine import build_structure
+        structure = build_structure(hb)
+    rs = ResidentTrainStep(model, hb, "cross_entropy", one_launch=True, structure=structure)
     for _ in range(3):
         rs.run()
     torch.cuda.synchronize()
