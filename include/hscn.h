@@ -468,8 +468,10 @@ int hscn_collate_gather_structure(const hscn_hetero_dataset* dataset, const hscn
  * reference train/train.py:73-95 -- pred = model(x_dict, edge_index_dict, batch) (model/hscn.py:102-114);
  * loss, score = criterion(loss_fn, pred, true) (loss.py:6-19); loss.backward().  Workgroup g runs forward, its row
  * of d(mean loss)/d pred and backward of graph g with structure and every activation resident in LDS; nothing is
- * exported between "forward" and "backward" (csrc/resident_step.h).  Results are bit-identical to
- * hscn_resident_fwd_with_virtual + hscn_resident_bwd_with_virtual(tail).
+ * exported between "forward" and "backward" (csrc/resident_step.h).  Prediction, score, loss and virtual features
+ * are bit-identical to hscn_resident_fwd_with_virtual + hscn_resident_bwd_with_virtual(tail); the parameter
+ * gradients agree with theirs to float rounding (H = 16 groups the weight gradient's partial sums by row tile);
+ * every output is bitwise reproducible from run to run.
  *   target [B,C], loss_kind 0 = BCE-with-logits / 1 = L1 (mean over B*C); pred, score [B,C] outputs;
  *   partials [B,P+1], grads [P+1], P = hscn_resident_param_count: grads[0..P) = parameter gradients in the order
  *   {W_ll, b_ll} per layer, W1, b1, W2, b2; grads[P] = the mean loss.

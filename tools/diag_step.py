@@ -29,6 +29,8 @@ def main():
     ids = "uniform" if "uniform" in sys.argv[1:] else "scn_untrained"
     hb_host, graphs, _ = bench.build_hetero_batch("peptides_func", 128, 16, 0, dev, ids)
     hb = hb_host.to(dev)
+    if "f16" in sys.argv[1:]:
+        hb = hb.with_feature_dtype(torch.float16)
     torch.manual_seed(0)
     Lyr = 3
     model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, 10, Lyr).to(dev)
