@@ -379,13 +379,17 @@ def stage_a_main(args):
     else:
         one = torch.ones((), device=dev)
 
-        def step():
+        def eager_step():
             for p in scn.parameters():
                 p.grad = None
             S, mc, o, total = scn.forward_graphs(big, with_total=True)
             total.backward(one)
+        step = eager_step
         issue = ("eager (layered operators + csrc/dense.hip through autograd)" if args.route == "dense" else
                  "eager (layered operators through autograd: the graphs do not fit the fused stage-A launch at this K)")
+        # (not replayed from a hipGraph: the layered gcn_norm selects its self loops with a boolean mask -- a
+        # data-dependent shape -- which a stream capture refuses; the line is host-bound, the roofline below times the
+        # dominant C call by itself)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
