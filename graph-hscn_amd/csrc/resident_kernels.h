@@ -496,7 +496,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   Y.tmpV = scratch(max_evv);
   Y.ck_tab = take(max_v ? maxck : 0);
   Y.ck_first = take(max_v ? max_v + 1 : 0);
-  Y.ck_arrive = take(max_v);
+  Y.ck_arrive = take(max_v ? max_v + 1 : 0);   // + the work counter of the chunk list (ck_arrive[max_v])
   Y.total = o;
   return Y;
 }
@@ -871,6 +871,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     // applies the two H x H matrices to the two aggregated rows.  Same values as transform-then-aggregate,
     // another rounding order.
     auto transforms_virtual = [&](const Grp& G_) {
+      if (G_.t == 0) ck_arrive[A.max_v] = 0;   // this layer's chunk counter (the phase barrier orders it before the reduce)
       att_logits<H>(xa, W + H * H, att_s, a_s, n, G_);
       att_logits<H>(xva, W + 2 * H * H, att_d, a_d, nv, G_);
     };
@@ -893,7 +894,17 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       constexpr int S = 64 / LPR;
       const int lane = threadIdx.x & 63, slot = lane / LPR, f = (lane % LPR) * 4;
       const int nck = ck_first[nv];
-      for (int ck = G_.w; ck < nck; ck += G_.nw) {
+      // chunks are handed out through an LDS counter (zeroed in the layer's first phase), not by wave index: whichever
+      // wave is free takes the next one -- in a virtual-only workgroup the loading waves join in once their rows are
+      // parked, so 16 clusters of a graph take one round on 16 waves instead of two on 12.  A chunk's arithmetic does
+      // not depend on who runs it, a cluster is finished by its last arriver in chunk order: same bits as before.
+      int* ck_next = ck_arrive + A.max_v;
+      (void)G_;
+      for (;;) {
+        int ck = 0;
+        if (lane == 0) ck = __hip_atomic_fetch_add(ck_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ck = __builtin_amdgcn_readfirstlane(ck);
+        if (ck >= nck) break;
         const int code = ck_tab[ck];
         const int v = code >> 8, c = code & 255;
         const int s = rowptr_lv[v], t = rowptr_lv[v + 1];
@@ -1104,6 +1115,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
           if (i < ncnt) ndst[i] = make_float4(pf[u][0], pf[u][1], pf[u][2], pf[u][3]);
         }
         for (int i = GA.t + PF * GA.nt; i < ncnt; i += GA.nt) ndst[i] = hand ? ldf4_sc1<TS>(nrs, i) : ldf4(nsrc, i);
+        reduce_virtual(GA);                  // (then help with whatever chunks are left)
         STAMP_T(43 + 4 * l, 0);              // group A done with its phase-2 work
         lds_barrier();
       } else {
