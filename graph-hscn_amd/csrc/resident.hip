@@ -92,6 +92,11 @@ int hscn_resident_train_step_supported(int F, int H, int L, int C, int max_n, in
   return step_supported(F, H, L, C, max_n, max_ell, max_v, max_evv);
 }
 
+int hscn_resident_train_step_wgs_per_cu(int F, int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv) {
+  if (!step_supported(F, H, L, C, max_n, max_ell, max_v, max_evv)) return 0;
+  return step_wgs_per_cu(H, L, C, max_n, max_ell, max_v, max_evv);
+}
+
 int hscn_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                              const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
                              const void* const* layer_params_host, const float* W1, const float* b1, const float* W2,

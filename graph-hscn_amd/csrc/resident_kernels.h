@@ -79,6 +79,8 @@ struct FwdArgs {
   // local workgroup of the same launch; ready[g] counts them (epoch * 8 + count), NULL: they come from an earlier launch
   const uint32_t* ready;
   const uint32_t* epoch;
+  int acq;   // 1: the consumer acquires (agent scope) and uses plain loads -- several workgroups share a CU (small
+             // graphs), outside the envelope the acquire-free sc1-load form was measured for; 0: sc1 loads, no acquire
   // structure_build = "dataset-resident": the CSRs of the virtual relations and the virtual degree norm of every
   // graph come from HBM (include/hscn.h: hscn_structure; built once per dataset, gathered with the batch) instead
   // of being rebuilt from the COO slices every step.  Virtual-only workgroups from layer 0 (the one-launch step).
@@ -1100,7 +1102,16 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         lds_barrier();
         STAMP(5 + 4 * l);
         float4* ndst = reinterpret_cast<float4*>(bh);
-        if (hand) {
+        const bool sc1l = hand && !A.acq;
+        if (hand && A.acq) {
+          wait_published<true>(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            const int i = GA.t + u * GA.nt;
+            const float4 q = ldf4(nsrc, i < ncnt ? i : 0);
+            pf[u][0] = q.x; pf[u][1] = q.y; pf[u][2] = q.z; pf[u][3] = q.w;
+          }
+        } else if (hand) {
           wait_published<false>(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
 #pragma unroll
           for (int u = 0; u < PF; ++u) {
@@ -1114,7 +1125,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
           const int i = GA.t + u * GA.nt;
           if (i < ncnt) ndst[i] = make_float4(pf[u][0], pf[u][1], pf[u][2], pf[u][3]);
         }
-        for (int i = GA.t + PF * GA.nt; i < ncnt; i += GA.nt) ndst[i] = hand ? ldf4_sc1<TS>(nrs, i) : ldf4(nsrc, i);
+        for (int i = GA.t + PF * GA.nt; i < ncnt; i += GA.nt) ndst[i] = sc1l ? ldf4_sc1<TS>(nrs, i) : ldf4(nsrc, i);
         reduce_virtual(GA);                  // (then help with whatever chunks are left)
         STAMP_T(43 + 4 * l, 0);              // group A done with its phase-2 work
         lds_barrier();
@@ -1951,7 +1962,7 @@ int fill_fwd_args(FwdArgs& A, const float* x_local, const float* x_virtual, cons
   A.max_n = max_n; A.max_v = max_v; A.max_ell = vonly ? 0 : max_ell; A.max_evv = max_evv;
   A.compute_virtual = compute_virtual; A.slope = slope; A.spec = 0; A.exp = 0; A.exp_dinv = 0; A.db = 0;
   A.l_begin = 0; A.l_end = L;
-  A.ready = nullptr; A.epoch = nullptr;
+  A.ready = nullptr; A.epoch = nullptr; A.acq = 0;
   A.pre_rp_lv = A.pre_col_lv = A.pre_rp_vv = A.pre_col_vv = nullptr; A.pre_dinv_v = nullptr;
   A.vs_rowptr_lv = A.vs_col_lv = A.vs_rowptr_vv = A.vs_col_vv = nullptr;
   A.vs_dinv_v = A.vs_xv = nullptr;
@@ -2293,6 +2304,20 @@ inline int impl_resident_structure(const int64_t* ei_ll, int64_t E_ll, const int
   k_structure<<<(unsigned)B, 256, lds, hscn_stream(stream_)>>>(A);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+
+// workgroups of the one-launch step that one CU takes at a time: 1 for 16-wave workgroups (they are not made to
+// share a CU), up to 4 for the 4-wave workgroups of small graphs (PCQM-Contact: n <= 64) when LDS allows
+inline int step_wgs_per_cu(int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv) {
+  if (max_n > 64) return 1;
+  size_t lds = step_lds_bytes(H, L, C, max_n, max_ell);
+  if (max_v > 0) {
+    const size_t lv = fwd_lds_bytes(H, C, max_n, max_v, 0, max_evv, 1, 0);
+    if (lv > lds) lds = lv;
+  }
+  if (lds == 0) return 4;
+  const int by_lds = (int)((size_t)160 * 1024 / lds);
+  return by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
 }
 
 inline int step_supported(int F, int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv) {

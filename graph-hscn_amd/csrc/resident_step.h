@@ -877,8 +877,13 @@ int launch_step(StepArgs& S, FwdArgs* V, hipStream_t st) {
     const size_t lv = pick_fwd_lds(*V, H);
     if (lv > 160 * 1024) return HSCN_E_UNSUPPORTED;
     if (lv > lds) lds = lv;
-    // the hand-off protocol is measured for one workgroup per CU: ask for more than half of a CU's LDS
-    if (lds < 81 * 1024) lds = 81 * 1024;
+    if (S.max_n > 64) {
+      // 16-wave workgroups: one per CU (the acquire-free consumer form is measured for exactly that): ask for more
+      // than half of a CU's LDS
+      if (lds < 81 * 1024) lds = 81 * 1024;
+    } else {
+      V->acq = 1;   // small graphs share CUs: the consumer acquires and uses plain loads (Guideline 16, R1 as written)
+    }
   }
   if (S.max_n <= 64) return launch_step_rt<H, 256, TS>(S, V, lds, st);
   return launch_step_rt<H, 1024, TS>(S, V, lds, st);

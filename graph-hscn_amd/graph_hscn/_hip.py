@@ -76,6 +76,7 @@ _SIGNATURES = {
     "hscn_resident_bwd_with_virtual": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                                c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P]),
     "hscn_resident_train_step_supported": (c_int, [c_int] * 8),
+    "hscn_resident_train_step_wgs_per_cu": (c_int, [c_int] * 8),
     "hscn_resident_train_step": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                          P, P, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_structure": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, P, P, c_int64, c_int, c_int, c_int,

@@ -113,9 +113,12 @@ class ResidentTrainStep:
         self.csr = (torch.empty(N + B, **i32), torch.empty(max(E_ll, 1), **i32), torch.empty(max(N, 1), **f32))
         self.virtual = torch.empty(max(V, 1), H, dtype=sdt, device=dev) if model.compute_virtual else None
         # the virtual branch rides on the two launches as extra workgroups while they land on idle CUs
-        self.idle_cus = bool(model.compute_virtual and model.overlap_virtual and V > 0
-                             and 2 * B <= _engine._cu_count(dev))
-        self.defer = self.idle_cus and L >= 2      # (the launch PAIR splits the branch only when it has a layer 1)
+        cus = _engine._cu_count(dev)
+        self.defer = bool(model.compute_virtual and model.overlap_virtual and V > 0 and L >= 2 and 2 * B <= cus)
+        # the one-launch step's virtual workgroups also fit beside small graphs' 4-wave workgroups (several per CU)
+        per_cu = int(_hip.lib().hscn_resident_train_step_wgs_per_cu(F, H, L, C, meta.max_n, meta.max_ell, meta.max_v,
+                                                                    meta.max_evv))
+        self.idle_cus = bool(model.compute_virtual and model.overlap_virtual and V > 0 and 2 * B <= cus * max(per_cu, 1))
         self._state = None
         if self.defer:
             self._state = (torch.empty(V + B, **i32), torch.empty(max(E_lv, 1), **i32), torch.empty(V + B, **i32),

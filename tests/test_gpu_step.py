@@ -190,6 +190,8 @@ def test_scn_direct_step_is_the_autograd_step_bit_for_bit():
                                                   ("peptides_func", 100, 16, 16, 3, 10, torch.float16),
                                                   ("peptides_struct", 32, 32, 16, 2, 11, torch.float32),
                                                   ("pcqm_contact", 120, 16, 32, 3, 1, torch.float32),
+                                                  ("pcqm_contact", 256, 16, 16, 3, 1, torch.float16),   # 512 workgroups: CUs shared
+                                                  ("pcqm_contact", 400, 16, 16, 2, 1, torch.float32),
                                                   ("peptides_func", 24, 4, 16, 1, 10, torch.float32)])
 def test_one_launch_step_against_the_launch_pair_at_full_occupancy(name, B, K, H, L, C, dtype):
     """The one-launch step with every CU busy (up to 2B = 256 workgroups: B local programs, B virtual-branch
