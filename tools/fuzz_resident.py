@@ -2,7 +2,7 @@
 """Randomised parity run of the graph-resident HSCN step against the CPU oracle: random graph sizes and edge
 lists (self loops, repeated edges, isolated nodes, hubs, asymmetric edges), random K / H / L / C / activation,
 both launch shapes (virtual branch fused into the forward, or riding on the two launches), loss tail on the
-backward launch.  Not part of the test suite (minutes of oracle time); prints one line per case.
+backward launch, and the one-launch training step (structure built per step and pre-built).  Not part of the test suite (minutes of oracle time); prints one line per case.
 
   python tools/fuzz_resident.py [cases] [seed]
 """
@@ -87,6 +87,26 @@ def run(cases, seed, verbose=True):
         xo = ob["x_dict"]
         for conv in om.convs:
             xo = {k: v.relu() for k, v in conv(xo, ob["edge_index_dict"]).items()}
+        # float64 referee for the virtual features (two float32 evaluations of one function: tests/test_gpu_resident.py)
+        import copy
+        with torch.no_grad():
+            x64 = {k: v.double() for k, v in ob["x_dict"].items()}
+            for conv in copy.deepcopy(om).double().convs:
+                x64 = {k: v.relu() for k, v in conv(x64, ob["edge_index_dict"]).items()}
+        v64 = x64["virtual"]
+
+        def virtual_ok(xv):
+            """1e-5 of the features' magnitude, or -- where float32 itself is further than that from the true value --
+            no further from the float64 evaluation than the float32 oracle is (+ 4 ulp of the magnitude)."""
+            ref_v = xo["virtual"]
+            got = xv[: ref_v.size(0)].detach().cpu().double()
+            scale = max(1.0, float(v64.abs().max()))
+            d = float((got - ref_v.double()).abs().max())
+            if d <= 1e-5 * scale:
+                return True, d
+            e_hip = float((got - v64).abs().max())
+            e_o32 = float((ref_v.detach().double() - v64).abs().max())
+            return e_hip <= e_o32 + 4 * 2.0 ** -23 * scale, d
         msgs = []
         for overlap in (False, True):
             pm.overlap_virtual, pm.keep_virtual = overlap, not overlap
@@ -117,9 +137,7 @@ def run(cases, seed, verbose=True):
             if xv is not None and xo["virtual"].size(0) > 0:
                 # 1e-5 relative to the magnitude of the features (tests/helpers.py::scale_close; HIP is shown to be as
                 # close to float64 as the float32 oracle in tests/test_gpu_resident.py)
-                ref_v = xo["virtual"]
-                d = float((xv[: ref_v.size(0)].detach().cpu() - ref_v).abs().max())
-                ok = d <= 1e-5 * max(1.0, float(ref_v.abs().max()))
+                ok, d = virtual_ok(xv)
                 if not ok:
                     msgs.append(f"virtual overlap={overlap} maxdiff {d:.2e}")
             for (n_, po), (_, pd) in zip(om.named_parameters(), pm.named_parameters()):
@@ -130,6 +148,37 @@ def run(cases, seed, verbose=True):
                 ok, d = close(pd.grad, po.grad, 1e-5, 2e-3)
                 if not ok:
                     msgs.append(f"grad {n_} overlap={overlap} maxdiff {d:.2e} (ref max {float(po.grad.abs().max()):.2e})")
+        # the same step as ONE launch (graph_hscn.step.ResidentTrainStep: forward, loss row and backward of a graph in
+        # one workgroup, virtual branch on its own workgroups through the in-launch hand-off), building its structure
+        # per step and loading it pre-built: against the oracle at the tolerances above
+        if not msgs:
+            from graph_hscn.step import ResidentTrainStep
+            pm.overlap_virtual, pm.keep_virtual = True, False
+            for mode in ("per-step", "dataset-resident"):
+                try:
+                    rs = ResidentTrainStep(pm, pb, loss_fn, one_launch=True,
+                                           structure=engine.build_structure(pb) if mode == "dataset-resident" else None)
+                except RuntimeError:
+                    break                                # H = 64 / graphs beyond its LDS layout: the launch pair is the route
+                rs.bind_grads()
+                rs.run()
+                torch.cuda.synchronize()
+                rs.check()
+                ok, d = close(rs.pred, out_o, 1e-5, 1e-5)
+                if not ok:
+                    msgs.append(f"one-launch ({mode}) pred maxdiff {d:.2e}")
+                if abs(float(rs.loss) - float(lo.detach())) > 1e-5 * max(1.0, abs(float(lo.detach()))):
+                    msgs.append(f"one-launch ({mode}) loss {float(rs.loss)} vs {float(lo.detach())}")
+                if rs.virtual is not None and xo["virtual"].size(0) > 0 and rs.idle_cus:
+                    ok, d = virtual_ok(rs.virtual)
+                    if not ok:
+                        msgs.append(f"one-launch ({mode}) virtual maxdiff {d:.2e}")
+                for (n_, po), (_, pd) in zip(om.named_parameters(), pm.named_parameters()):
+                    if po.grad is None:
+                        continue
+                    ok, d = close(pd.grad, po.grad, 1e-5, 2e-3)
+                    if not ok:
+                        msgs.append(f"one-launch ({mode}) grad {n_} maxdiff {d:.2e} (ref max {float(po.grad.abs().max()):.2e})")
         is_refusal = bool(msgs) and msgs[0].startswith("refused")
         tag = "ok " if not msgs else ("REFUSED" if is_refusal else "BAD")
         bad += bool(msgs) and not is_refusal
