@@ -153,6 +153,35 @@ class StaticHeteroBatch:
         return self.batch
 
 
+def capture_optimizer_step(params, optimizer, warmup: int = 3) -> "torch.cuda.CUDAGraph":
+    """``optimizer.step()`` (an optimizer built with ``capturable=True``; ``fused=True`` keeps it to one launch) on
+    the gradient buffers ``p.grad`` points at NOW, as a hipGraph of its own.  The warm-up steps PyTorch's capture
+    recipe asks for are undone: parameters and optimizer state are put back in place (state the warm-up created is
+    zeroed: the initial state of the Adam family)."""
+    params = list(params)
+    snap_p = [p.detach().clone() for p in params]
+    snap_s = {id(p): {k: v.clone() for k, v in st.items() if isinstance(v, Tensor)} for p, st in optimizer.state.items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            optimizer.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        optimizer.step()
+    with torch.no_grad():
+        for p, s0 in zip(params, snap_p):
+            p.copy_(s0)
+        for p, st in optimizer.state.items():
+            for k, v in st.items():
+                if isinstance(v, Tensor):
+                    old = snap_s.get(id(p), {}).get(k)
+                    v.copy_(old) if old is not None else v.zero_()
+    return g
+
+
 class CapturedStep:
     """``zero grads -> model(batch) -> criterion -> backward`` captured once on ``static.batch``.
     ``replay()`` runs it on whatever was last loaded; ``loss`` / ``pred`` / ``score`` are the captured

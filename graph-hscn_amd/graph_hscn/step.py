@@ -224,6 +224,32 @@ class ResidentTrainStep:
         self.meta.check()
 
 
+class ScnWorkspace:
+    """Output / scratch buffers of the stage-A launches sized for the largest step of a loop, shared by all of its
+    ``ScnTrainStep`` objects (a step uses a prefix): one set of gradient buffers means one captured optimizer step
+    serves every graph of the reference's one-optimizer-step-per-graph loop (train/train_clustering.py:36-50)."""
+
+    def __init__(self, device, max_nodes: int, max_edges: int, max_graphs: int, F: int, H: int, K: int,
+                 dtype=torch.float32):
+        f32 = dict(dtype=torch.float32, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        N, E, B = max(int(max_nodes), 1), max(int(max_edges), 1), max(int(max_graphs), 1)
+        self.cap = (N, E, B)
+        self.S = torch.empty(N, K, **f32)
+        self.y = torch.empty(N, H, dtype=dtype, device=device)
+        self.stats = torch.empty(B, 4, **f32)
+        self.ss = torch.empty(B, K, K, **f32)
+        self.losses = torch.empty(3, **f32)
+        self.ex = (torch.empty(N + B, **i32), torch.empty(E, **i32), torch.empty(N + B, **i32), torch.empty(E, **i32),
+                   torch.empty(N, 16, **f32), torch.empty(N, **f32))
+        P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
+        self.partials = torch.empty(B, P, **f32)
+        self.grads = torch.zeros(P, **f32)
+        self.one = torch.ones(1, **f32)
+        self.ticket = torch.zeros(1, **i32)
+        self.flag = torch.zeros(1, **i32)
+
+
 class ScnTrainStep:
     """``optimizer.zero_grad(); S, mc, o = model.forward_graphs(data); (mc + o).backward()`` -- the body of
     the reference's clustering loop (train/train_clustering.py:37-49) for one ``Data`` graph or a block-diagonal
@@ -232,7 +258,7 @@ class ScnTrainStep:
     Outputs refreshed by ``run()``: ``S`` [N,K] (softmax assignment), ``losses`` [3] = {mincut, ortho, their sum},
     ``grads`` (flat: W_rel, b_rel, W_root, W_mlp, b_mlp)."""
 
-    def __init__(self, model, data):
+    def __init__(self, model, data, workspace: Optional[ScnWorkspace] = None):
         from .model.hscn import SCN
         if not isinstance(model, SCN):
             raise TypeError("ScnTrainStep drives graph_hscn.model.hscn.SCN")
@@ -253,21 +279,17 @@ class ScnTrainStep:
         H, K = conv.lin_rel.weight.shape[0], lin.weight.shape[0]
         B, E = meta.num_graphs, self.ei.size(1)
         self.dims = (N, F, H, K, B, E)
-        f32 = dict(dtype=torch.float32, device=dev)
-        i32 = dict(dtype=torch.int32, device=dev)
-        self.S = torch.empty(N, K, **f32)
-        self.y = torch.empty(N, H, dtype=self.x.dtype, device=dev)
-        self.stats = torch.empty(B, 4, **f32)
-        self.ss = torch.empty(B, K, K, **f32)
-        self.losses = torch.empty(3, **f32)
-        if meta.ticket is None:
-            meta.ticket = torch.zeros(1, **i32)
-        self.ex = (torch.empty(N + B, **i32), torch.empty(max(E, 1), **i32), torch.empty(N + B, **i32),
-                   torch.empty(max(E, 1), **i32), torch.empty(max(N, 1), 16, **f32), torch.empty(max(N, 1), **f32))
-        P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
-        self.partials = torch.empty(B, P, **f32)
-        self.grads = torch.zeros(P, **f32)
-        self.one = torch.ones(1, **f32)
+        ws = workspace if workspace is not None else ScnWorkspace(dev, N, E, B, F, H, K, self.x.dtype)
+        if N > ws.cap[0] or E > ws.cap[1] or B > ws.cap[2] or ws.y.dtype != self.x.dtype:
+            raise ValueError("the shared workspace is smaller than this step (or of another storage type)")
+        self.workspace = ws
+        if workspace is not None:        # the loop's steps share one ticket / flag word as well
+            meta.ticket, meta.flag = ws.ticket, ws.flag
+        elif meta.ticket is None:
+            meta.ticket = ws.ticket
+        self.S, self.y, self.stats, self.ss = ws.S[:N], ws.y[:N], ws.stats[:B], ws.ss[:B]
+        self.losses, self.ex, self.partials, self.grads, self.one = ws.losses, ws.ex, ws.partials, ws.grads, ws.one
+        P = int(self.grads.numel())
         views, off = [], 0
         for p in self._mp:
             views.append((p, self.grads[off: off + p.numel()].view_as(p)))
@@ -296,6 +318,17 @@ class ScnTrainStep:
              ptr(W_mlp), ptr(self.S), ptr(self.y), ptr(self.stats), ptr(self.ss), ptr(self.one), ptr(self.one),
              *[ptr(t) for t in self.ex], m.max_n, m.max_e, ptr(self.partials), ptr(self.grads), ptr(m.flag), st)
         return self.losses[2]
+
+    def run_forward(self) -> Tensor:
+        """The forward launch alone (the assignment pass, train/train_clustering.py:57-69): refreshes ``S``."""
+        N, F, H, K, B, E = self.dims
+        m = self.meta
+        W_rel, b_rel, W_root, W_mlp, b_mlp = (p.contiguous() for p in self._mp)
+        call("hscn_scn_resident_fwd" + self._sfx, ptr(self.x), ptr(self.ei) if E else None, E, ptr(m.nptr), ptr(m.eptr),
+             N, B, F, H, K, self.act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), m.max_n, m.max_e,
+             ptr(self.S), ptr(self.y), ptr(self.stats), ptr(self.ss), ptr(self.losses), ptr(m.ticket),
+             *([None] * 6), ptr(m.flag), stream())
+        return self.S
 
     def check(self) -> None:
         self.meta.check()

@@ -59,11 +59,73 @@ def _forward(model: SCN, graphs: Sequence, device, cache: dict = None, key=None)
     return model(big.x.to(device).float(), ei, ew, node_ptr=ptr), big.ptr
 
 
+def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, batch_graphs: int, device):
+    """The same loop with every step issued as direct C-ABI launches (``step.ScnTrainStep`` on one shared workspace:
+    forward launch, backward launch + ordered reduction) followed by ONE replay of the captured optimizer step --
+    three host calls per step instead of an autograd graph and an eager ``optimizer.step()`` (~170 us of Python per
+    graph).  Same schedule, same arithmetic: the reference's trajectory (tests/test_gpu_pipeline.py::
+    test_stage_a_driver_follows_the_reference_trajectory).  Returns None when the model / optimizer / graphs do not
+    qualify (the caller then takes the autograd loop)."""
+    from ..replay import capture_optimizer_step
+    from ..step import ScnTrainStep, ScnWorkspace
+    n = len(dataset)
+    groups = [[dataset[j] for j in range(i, min(i + batch_graphs, n))] for i in range(0, n, batch_graphs)]
+    datas = [g[0] if len(g) == 1 else Batch.from_data_list(g) for g in groups]
+    if any(getattr(d, "edge_weight", None) is not None for d in datas) or not all(model.resident_ok(d) for d in datas):
+        return None
+    try:
+        optimizer = OPTIM_DICT[optim_cfg.optim_type](model.parameters(), lr=optim_cfg.lr,
+                                                      weight_decay=optim_cfg.weight_decay, capturable=True, fused=True)
+    except (TypeError, RuntimeError):
+        return None                          # (Adagrad has no capturable step)
+    conv, lin = model.mp.module_0, list(model.mlp)[0]
+    H, F = conv.lin_rel.weight.shape
+    K = lin.weight.shape[0]
+    ws = ScnWorkspace(device, max(int(d.num_nodes) for d in datas), max(int(d.edge_index.size(1)) for d in datas),
+                      max(len(g) for g in groups), F, H, K)
+    steps = []
+    for d in datas:                          # the graphs go to the device once (the loop revisits them every epoch)
+        d = d.to(device)
+        d.x = d.x.float()
+        steps.append(ScnTrainStep(model, d, workspace=ws))
+    steps[0].bind_grads()                    # one set of gradient buffers for every step
+    opt_graph = capture_optimizer_step(model.parameters(), optimizer)
+    for epoch in range(model_cfg.cluster_epochs):
+        if logger is not None:
+            logger.info(f"Fitting clustering, epoch {epoch}...")
+        for st in steps:                     # train_clustering.py:36-50: one optimizer step per graph (or per batch)
+            st.run()
+            opt_graph.replay()
+    if logger is not None:
+        logger.info("Generating cluster assignments...")
+    ids_dev = []
+    with torch.no_grad():                    # train_clustering.py:57-69 (one read-back for the whole pass)
+        for st in steps:
+            st.run_forward()
+            ids_dev.append(_assign(st.S))
+    torch.cuda.synchronize(device)
+    steps[0].check()
+    out: List[np.ndarray] = []
+    for d, ids in zip(datas, ids_dev):
+        ids = ids.cpu().numpy()
+        if "ptr" in d and d.ptr is not None:
+            p = d.ptr.cpu().numpy()
+            out.extend(ids[p[k]:p[k + 1]] for k in range(len(p) - 1))
+        else:
+            out.append(ids)
+    model.last_engine = "resident"
+    return out
+
+
 def train_clustering(logger, dataset, model: SCN, model_cfg, optim_cfg, training_cfg,
-                     batch_graphs: int = 1) -> List[np.ndarray]:
+                     batch_graphs: int = 1, direct: bool = True) -> List[np.ndarray]:
     device = next(model.parameters()).device
     if device.type != "cuda":
         raise RuntimeError("train_clustering runs on the MI355X HIP path: move the SCN to 'cuda'")
+    if direct:
+        done = _train_clustering_direct(logger, dataset, model, model_cfg, optim_cfg, batch_graphs, device)
+        if done is not None:
+            return done
     optimizer = OPTIM_DICT[optim_cfg.optim_type](lr=optim_cfg.lr, weight_decay=optim_cfg.weight_decay,
                                                  params=model.parameters())
     n = len(dataset)

@@ -32,7 +32,18 @@ def main(G=1024, epochs=5, K=16):
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         assert len(ids) == G
-        out[f"batch_graphs={bg}"] = {"seconds": t, "graph_visits_per_s": G * (epochs + 1) / t}
+        # steady state: the difference of two runs that differ in the number of epochs only (setup -- uploading the
+        # graphs, building the per-step objects, capturing the optimizer step -- cancels)
+        mc2 = HSCNConfig("relu", num_clusters=K, cluster_epochs=3 * epochs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        train_clustering(None, graphs, scn, mc2, oc, tc, batch_graphs=bg)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t0
+        per_visit = (t2 - t) / (2 * epochs * G)
+        out[f"batch_graphs={bg}"] = {"seconds": t, "graph_visits_per_s": G * (epochs + 1) / t,
+                                     "steady_state_us_per_graph_visit": per_visit * 1e6,
+                                     "steady_state_graphs_per_s": 1.0 / per_visit}
     print(json.dumps(out))
 
 
