@@ -62,13 +62,23 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   constexpr size_t GSCR = 4096;
   const int KF = K > FP ? K : FP;
   const size_t xa = (size_t)2 * max_n * FP, sk0 = (size_t)max_n * (bwd ? KF : K), sk = (bwd && sk0 < GSCR) ? GSCR : sk0;
-  Y.R1 = take(bwd ? sk : (xa > sk ? xa : sk));
+  const size_t sks = (size_t)max_n * K + GSCR;          // the one-launch step: S and, behind it, the tile scratch of S^T S
+  // (forward launch: the per-wave S^T S tiles of scn_softmax are parked behind S as well when K <= 16)
+  const size_t r1f = (xa > sk ? xa : sk), r1s = (K <= 16 || bwd == 2) ? (r1f > sks ? r1f : sks) : r1f;
+  Y.R1 = take(bwd == 1 ? sk : r1s);
   const size_t st = (size_t)2 * (((size_t)max_e + 3) / 4 * 4);
   const size_t yh0 = (size_t)max_n * H, yh = (!bwd && yh0 < GSCR) ? GSCR : yh0;
+  const size_t bs = (size_t)2 * (max_n + 1) + (size_t)2 * max_e + 16;   // the CSR builders' scratch (step: inside R3)
   Y.R2 = take(yh > st ? yh : st);                      // y; the staged COO slice overlays it first
   Y.ek = Y.R2;
   Y.eo = Y.R2 + ((size_t)max_e + 3) / 4 * 4;
-  Y.R3 = take(bwd ? sk : 0);
+  size_t r3 = bwd == 2 ? (sk > bs ? sk : bs) : bwd ? sk : 0;
+  if (bwd == 2) {   // S | y | dlogits (contiguous) later hold the 16 waves' gradient partials of scn_bwd_tiles
+    const size_t NT = ((size_t)K + 15) / 16, TD = (size_t)H / 16;
+    const size_t need = 16 * ((NT * TD + 2 * TD) * 256 + 16 * NT + H), have = (o - Y.R1) + r3;
+    if (have < need) r3 += need - have;
+  }
+  Y.R3 = take(r3);
   Y.dinv = take(max_n);
   Y.dout = take(max_n);
   Y.wt = take((size_t)2 * H * FP + H + (size_t)K * H + K + (size_t)K * K);  // W_rel^T | W_root^T | b_rel | W_mlp^T | b_mlp | Gss
@@ -82,6 +92,11 @@ __host__ __device__ inline ScnLayout scn_layout(int H, int K, int max_n, int max
   Y.tmp = take(bwd ? 0 : max_e);
   Y.cursor2 = take(bwd ? 0 : max_n + 1);
   Y.tmp2 = take(bwd ? 0 : max_e);
+  if (bwd == 2) {   // the step builds them in R3 (dlogits are not live before the backward half)
+    size_t q = Y.R3;
+    auto sub = [&](size_t n) { size_t r = q; q += (n + 3) & ~(size_t)3; return r; };
+    Y.cursor = sub(max_n + 1); Y.tmp = sub(max_e); Y.cursor2 = sub(max_n + 1); Y.tmp2 = sub(max_e);
+  }
   Y.wsum = take(32);
   Y.ssl = take(bwd ? (size_t)K * K : 0);   // the forward's S^T S, fetched with the rest of the front
   Y.total = o;
@@ -117,7 +132,7 @@ __device__ void gram_mfma(const float* Am, int lda, int O, const float* Bm, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) scratch[(rg * TPP + tl) * 256 + (lj * 4 + r) * 16 + li] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
     for (int idx = threadIdx.x; idx < TPP * 256; idx += SRT) {
       const int t_ = t0 + idx / 256, e_ = idx & 255;
       if (t_ < NT) {
@@ -127,7 +142,7 @@ __device__ void gram_mfma(const float* Am, int lda, int O, const float* Bm, int 
         if (oo < O && kk < kmax) out[(size_t)oo * ldo + kk] = s_;
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -144,7 +159,7 @@ __device__ void col_sum(const float* M, int ld, int C, int n, float* out, float*
       s_ = wave_sum(s_);
       if (lane == 0) out[c] = s_;
     }
-    __syncthreads();
+    lds_barrier();
     return;
   }
   const int LQ = C / 4, SQ = 64 / LQ;                 // lanes per row, row slots per wave
@@ -161,7 +176,7 @@ __device__ void col_sum(const float* M, int ld, int C, int n, float* out, float*
     acc.w += __shfl_xor(acc.w, o_, 64);
   }
   if (slot == 0) *reinterpret_cast<float4*>(scratch + wave * C + f) = acc;
-  __syncthreads();
+  lds_barrier();
   for (int c = threadIdx.x; c < C; c += SRT) {
     float s_ = 0.f;
     for (int w = 0; w < NW; ++w) s_ += scratch[w * C + c];
@@ -192,8 +207,10 @@ __device__ __forceinline__ void scn_losses_wave(const float* stats, float* losse
   const int lane = threadIdx.x & 63;
   float mc = 0.f, o = 0.f;
   for (int g = lane; g < G; g += 64) {
-    mc += -(stats[(size_t)g * 4 + 0] / stats[(size_t)g * 4 + 1]);
-    o += stats[(size_t)g * 4 + 3];
+    const float num = __hip_atomic_load(stats + (size_t)g * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float den = __hip_atomic_load(stats + (size_t)g * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mc += -(num / den);
+    o += __hip_atomic_load(stats + (size_t)g * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   mc = wave_sum(mc);
   o = wave_sum(o);
@@ -370,6 +387,334 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   STAMP(3);
 }
 
+// ---- forward middle: shared by the forward launch and the one-launch step -------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One 16 x 16 output tile on v_mfma_f32_16x16x4_f32: acc[r] <-> (tile row 4 * lj + r, tile column li)
+//   acc += sum_{k' < Kc} A[li][k'] * B[k'][bcol]
+// The contraction index is dealt to the four lane groups in contiguous runs (lane group lj: k' in
+// [KSp * lj, KSp * (lj + 1)), KSp = the padded quarter), so a lane's A operands are float4 pieces of ONE row:
+// 16 rows x 64 bytes per instruction, conflict free.  Arow = the lane's row (16-byte aligned) or nullptr (a row
+// outside the graph: zeros); Kc % 4 == 0.  B[k'][c] = Bm[k' * bsk + c * bsc]; bok: the lane's column exists.
+__device__ __forceinline__ f32x4 tile_mm(const float* Arow, int Kc, const float* Bm, int bsk, int bsc, int bcol,
+                                         bool bok, f32x4 acc) {
+  const int lj = (threadIdx.x & 63) >> 4;
+  const int KSp = ((Kc + 15) >> 4) << 2;
+  const int kb = KSp * lj;
+  for (int q = 0; q < KSp; q += 4) {
+    const int k0 = kb + q;
+    const bool kok = k0 < Kc;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (Arow && kok) a = *reinterpret_cast<const float4*>(Arow + k0);
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (bok && kok) {
+      const float* bp = Bm + (size_t)k0 * bsk + (size_t)bcol * bsc;
+      b0 = bp[0]; b1 = bp[bsk]; b2 = bp[2 * bsk]; b3 = bp[3 * bsk];
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// y = act((agg W_rel^T + b_rel) + x W_root^T) for the 16 rows of tile rt, off the matrix cores.  KEEP: also hand
+// back x and agg of the tile as the B operands of the backward's weight-gradient products (xb / ab [s] = element
+// (row 4 * lj + s, feature li): the row order tile_mm's accumulators have), so the backward half needs no copy
+// of x / agg in LDS.
+template <int H, typename TS, bool KEEP>
+__device__ __forceinline__ void scn_hidden_tile(const ScnArgs& A, int rt, const float* xs, const float* agg, float* yl,
+                                                const float* WrT, const float* WoT, const float* brl, int n0, int n,
+                                                float (&xb)[4], float (&ab)[4]) {
+  constexpr int TD = H / 16;
+  const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int r0 = rt * 16;
+  const bool rowok = r0 + li < n;
+  const float* ar = rowok ? agg + (r0 + li) * FP : nullptr;
+  const float* xr = rowok ? xs + (r0 + li) * FP : nullptr;
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a1 = tile_mm(ar, FP, WrT, H, 1, ct * 16 + li, true, z);
+    const f32x4 a2 = tile_mm(xr, FP, WoT, H, 1, ct * 16 + li, true, z);
+    const float b = brl[ct * 16 + li];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + lj * 4 + r;
+      if (row < n) {
+        const float v = rnd<TS>(apply_act((a1[r] + b) + a2[r], A.act));   // the hidden activation as its storage type holds it
+        yl[row * H + ct * 16 + li] = v;
+        if (A.y) stf(reinterpret_cast<TS*>(A.y), (size_t)(n0 + row) * H + ct * 16 + li, v);
+      }
+    }
+  }
+  if (KEEP) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const int j = r0 + 4 * lj + s_;
+      xb[s_] = j < n ? xs[j * FP + li] : 0.f;
+      ab[s_] = j < n ? agg[j * FP + li] : 0.f;
+    }
+  }
+}
+
+// all tiles of the graph, a wave owns tiles wave, wave + NW, ...  Ends without a barrier.
+template <int H, typename TS>
+__device__ __forceinline__ void scn_hidden(const ScnArgs& A, const float* xs, const float* agg, float* yl,
+                                           const float* WrT, const float* WoT, const float* brl, int n0, int n) {
+  constexpr int NW = SRT / 64;
+  const int ntile = (n + 15) >> 4;
+  float d0[4], d1[4];
+  for (int rt = threadIdx.x >> 6; rt < ntile; rt += NW)
+    scn_hidden_tile<H, TS, false>(A, rt, xs, agg, yl, WrT, WoT, brl, n0, n, d0, d1);
+}
+
+// logits = y W_mlp^T + b_mlp off the matrix cores, softmax over the K columns in the accumulators (a row's
+// columns sit in the 16 lanes of a DPP row and up to four column tiles).  S may overlay x / agg (dead), never
+// y.  No barrier.
+// K <= 16 (one column tile): the softmax values are, as they sit in the accumulators, both operands of S^T S =
+// sum_rows S[row][a] S[row][b]; the wave adds its tiles' contribution on the spot and parks its 16 x 16 partial
+// in ss_part [NW][256] (the caller folds the first min(ntile, NW) of them in wave order behind its next barrier).
+template <int H>
+__device__ __forceinline__ void scn_softmax(const ScnArgs& A, const float* yl, float* Sl, const float* WmT,
+                                            const float* bml, int n0, int n, float* ss_part) {
+  constexpr int NW = SRT / 64;
+  const int K = A.K, NT = (K + 15) >> 4;
+  const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int ntile = (n + 15) >> 4;
+  f32x4 ssacc = {0.f, 0.f, 0.f, 0.f};
+  for (int rt = threadIdx.x >> 6; rt < ntile; rt += NW) {
+    const int r0 = rt * 16;
+    const float* yr = r0 + li < n ? yl + (r0 + li) * H : nullptr;
+    float sc[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = nt * 16 + li;
+      const bool cok = nt < NT && col < K;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (nt < NT) acc = tile_mm(yr, H, WmT, K, 1, col, cok, acc);
+      const float bk = cok ? bml[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[nt][r] = cok ? acc[r] + bk : -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + lj * 4 + r;
+      float m = fmaxf(fmaxf(sc[0][r], sc[1][r]), fmaxf(sc[2][r], sc[3][r]));
+      m = row16_max(m);
+      float ex[4], sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        ex[nt] = (nt < NT && nt * 16 + li < K) ? expf(sc[nt][r] - m) : 0.f;
+        sum += ex[nt];
+      }
+      sum = row16_sum(sum);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = nt * 16 + li;
+        float v = 0.f;
+        if (nt < NT && col < K && row < n) {
+          v = ex[nt] / sum;
+          Sl[row * K + col] = v;
+          if (A.S) A.S[(size_t)(n0 + row) * K + col] = v;
+        }
+        if (nt == 0 && NT == 1) ssacc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, ssacc, 0, 0, 0);
+      }
+    }
+  }
+  if (NT == 1 && (int)(threadIdx.x >> 6) < ntile) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss_part[(threadIdx.x >> 6) * 256 + (lj * 4 + r) * 16 + li] = ssacc[r];
+  }
+}
+
+// sum_{p in [s, t)} of the float4 at M[col[p] * ld], added in p order (four column / row reads of a trip in flight)
+__device__ __forceinline__ float4 gather_sum4(const int* col, int s, int t, const float* M, int ld) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p0 = s; p0 < t; p0 += 4) {
+    int j[4];
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) j[u] = (p0 + u < t) ? col[p0 + u] : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(M + j[u] * ld);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u < t) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  }
+  return a;
+}
+
+// sum over idx = lane, lane + 64, ... < KK of f(idx), added in idx order; four terms are evaluated side by side
+// (their divisions overlap) before they are added
+template <typename Fn>
+__device__ __forceinline__ float lane_strided_sum(int KK, Fn f) {
+  const int lane = threadIdx.x & 63;
+  float v = 0.f;
+  for (int base = 0; base < KK; base += 256) {
+    float t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + 64 * u + lane;
+      t[u] = idx < KK ? f(idx) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v += t[u];
+  }
+  return v;
+}
+
+// the statistics of graph g to HBM and, with a ticket counter, the batch losses by the workgroup that takes the last
+// ticket: it sums the per-graph statistics in graph order (the order, hence the result, does not depend on who it
+// is).  Wave 0 only.  The statistics are write-through (sc1) stores drained before the ticket is taken and are read
+// back with agent-scope loads (cdna_hip_programming.md Guideline 16), so no agent-scope fence -- an L2 write-back
+// and invalidate, microseconds at the end of every workgroup -- is needed on either side.
+__device__ __forceinline__ void scn_stats_publish(const ScnArgs& A, int g, float num, float den, float nrm, float o) {
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) {
+    stf_sc1(A.stats, (size_t)g * 4 + 0, num);
+    stf_sc1(A.stats, (size_t)g * 4 + 1, den);
+    stf_sc1(A.stats, (size_t)g * 4 + 2, nrm);
+    stf_sc1(A.stats, (size_t)g * 4 + 3, o);
+  }
+  if (A.ticket) {
+    int last = 0;
+    if (lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = __hip_atomic_fetch_add(A.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.B - 1;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the ticket)
+      scn_losses_wave(A.stats, A.losses, A.B);
+      if (lane == 0) __hip_atomic_store(A.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// <Gq, ss> of the orthogonality backward (wave 0; every lane receives it)
+__device__ __forceinline__ float scn_ortho_inner(const float* ssl, int K, float nrm, float o) {
+  const float isk = 1.0f / sqrtf((float)K);
+  float v = 0.f;
+  if (o > 0.f)
+    v = lane_strided_sum(K * K, [&](int i) {
+      const int a = i / K, b = i - a * K;
+      return ((ssl[i] / nrm - (a == b ? isk : 0.f)) / o) * ssl[i];
+    });
+  return wave_sum(v);
+}
+
+// MinCUT statistics on the binary A + I
+//   num = sum_i S_i . (sum_{p in row_s(i)} S[col] + S_i),  den = sum_i dout_i |S_i|^2,  ss = S^T S -> ssl [K][K] (LDS)
+// then stats[g] = {num, den, |ss|_F, ortho}.  `scratch`: 16 x 256 words (K <= 16: the tiles scn_softmax parked).
+// K % 4 == 0: a wave owns 16-row tiles, lane (li = row, lj = a float4 of columns) walks the row's neighbours once
+// for four columns.  STEP (the one-launch step): the backward's neighbour term
+//   T = (A S)_i + (A^T S)_i + 2 S_i      (K % 4 == 0; otherwise the raw (A S)_i, the tail adds the rest)
+// is kept in as_out [n][K] and the statistics are published by the caller after the backward half.  Every thread
+// receives the statistics and the backward's <Gq, ss> in R.  Ends behind a barrier.
+struct ScnStats { float num, den, nrm, o, inner; };
+template <int NW, bool STEP>
+__device__ __forceinline__ void scn_stats(const ScnArgs& A, const float* Sl, const int* rowptr_s, const int* col_s,
+                                          const int* rowptr_d, const int* col_d, const float* dout, float* red,
+                                          float* scratch, float* ssl, ScnStats& R, float* as_out, int n, int g) {
+  const int K = A.K, KK = K * K;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    float num = 0.f, den = 0.f;
+    if ((K & 3) == 0) {
+      const int li = lane & 15, lj = lane >> 4, CG = K >> 2, ntile = (n + 15) >> 4;
+      for (int rt = wave; rt < ntile; rt += NW) {
+        const int i = rt * 16 + li;
+        if (i < n) {
+          const int ps = rowptr_s[i], pe = rowptr_s[i + 1];
+          int qs = 0, qe = 0;
+          if (STEP) { qs = rowptr_d[i]; qe = rowptr_d[i + 1]; }
+          const float di = dout[i];
+          for (int cg = lj; cg < CG; cg += 4) {
+            const float4 sv = *reinterpret_cast<const float4*>(Sl + i * K + 4 * cg);
+            float4 as = gather_sum4(col_s, ps, pe, Sl + 4 * cg, K);
+            if (STEP) {
+              const float4 ad = gather_sum4(col_d, qs, qe, Sl + 4 * cg, K);
+              float4 t = as;
+              t.x += ad.x; t.y += ad.y; t.z += ad.z; t.w += ad.w;
+              t.x += 2.f * sv.x; t.y += 2.f * sv.y; t.z += 2.f * sv.z; t.w += 2.f * sv.w;
+              *reinterpret_cast<float4*>(as_out + i * K + 4 * cg) = t;
+            }
+            as.x += sv.x; as.y += sv.y; as.z += sv.z; as.w += sv.w;
+            num = fmaf(sv.x, as.x, num); num = fmaf(sv.y, as.y, num);
+            num = fmaf(sv.z, as.z, num); num = fmaf(sv.w, as.w, num);
+            den = fmaf(di, sv.x * sv.x, den); den = fmaf(di, sv.y * sv.y, den);
+            den = fmaf(di, sv.z * sv.z, den); den = fmaf(di, sv.w * sv.w, den);
+          }
+        }
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < n * K; idx += SRT) {
+        const int i = idx / K, k = idx - i * K;
+        const float sv = Sl[idx];
+        float as = gather_sum(col_s, rowptr_s[i], rowptr_s[i + 1], Sl, K, k);
+        if (STEP) as_out[idx] = as;
+        as += sv;
+        num = fmaf(sv, as, num);
+        den = fmaf(dout[i], sv * sv, den);
+      }
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if (lane == 0) { red[wave] = num; red[16 + wave] = den; }
+  }
+  // ss = S^T S: K <= 16 -- the per-wave tiles scn_softmax parked in `scratch`, folded in wave order; otherwise
+  // through the tile outer product
+  if (K <= 16) {
+    const int ntile = (n + 15) >> 4, NWA = ntile < NW ? ntile : NW;
+    for (int e = threadIdx.x; e < 256; e += SRT) {
+      float v = 0.f;
+      for (int w = 0; w < NWA; ++w) v += scratch[w * 256 + e];
+      const int a = e >> 4, b = e & 15;
+      if (a < K && b < K) ssl[a * K + b] = v;
+    }
+    lds_barrier();
+  } else {
+    gram_mfma<NW>(Sl, K, K, Sl, K, K, n, scratch, ssl, K, K);
+    lds_barrier();
+  }
+  STAMP(6);
+  if (A.ss)
+    for (int idx = threadIdx.x; idx < KK; idx += SRT) A.ss[(size_t)g * KK + idx] = ssl[idx];
+  // norms by the whole workgroup, two rounds (|ss|_F, then everything that needs it); every thread ends with
+  // the same values (ordered sums of the 16 wave partials)
+  {
+    float p2 = 0.f;
+    for (int idx = threadIdx.x; idx < KK; idx += SRT) p2 += ssl[idx] * ssl[idx];
+    p2 = wave_sum(p2);
+    if (lane == 0) red[32 + wave] = p2;
+  }
+  lds_barrier();
+  float num = 0.f, den = 0.f, n2 = 0.f;
+  for (int w = 0; w < NW; ++w) { num += red[w]; den += red[16 + w]; n2 += red[32 + w]; }
+  const float nrm = sqrtf(n2);
+  const float isk = 1.0f / sqrtf((float)K);
+  {
+    float po = 0.f, pw = 0.f;
+    for (int idx = threadIdx.x; idx < KK; idx += SRT) {
+      const int a = idx / K, b = idx - a * K;
+      const float q = ssl[idx] / nrm - (a == b ? isk : 0.f);
+      po += q * q;
+      pw += q * ssl[idx];
+    }
+    po = wave_sum(po);
+    pw = wave_sum(pw);
+    if (lane == 0) { red[48 + wave] = po; red[64 + wave] = pw; }
+  }
+  lds_barrier();
+  float o2 = 0.f, wq = 0.f;
+  for (int w = 0; w < NW; ++w) { o2 += red[48 + w]; wq += red[64 + w]; }
+  R.num = num; R.den = den; R.nrm = nrm; R.o = sqrtf(o2);
+  R.inner = R.o > 0.f ? wq / R.o : 0.f;   // <Gq, ss> of the orthogonality backward: sum_i ((q_i / o) ss_i)
+  if (!STEP && threadIdx.x < 64) scn_stats_publish(A, g, R.num, R.den, R.nrm, R.o);
+}
+
 template <int H, typename TS>
 __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -384,7 +729,6 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   const ScnLayout Y = scn_layout(H, K, A.max_n, A.max_e, 0);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = fb + Y.R1, *yl = fb + Y.R2;
   float *dout = fb + Y.dout, *red = fb + Y.red;
   float* WrT = fb + Y.wt;            // [FP][H]
@@ -396,134 +740,316 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
 
   STAMP(0);
   scn_front<H, TS>(A, Y, fb, ib, n0, n, e0, ne, g);
-
-  // y = act(W_rel agg + b_rel + W_root x): thread (row, o); both weight columns in registers
-  {
-    const int o = threadIdx.x % H, r0 = threadIdx.x / H;
-    float wr[FP], wo[FP];
-#pragma unroll
-    for (int k = 0; k < FP; ++k) { wr[k] = WrT[k * H + o]; wo[k] = WoT[k * H + o]; }
-    const float b = brl[o];
-    for (int i = r0; i < n; i += SRT / H) {
-      float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int k4 = 0; k4 < FP / 4; ++k4) {
-        const float4 av = *reinterpret_cast<const float4*>(agg + i * FP + 4 * k4);
-        const float4 xv = *reinterpret_cast<const float4*>(xs + i * FP + 4 * k4);
-        a1 = fmaf(av.x, wr[4 * k4 + 0], a1); a1 = fmaf(av.y, wr[4 * k4 + 1], a1);
-        a1 = fmaf(av.z, wr[4 * k4 + 2], a1); a1 = fmaf(av.w, wr[4 * k4 + 3], a1);
-        a2 = fmaf(xv.x, wo[4 * k4 + 0], a2); a2 = fmaf(xv.y, wo[4 * k4 + 1], a2);
-        a2 = fmaf(xv.z, wo[4 * k4 + 2], a2); a2 = fmaf(xv.w, wo[4 * k4 + 3], a2);
-      }
-      const float v = rnd<TS>(apply_act((a1 + b) + a2, A.act));   // the hidden activation as its storage type holds it
-      yl[i * H + o] = v;
-      stf(reinterpret_cast<TS*>(A.y), (size_t)(n0 + i) * H + o, v);
-    }
-  }
-  __syncthreads();
+  scn_hidden<H, TS>(A, xs, agg, yl, WrT, WoT, brl, n0, n);
+  lds_barrier();
   STAMP(4);
-  // logits + softmax: KP lanes per row (KP = pow2 >= K), x / agg are dead: S overlays them
+  scn_softmax<H>(A, yl, Sl, WmT, bml, n0, n, Sl + (size_t)A.max_n * K);   // x / agg are dead: S overlays them (y lives in R2: no overlap)
+  lds_barrier();
+  STAMP(5);
+  // (K > 16: y is in HBM already, its LDS copy is the scratch of the tile product; ss takes the slot the backward uses for Gss)
+  ScnStats R;
+  scn_stats<NW, false>(A, Sl, rowptr_s, col_s, nullptr, nullptr, dout, red, K <= 16 ? Sl + (size_t)A.max_n * K : yl, bml + K, R,
+                       nullptr, n, g);
+  STAMP(63);
+}
+
+// ---- backward proper: shared by the backward launch and the one-launch step -----------------------
+// In LDS on entry (behind a barrier): S (R1), y (R2), the forward's S^T S (ssl), both CSRs, dout, W_mlp^T; x and
+// agg wait in registers (xr / agr, slot idx = thread + i * SRT of the [n][FP] arrays) until the buffers they take
+// over are dead: R3 holds dlogits, then agg; R1 holds S, then x.  Rows beyond the register window are re-read
+// from pag / A.x (pag NULL: the caller guarantees n * FP <= XPT * SRT).  Writes the parameter-gradient
+// partials of this graph to `part` (global).
+// STEP: <Gq, ss> (`inner`) and the raw (A S) gather (as_in [n][K], may alias DL) come from the forward half.
+constexpr int SCN_XPT = 8;
+template <int H, typename TS, bool STEP>
+__device__ __forceinline__ void scn_bwd_tail(const ScnArgs& A, int n0, int n, float* Sl, float* yl, float* DL,
+                                             const float* dout, float* red, const float* WmT, float* Gss,
+                                             const float* ssl, const int* rowptr_d, const int* col_d,
+                                             const int* rowptr_s, const int* col_s, const float (&agr)[SCN_XPT],
+                                             const float (&xr)[SCN_XPT], const float* pag, float* part, float num,
+                                             float den, float nrm, float o, float inner_in, const float* as_in) {
+  constexpr int NW = SRT / 64, XPT = SCN_XPT;
+  const int K = A.K, KK = A.K * A.K;
+  const int lane = threadIdx.x & 63;
+  float *xs = Sl, *agg = DL;
+  const float gmc = (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
+  const float isk = 1.0f / sqrtf((float)K);
+  const float* ssg = ssl;
+  if (!STEP) {
+    if (threadIdx.x < 64) {
+      const float v = scn_ortho_inner(ssg, K, nrm, o);
+      if (lane == 0) red[0] = v;
+    }
+    lds_barrier();
+  }
+  STAMP(12);
+  const float inner = STEP ? inner_in : red[0];
+  for (int i = threadIdx.x; i < KK; i += SRT) {
+    const int a = i / K, b = i - a * K;
+    const float gq = o > 0.f ? (ssg[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
+    Gss[i] = (gq - inner / (nrm * nrm) * ssg[i]) / nrm;
+  }
+  lds_barrier();
+  STAMP(13);
+  // dS -> DL, then dlogits = S * (dS - <dS, S>) in place (KP lanes per row)
+  const float c_num = -gmc / den, c_den = gmc * num / (den * den);
   {
     int KP = 1;
     while (KP < K) KP <<= 1;
     const int k = threadIdx.x % KP, r0 = threadIdx.x / KP;
-    float wcol[H];   // this lane's column of W_mlp^T
+    float gcol[32];   // this lane's column of Gss (K <= 32)
 #pragma unroll
-    for (int h = 0; h < H; ++h) wcol[h] = k < K ? WmT[h * K + k] : 0.f;
-    const float bk = k < K ? bml[k] : 0.f;
+    for (int a = 0; a < 32; ++a) gcol[a] = (a < K && k < K && K <= 32) ? Gss[a * K + k] : 0.f;
     for (int i = r0; i < n; i += SRT / KP) {
-      float s = -INFINITY;
+      float dS = 0.f, sv = 0.f;
       if (k < K) {
+        sv = Sl[i * K + k];
+        float as = STEP ? as_in[i * K + k] : gather_sum(col_s, rowptr_s[i], rowptr_s[i + 1], Sl, K, k);   // (A S)_i
+        as += gather_sum(col_d, rowptr_d[i], rowptr_d[i + 1], Sl, K, k);                  // (A^T S)_i
+        as += 2.f * sv;                                                                   // the two identity terms
+        float orth = 0.f;
+        if (K <= 32 && (K & 3) == 0) {
+#pragma unroll
+          for (int a4 = 0; a4 < 8; ++a4) {
+            if (4 * a4 < K) {
+              const float4 sv4 = *reinterpret_cast<const float4*>(Sl + i * K + 4 * a4);
+              orth = fmaf(sv4.x, gcol[4 * a4 + 0], orth); orth = fmaf(sv4.y, gcol[4 * a4 + 1], orth);
+              orth = fmaf(sv4.z, gcol[4 * a4 + 2], orth); orth = fmaf(sv4.w, gcol[4 * a4 + 3], orth);
+            }
+          }
+        } else {
+          for (int a = 0; a < K; ++a) orth = fmaf(Sl[i * K + a], Gss[a * K + k], orth);
+        }
+        dS = c_num * as + c_den * 2.f * dout[i] * sv + go * 2.f * orth;
+      }
+      const float dot = seg_sum(dS * sv, KP);
+      if (k < K) DL[i * K + k] = sv * (dS - dot);
+    }
+  }
+  lds_barrier();
+  STAMP(14);
+  // parameter-gradient partials.  layout: W_rel [H*F], b_rel [H], W_root [H*F], W_mlp [K*H], b_mlp [K]
+  const int oWrel = 0, obrel = H * A.F, oWroot = obrel + H, oWmlp = oWroot + H * A.F, obmlp = oWmlp + K * H;
+  gram_mfma<NW>(DL, K, K, yl, H, H, n, Sl, part + oWmlp, H, H);   // dW_mlp[k][h] = sum_i DL[i][k] y[i][h]  (S is dead: scratch)
+  col_sum<NW>(DL, K, K, n, part + obmlp, red);
+  lds_barrier();
+  STAMP(15);
+  // dz = (DL W_mlp) * act'(y)  in place over y: thread (row, h)
+  {
+    const int h = threadIdx.x % H, r0 = threadIdx.x / H;
+    if (K <= 32 && (K & 3) == 0) {
+      float wrow[32];   // row h of W_mlp^T (K <= 32)
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wrow[k] = k < K ? WmT[h * K + k] : 0.f;
+      for (int i = r0; i < n; i += SRT / H) {
         float a = 0.f;
 #pragma unroll
-        for (int h4 = 0; h4 < H / 4; ++h4) {
-          const float4 yv = *reinterpret_cast<const float4*>(yl + i * H + 4 * h4);
-          a = fmaf(yv.x, wcol[4 * h4 + 0], a); a = fmaf(yv.y, wcol[4 * h4 + 1], a);
-          a = fmaf(yv.z, wcol[4 * h4 + 2], a); a = fmaf(yv.w, wcol[4 * h4 + 3], a);
+        for (int k4 = 0; k4 < 8; ++k4) {
+          if (4 * k4 < K) {
+            const float4 d4 = *reinterpret_cast<const float4*>(DL + i * K + 4 * k4);
+            a = fmaf(d4.x, wrow[4 * k4 + 0], a); a = fmaf(d4.y, wrow[4 * k4 + 1], a);
+            a = fmaf(d4.z, wrow[4 * k4 + 2], a); a = fmaf(d4.w, wrow[4 * k4 + 3], a);
+          }
         }
-        s = a + bk;
+        yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
       }
-      const float m = seg_max(s, KP);
-      const float ex = k < K ? expf(s - m) : 0.f;
-      const float sum = seg_sum(ex, KP);
-      // all rows of this pass were read (y) before S overwrites x/agg: y lives in R2, S in R1 -- no overlap
-      if (k < K) {
-        const float v = ex / sum;
-        Sl[i * K + k] = v;
-        A.S[(size_t)(n0 + i) * K + k] = v;
+    } else {
+      for (int i = r0; i < n; i += SRT / H) {
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a = fmaf(DL[i * K + k], WmT[h * K + k], a);
+        yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
       }
     }
   }
-  __syncthreads();
-  STAMP(5);
-  // MinCUT statistics on the binary A + I
-  //   num = sum_i S_i . (sum_{p in row_s(i)} S[col] + S_i),  den = sum_i dout_i |S_i|^2,  ss = S^T S
-  {
-    float num = 0.f, den = 0.f;
-    for (int idx = threadIdx.x; idx < n * K; idx += SRT) {
-      const int i = idx / K, k = idx - i * K;
-      const float sv = Sl[idx];
-      float as = gather_sum(col_s, rowptr_s[i], rowptr_s[i + 1], Sl, K, k);
-      as += sv;
-      num = fmaf(sv, as, num);
-      den = fmaf(dout[i], sv * sv, den);
-    }
-    num = wave_sum(num);
-    den = wave_sum(den);
-    if (lane == 0) { red[wave] = num; red[16 + wave] = den; }
+  lds_barrier();
+  STAMP(16);
+  // dlogits are dead: agg takes their buffer (R3), S's buffer (R1) is the scratch of the first product
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * SRT;
+    if (idx < n * FP) agg[idx] = agr[i];
   }
-  // ss = S^T S through the tile outer product into LDS, then to global
-  float* ssl = bml + K;  // [K][K] (the slot the backward uses for Gss)
-  const int KK = K * K;
-  gram_mfma<NW>(Sl, K, K, Sl, K, K, n, yl, ssl, K, K);   // (y is in HBM already: its LDS copy is the scratch)
-  __syncthreads();
-  STAMP(6);
-  for (int idx = threadIdx.x; idx < KK; idx += SRT) A.ss[(size_t)g * KK + idx] = ssl[idx];
-  if (threadIdx.x < 64) {
-    float num = 0.f, den = 0.f;
-    for (int w = 0; w < NW; ++w) { num += red[w]; den += red[16 + w]; }
-    float n2 = 0.f;
-    for (int idx = lane; idx < KK; idx += 64) n2 += ssl[idx] * ssl[idx];
-    n2 = wave_sum(n2);
-    const float nrm = sqrtf(n2);
-    const float isk = 1.0f / sqrtf((float)K);
-    float o2 = 0.f;
-    for (int idx = lane; idx < KK; idx += 64) {
-      const int a = idx / K, b = idx - a * K;
-      const float q = ssl[idx] / nrm - (a == b ? isk : 0.f);
-      o2 += q * q;
-    }
-    o2 = wave_sum(o2);
-    if (lane == 0) {
-      A.stats[g * 4 + 0] = num;
-      A.stats[g * 4 + 1] = den;
-      A.stats[g * 4 + 2] = nrm;
-      A.stats[g * 4 + 3] = sqrtf(o2);
-    }
-    // the batch losses without a launch of their own: the workgroup that takes the last ticket sums
-    // the per-graph statistics in graph order (the order, hence the result, does not depend on who
-    // it is); device-scope fences order the statistics stores against the ticket
-    if (A.ticket) {
-      int last = 0;
-      if (lane == 0) {
-        __threadfence();
-        last = atomicAdd(A.ticket, 1) == A.B - 1;
+  if (pag)
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = pag[idx];
+  lds_barrier();
+  gram_mfma<NW>(yl, H, H, agg, FP, FP, n, Sl, part + oWrel, A.F, A.F);    // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
+  // x takes S's buffer, agg's is the scratch of the second product
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = threadIdx.x + i * SRT;
+    if (idx < n * FP) xs[idx] = xr[i];
+  }
+  for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
+    const int i = idx / FP, k = idx - i * FP;
+    xs[idx] = k < A.F ? ldf(reinterpret_cast<const TS*>(A.x), (size_t)(n0 + i) * A.F + k) : 0.f;
+  }
+  lds_barrier();
+  gram_mfma<NW>(yl, H, H, xs, FP, FP, n, agg, part + oWroot, A.F, A.F);   // dW_root[o][k] = sum_i dz[i][o] x[i][k]
+  col_sum<NW>(yl, H, H, n, part + obrel, red);
+}
+
+// ---- the backward half of the one-launch step as ONE pass over the wave's own 16-row tiles ---------------
+// (K % 4 == 0, K <= 16 * NTC, at most two tiles per wave: n <= 512.)  Everything between Gss and the parameter-gradient
+// partials stays in the registers of the wave that owns the rows:
+//   orth = S Gss (matrix cores) -> dS -> dlogits DL (accumulator layout; also to LDS, own rows, as the A operand
+//   of the next product) -> dz = (DL W_mlp) * act'(y) (matrix cores) -> the three weight-gradient products
+//   dW_mlp += DL^T y, dW_rel += dz^T agg, dW_root += dz^T x with the accumulators of one product as the A
+//   operands of the next (row order 4 * lj + s on both sides), x / agg from the registers the forward half left.
+// The per-wave partial tiles and bias sums are parked in the (then dead) S | y | dlogits buffers behind ONE
+// barrier and folded in wave order: three barriers for the whole backward half.
+// T = as_in [n][K] (aliases DL: an element is read by the lane that overwrites it).
+template <int H, typename TS, int NTC>
+__device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const float* Sl, const float* yl, float* DL,
+                                              const float* dout, const float* WmT, const float* Gss,
+                                              const float (&xb)[2][4], const float (&ab)[2][4], float* scratch,
+                                              float* part, float num, float den) {
+  constexpr int NW = SRT / 64, TD = H / 16;
+  const int K = A.K, NT = (K + 15) >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int ntile = (n + 15) >> 4;
+  const float gmc = (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
+  const float c_num = -gmc / den, c_den = gmc * num / (den * den);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gWm[NTC][TD], gWr[TD], gWo[TD];
+  float dbm[NTC], dbr[TD];
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) {
+    dbm[nt] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct) gWm[nt][ct] = z4;
+  }
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct) { gWr[ct] = z4; gWo[ct] = z4; dbr[ct] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rt = wave + t * NW;
+    if (rt < ntile) {
+      const int r0 = rt * 16;
+      const bool rowok = r0 + li < n;
+      const float* Srow = rowok ? Sl + (r0 + li) * K : nullptr;
+      float sv[NTC][4], dS[NTC][4], dl[NTC][4];
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) {
+        const int col = nt * 16 + li;
+        const bool cok = nt < NT && col < K;
+        f32x4 orth = z4;
+        if (nt < NT) orth = tile_mm(Srow, K, Gss, K, 1, col, cok, orth);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + lj * 4 + r;
+          const bool ok = cok && row < n;
+          const float s_ = ok ? Sl[row * K + col] : 0.f;
+          const float t_ = ok ? DL[row * K + col] : 0.f;
+          const float d_ = ok ? dout[row] : 0.f;
+          sv[nt][r] = s_;
+          dS[nt][r] = ok ? c_num * t_ + c_den * 2.f * d_ * s_ + go * 2.f * orth[r] : 0.f;
+        }
       }
-      last = __builtin_amdgcn_readfirstlane(last);
-      if (last) {
-        __threadfence();
-        scn_losses_wave(A.stats, A.losses, A.B);
-        if (lane == 0) *A.ticket = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float dot = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) dot += dS[nt][r] * sv[nt][r];
+        dot = row16_sum(dot);
+        const int row = r0 + lj * 4 + r;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+          const int col = nt * 16 + li;
+          dl[nt][r] = sv[nt][r] * (dS[nt][r] - dot);
+          if (nt < NT && col < K && row < n) DL[row * K + col] = dl[nt][r];
+        }
+      }
+      float yv[TD][4];
+#pragma unroll
+      for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + lj * 4 + r;
+          yv[ct][r] = row < n ? yl[row * H + ct * 16 + li] : 0.f;
+        }
+      // dW_mlp[k][h] += sum_rows DL[row][k] y[row][h];  db_mlp[k] += sum_rows DL[row][k]
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+        if (nt < NT) {
+#pragma unroll
+          for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              gWm[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[nt][r], yv[ct][r], gWm[nt][ct], 0, 0, 0);
+          dbm[nt] += ((dl[nt][0] + dl[nt][1]) + dl[nt][2]) + dl[nt][3];
+        }
+      // dz = (DL W_mlp) * act'(y): A = the tile's DL rows (this wave's own stores, in order behind them)
+      const float* DLrow = rowok ? DL + (r0 + li) * K : nullptr;
+#pragma unroll
+      for (int ct = 0; ct < TD; ++ct) {
+        const f32x4 acc = tile_mm(DLrow, K, WmT, 1, K, ct * 16 + li, true, z4);
+        float dz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + lj * 4 + r;
+          dz[r] = row < n ? acc[r] * act_grad_from_output(yv[ct][r], A.act) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gWr[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[r], ab[t][r], gWr[ct], 0, 0, 0);
+          gWo[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[r], xb[t][r], gWo[ct], 0, 0, 0);
+        }
+        dbr[ct] += ((dz[0] + dz[1]) + dz[2]) + dz[3];
       }
     }
   }
-  STAMP(63);
+  // bias sums over the four lane groups (rows 4 * lj + r): every lane ends with the wave's total of its column
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) { dbm[nt] += __shfl_xor(dbm[nt], 16, 64); dbm[nt] += __shfl_xor(dbm[nt], 32, 64); }
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct) { dbr[ct] += __shfl_xor(dbr[ct], 16, 64); dbr[ct] += __shfl_xor(dbr[ct], 32, 64); }
+  STAMP(14);
+  lds_barrier();   // every wave is done with S, T / DL and y: their buffers take the partials
+  // block of wave w: tiles {dW_mlp (nt, ct)}, {dW_rel ct}, {dW_root ct} (256 words each, [m][n]), db_mlp [16 * NT], db_rel [H]
+  const int NTL = NT * TD + 2 * TD, WSZ = NTL * 256 + 16 * NT + H;
+  const int NWA = ntile < NW ? ntile : NW;   // waves that own a tile
+  if (wave < NWA) {
+    float* blk = scratch + (size_t)wave * WSZ;
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt)
+      if (nt < NT) {
+#pragma unroll
+        for (int ct = 0; ct < TD; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) blk[(nt * TD + ct) * 256 + (lj * 4 + r) * 16 + li] = gWm[nt][ct][r];
+        if (lj == 0) blk[NTL * 256 + nt * 16 + li] = dbm[nt];
+      }
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        blk[(NT * TD + ct) * 256 + (lj * 4 + r) * 16 + li] = gWr[ct][r];
+        blk[(NT * TD + TD + ct) * 256 + (lj * 4 + r) * 16 + li] = gWo[ct][r];
+      }
+      if (lj == 0) blk[NTL * 256 + 16 * NT + ct * 16 + li] = dbr[ct];
+    }
+  }
+  lds_barrier();
+  STAMP(15);
+  // fold in wave order.  layout of part: W_rel [H*F], b_rel [H], W_root [H*F], W_mlp [K*H], b_mlp [K]
+  const int F = A.F;
+  const int obrel = H * F, oWroot = obrel + H, oWmlp = oWroot + H * F, obmlp = oWmlp + K * H;
+  for (int p = threadIdx.x; p < A.P; p += SRT) {
+    int off;
+    if (p < obrel) { const int o_ = p / F, f = p - o_ * F; off = (NT * TD + (o_ >> 4)) * 256 + (o_ & 15) * 16 + f; }
+    else if (p < oWroot) off = NTL * 256 + 16 * NT + (p - obrel);
+    else if (p < oWmlp) { const int q = p - oWroot, o_ = q / F, f = q - o_ * F; off = (NT * TD + TD + (o_ >> 4)) * 256 + (o_ & 15) * 16 + f; }
+    else if (p < obmlp) { const int q = p - oWmlp, k_ = q / H, h = q - k_ * H; off = ((k_ >> 4) * TD + (h >> 4)) * 256 + (k_ & 15) * 16 + (h & 15); }
+    else off = NTL * 256 + (p - obmlp);
+    float v = 0.f;
+    for (int w = 0; w < NWA; ++w) v += scratch[(size_t)w * WSZ + off];
+    part[p] = v;
+  }
 }
 
 template <int H, typename TS>
 __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int NW = SRT / 64;
   const int g = blockIdx.x, K = A.K, KK = A.K * A.K;
   const int n0 = A.nptr[g], n = A.nptr[g + 1] - n0;
   const int e0 = A.eptr[g], ne = A.eptr[g + 1] - e0;
@@ -536,9 +1062,8 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   const ScnLayout Y = scn_layout(H, K, A.max_n, A.max_e, 1);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
-  const int lane = threadIdx.x & 63;
-  float *Sl = fb + Y.R1, *xs = fb + Y.R1;      // S, and x once S is dead
-  float *yl = fb + Y.R2, *DL = fb + Y.R3, *agg = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;   // dlogits, then agg
+  float* Sl = fb + Y.R1;                                   // S, and x once S is dead
+  float *yl = fb + Y.R2, *DL = fb + Y.R3, *dout = fb + Y.dout, *red = fb + Y.red;   // dlogits, then agg
   float* WmT = fb + Y.wt + 2 * FP * H + H;   // [H][K] (same offsets as the forward's weight block)
   float* Gss = WmT + (size_t)H * K + K;      // [K][K]
   float* ssl = fb + Y.ssl;                   // [K][K] the forward's S^T S
@@ -547,7 +1072,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
   STAMP(0);
   // ---- front: everything comes from HBM in one batch of requests -- the CSRs, agg and the binary
   // out-degree the forward launch exported, x, S and y, W_mlp -- then is parked in LDS
-  constexpr int XPT = 8;
+  constexpr int XPT = SCN_XPT;
   float agr[XPT], xr[XPT];   // agg and x wait in registers until the LDS buffers they take over are dead
   const float* pag = A.ex_agg + (size_t)n0 * FP;
   {
@@ -641,126 +1166,96 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
     }
   }
   const float num = A.stats[g * 4 + 0], den = A.stats[g * 4 + 1], nrm = A.stats[g * 4 + 2], o = A.stats[g * 4 + 3];
-  const float gmc = (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
-  const float isk = 1.0f / sqrtf((float)K);
-  const float* ssg = ssl;
-  __syncthreads();   // the front's LDS stores
+  lds_barrier();   // the front's LDS stores
   STAMP(1);
-  if (threadIdx.x < 64) {
-    float v = 0.f;
-    if (o > 0.f)
-      for (int i = lane; i < KK; i += 64) {
-        const int a = i / K, b = i - a * K;
-        v += ((ssg[i] / nrm - (a == b ? isk : 0.f)) / o) * ssg[i];
-      }
-    v = wave_sum(v);
-    if (lane == 0) red[0] = v;
-  }
-  __syncthreads();
-  STAMP(2);
-  const float inner = red[0];
-  for (int i = threadIdx.x; i < KK; i += SRT) {
-    const int a = i / K, b = i - a * K;
-    const float gq = o > 0.f ? (ssg[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
-    Gss[i] = (gq - inner / (nrm * nrm) * ssg[i]) / nrm;
-  }
-  __syncthreads();
-  STAMP(3);
-  // dS -> DL, then dlogits = S * (dS - <dS, S>) in place (KP lanes per row)
-  const float c_num = -gmc / den, c_den = gmc * num / (den * den);
-  {
-    int KP = 1;
-    while (KP < K) KP <<= 1;
-    const int k = threadIdx.x % KP, r0 = threadIdx.x / KP;
-    float gcol[32];   // this lane's column of Gss (K <= 32)
-#pragma unroll
-    for (int a = 0; a < 32; ++a) gcol[a] = (a < K && k < K && K <= 32) ? Gss[a * K + k] : 0.f;
-    for (int i = r0; i < n; i += SRT / KP) {
-      float dS = 0.f, sv = 0.f;
-      if (k < K) {
-        sv = Sl[i * K + k];
-        float as = gather_sum(col_s, rowptr_s[i], rowptr_s[i + 1], Sl, K, k);             // (A S)_i
-        as += gather_sum(col_d, rowptr_d[i], rowptr_d[i + 1], Sl, K, k);                  // (A^T S)_i
-        as += 2.f * sv;                                                                   // the two identity terms
-        float orth = 0.f;
-        if (K <= 32 && (K & 3) == 0) {
-#pragma unroll
-          for (int a4 = 0; a4 < 8; ++a4) {
-            if (4 * a4 < K) {
-              const float4 sv4 = *reinterpret_cast<const float4*>(Sl + i * K + 4 * a4);
-              orth = fmaf(sv4.x, gcol[4 * a4 + 0], orth); orth = fmaf(sv4.y, gcol[4 * a4 + 1], orth);
-              orth = fmaf(sv4.z, gcol[4 * a4 + 2], orth); orth = fmaf(sv4.w, gcol[4 * a4 + 3], orth);
-            }
-          }
-        } else {
-          for (int a = 0; a < K; ++a) orth = fmaf(Sl[i * K + a], Gss[a * K + k], orth);
-        }
-        dS = c_num * as + c_den * 2.f * dout[i] * sv + go * 2.f * orth;
-      }
-      const float dot = seg_sum(dS * sv, KP);
-      if (k < K) DL[i * K + k] = sv * (dS - dot);
-    }
-  }
-  __syncthreads();
-  STAMP(4);
-  // parameter-gradient partials.  layout: W_rel [H*F], b_rel [H], W_root [H*F], W_mlp [K*H], b_mlp [K]
-  const int oWrel = 0, obrel = H * A.F, oWroot = obrel + H, oWmlp = oWroot + H * A.F, obmlp = oWmlp + K * H;
-  gram_mfma<NW>(DL, K, K, yl, H, H, n, Sl, part + oWmlp, H, H);   // dW_mlp[k][h] = sum_i DL[i][k] y[i][h]  (S is dead: scratch)
-  col_sum<NW>(DL, K, K, n, part + obmlp, red);
-  __syncthreads();
-  STAMP(5);
-  // dz = (DL W_mlp) * act'(y)  in place over y: thread (row, h)
-  {
-    const int h = threadIdx.x % H, r0 = threadIdx.x / H;
-    if (K <= 32 && (K & 3) == 0) {
-      float wrow[32];   // row h of W_mlp^T (K <= 32)
-#pragma unroll
-      for (int k = 0; k < 32; ++k) wrow[k] = k < K ? WmT[h * K + k] : 0.f;
-      for (int i = r0; i < n; i += SRT / H) {
-        float a = 0.f;
-#pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-          if (4 * k4 < K) {
-            const float4 d4 = *reinterpret_cast<const float4*>(DL + i * K + 4 * k4);
-            a = fmaf(d4.x, wrow[4 * k4 + 0], a); a = fmaf(d4.y, wrow[4 * k4 + 1], a);
-            a = fmaf(d4.z, wrow[4 * k4 + 2], a); a = fmaf(d4.w, wrow[4 * k4 + 3], a);
-          }
-        }
-        yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
-      }
-    } else {
-      for (int i = r0; i < n; i += SRT / H) {
-        float a = 0.f;
-        for (int k = 0; k < K; ++k) a = fmaf(DL[i * K + k], WmT[h * K + k], a);
-        yl[i * H + h] = a * act_grad_from_output(yl[i * H + h], A.act);
-      }
-    }
-  }
-  __syncthreads();
-  STAMP(6);
-  // dlogits are dead: agg takes their buffer (R3), S's buffer (R1) is the scratch of the first product
-#pragma unroll
-  for (int i = 0; i < XPT; ++i) {
-    const int idx = threadIdx.x + i * SRT;
-    if (idx < n * FP) agg[idx] = agr[i];
-  }
-  for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = pag[idx];
-  __syncthreads();
-  gram_mfma<NW>(yl, H, H, agg, FP, FP, n, Sl, part + oWrel, A.F, A.F);    // dW_rel[o][k] = sum_i dz[i][o] agg[i][k]
-  // x takes S's buffer, agg's is the scratch of the second product
-#pragma unroll
-  for (int i = 0; i < XPT; ++i) {
-    const int idx = threadIdx.x + i * SRT;
-    if (idx < n * FP) xs[idx] = xr[i];
-  }
-  for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
-    const int i = idx / FP, k = idx - i * FP;
-    xs[idx] = k < A.F ? ldf(reinterpret_cast<const TS*>(A.x), (size_t)(n0 + i) * A.F + k) : 0.f;
-  }
-  __syncthreads();
-  gram_mfma<NW>(yl, H, H, xs, FP, FP, n, agg, part + oWroot, A.F, A.F);   // dW_root[o][k] = sum_i dz[i][o] x[i][k]
-  col_sum<NW>(yl, H, H, n, part + obrel, red);
+  scn_bwd_tail<H, TS, false>(A, n0, n, Sl, yl, DL, dout, red, WmT, Gss, ssl, rowptr_d, col_d, rowptr_s, col_s, agr, xr,
+                             pag, part, num, den, nrm, o, 0.f, nullptr);
   STAMP(63);
+}
+
+// ---- the one-launch step: forward, losses and backward of graph g in one workgroup -----------------
+// What the forward launch exported for the backward launch (both CSRs, agg, dout, S, y, S^T S, the statistics)
+// simply stays in LDS; x and agg move to registers before S takes their buffer.  Upstream gradients g_mc / g_o
+// (device scalars, the reference's loss = mincut + ortho has both = 1) are divided by B as in the backward launch.
+// With B == 1 the partials ARE the gradients (A.partials = grads): no fold launch.
+template <int H, typename TS>
+__global__ void __launch_bounds__(SRT) k_scn_step(const ScnArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NW = SRT / 64;
+  const int g = blockIdx.x, K = A.K;
+  const int n0 = A.nptr[g], n = A.nptr[g + 1] - n0;
+  const int e0 = A.eptr[g], ne = A.eptr[g + 1] - e0;
+  float* part = A.partials + (size_t)g * A.P;
+  if (n > A.max_n || ne > A.max_e || n < 0 || ne < 0) {
+    if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+    for (int i = threadIdx.x; i < A.P; i += SRT) part[i] = 0.f;
+    return;
+  }
+  const ScnLayout Y = scn_layout(H, K, A.max_n, A.max_e, 2);
+  float* fb = reinterpret_cast<float*>(smem);
+  int* ib = reinterpret_cast<int*>(smem);
+  float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = fb + Y.R1, *yl = fb + Y.R2, *DL = fb + Y.R3;
+  float *dout = fb + Y.dout, *red = fb + Y.red;
+  float* WrT = fb + Y.wt;
+  float* WoT = WrT + FP * H;
+  float* brl = WoT + FP * H;
+  float* WmT = brl + H;
+  float* bml = WmT + (size_t)H * K;
+  float* Gss = bml + K;
+  float* ssl = fb + Y.ssl;
+  int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
+
+#ifdef HSCN_REPEAT   // diagnostic: the body twice, the stamps of the second (instruction cache warm) pass survive
+  for (int rep = 0; rep < 2; ++rep) {
+#endif
+  STAMP(0);
+  scn_front<H, TS>(A, Y, fb, ib, n0, n, e0, ne, g);
+  // (K % 4 == 0: hscn_scn_resident_train_step_supported)
+  const int wave = threadIdx.x >> 6, ntile = (n + 15) >> 4;
+  float xb[2][4], ab[2][4];    // x / agg of the wave's own tiles as B operands of the backward half
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) { xb[t][s_] = 0.f; ab[t][s_] = 0.f; }
+    const int rt = wave + t * NW;
+    if (rt < ntile) scn_hidden_tile<H, TS, true>(A, rt, xs, agg, yl, WrT, WoT, brl, n0, n, xb[t], ab[t]);
+  }
+  lds_barrier();
+  STAMP(4);
+  scn_softmax<H>(A, yl, Sl, WmT, bml, n0, n, Sl + (size_t)A.max_n * K);
+  lds_barrier();
+  STAMP(5);
+  // the backward's neighbour term is kept in the dlogits buffer (each element is read back by the lane that
+  // overwrites it); the tile scratch of S^T S is the part of x | agg behind S
+  ScnStats R;
+  scn_stats<NW, true>(A, Sl, rowptr_s, col_s, rowptr_d, col_d, dout, red, Sl + (size_t)A.max_n * K, ssl, R, DL, n, g);
+  STAMP(7);
+  const float num = R.num, den = R.den, nrm = R.nrm, o = R.o;
+  {
+    const float inner = R.inner;
+    const float isk = 1.0f / sqrtf((float)K);
+    for (int i = threadIdx.x; i < K * K; i += SRT) {
+      const int a = i / K, b = i - a * K;
+      const float gq = o > 0.f ? (ssl[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
+      Gss[i] = (gq - inner / (nrm * nrm) * ssl[i]) / nrm;
+    }
+  }
+  lds_barrier();
+  STAMP(13);
+  // (column tiles x hidden tiles <= 2: more accumulators than that do not fit the register file of 16 waves)
+  if (H == 32 || K <= 16) scn_bwd_tiles<H, TS, 1>(A, n, Sl, yl, DL, dout, WmT, Gss, xb, ab, fb + Y.R1, part, num, den);
+  else if constexpr (H == 16) scn_bwd_tiles<H, TS, 2>(A, n, Sl, yl, DL, dout, WmT, Gss, xb, ab, fb + Y.R1, part, num, den);
+  STAMP(62);
+#ifdef HSCN_REPEAT
+  STAMP(63);
+  lds_barrier();
+  if (rep == 0) continue;
+#endif
+  if (threadIdx.x < 64) scn_stats_publish(A, g, num, den, nrm, o);   // off the critical path: after the backward half
+  STAMP(63);
+#ifdef HSCN_REPEAT
+  }
+#endif
 }
 
 __global__ void k_scn_losses(const float* __restrict__ stats, float* __restrict__ losses, int G) {
@@ -773,7 +1268,11 @@ template <int H, typename TS>
 int launch_scn(ScnArgs& A, int bwd, hipStream_t st) {
   const size_t lds = scn_layout(H, A.K, A.max_n, A.max_e, bwd).total * 4;
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
-  if (bwd) {
+  if (bwd == 2) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_scn_step<H, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_scn_step<H, TS><<<(unsigned)A.B, SRT, lds, st>>>(A);
+  } else if (bwd) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_scn_bwd<H, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     k_scn_bwd<H, TS><<<(unsigned)A.B, SRT, lds, st>>>(A);
@@ -805,6 +1304,47 @@ int hscn_scn_resident_supported(int F, int H, int K, int max_n, int max_e) {
 }
 
 int64_t hscn_scn_resident_param_count(int F, int H, int K) { return scn_param_count(F, H, K); }
+
+int hscn_scn_resident_train_step_supported(int F, int H, int K, int max_n, int max_e) {
+  if (!hscn_scn_resident_supported(F, H, K, max_n, max_e)) return 0;
+  // float4 rows of S; at most two 16-row tiles per wave; at most two accumulator tiles of dW_mlp per wave
+  if ((K & 3) != 0 || max_n > 512 || ((K + 15) / 16) * (H / 16) > 2) return 0;
+  if (scn_layout(H, K, max_n, max_e, 2).total * 4 > 160 * 1024) return 0;
+  return 1;
+}
+
+static int scn_step_impl(int f16, const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                         const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act, const float* W_rel,
+                         const float* b_rel, const float* W_root, const float* W_mlp, const float* b_mlp,
+                         const float* g_mc, const float* g_o, int max_n, int max_e, float* S, float* stats,
+                         float* losses, int32_t* ticket, float* partials, float* grads, int32_t* flag,
+                         void* stream_) {
+  if (B < 1 || N < 0 || E < 0) return HSCN_E_BADARG;
+  if (!hscn_scn_resident_train_step_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
+  if (!x || !nptr || !eptr || !W_rel || !b_rel || !W_root || !W_mlp || !b_mlp || !stats || !losses || !grads ||
+      (B > 1 && !partials) || (E > 0 && !edge_index))
+    return HSCN_E_BADARG;
+  ScnArgs A{};
+  A.x = x; A.src = edge_index; A.dst = edge_index ? edge_index + E : nullptr; A.nptr = nptr; A.eptr = eptr;
+  A.W_rel = W_rel; A.b_rel = b_rel; A.W_root = W_root; A.W_mlp = W_mlp; A.b_mlp = b_mlp;
+  A.S = S; A.stats = stats; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act; A.g_mc = g_mc; A.g_o = g_o;
+  A.losses = losses; A.ticket = ticket;
+  A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
+  A.partials = B == 1 ? grads : partials;   // one graph: its partials are the gradients
+  hipStream_t st = hscn_stream(stream_);
+  int rc = f16 ? (H == 16 ? launch_scn<16, half_t>(A, 2, st) : launch_scn<32, half_t>(A, 2, st))
+               : (H == 16 ? launch_scn<16, float>(A, 2, st) : launch_scn<32, float>(A, 2, st));
+  if (rc) return rc;
+  if (!ticket) {
+    k_scn_losses<<<1, 64, 0, st>>>(stats, losses, (int)B);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
+  if (B > 1) {
+    k_param_reduce<<<hscn_blocks(A.P, 32), 256, 0, st>>>(partials, grads, (int)B, A.P, -1, 0.f);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+  }
+  return 0;
+}
 
 static int scn_fwd_impl(int f16, const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                           const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
@@ -892,6 +1432,24 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
   return scn_bwd_impl(0, x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_mlp, S, y, stats, ss, g_mc, g_o,
                       ex_rowptr_d, ex_col_d, ex_rowptr_s, ex_col_s, ex_agg, ex_dout, max_n, max_e, partials, grads,
                       flag, stream_);
+}
+int hscn_scn_resident_train_step(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                                 const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                                 const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
+                                 const float* b_mlp, const float* g_mc, const float* g_o, int max_n, int max_e,
+                                 float* S, float* stats, float* losses, int32_t* ticket, float* partials,
+                                 float* grads, int32_t* flag, void* stream_) {
+  return scn_step_impl(0, x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_rel, b_rel, W_root, W_mlp, b_mlp, g_mc,
+                       g_o, max_n, max_e, S, stats, losses, ticket, partials, grads, flag, stream_);
+}
+int hscn_scn_resident_train_step_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                                     const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                                     const float* W_rel, const float* b_rel, const float* W_root,
+                                     const float* W_mlp, const float* b_mlp, const float* g_mc, const float* g_o,
+                                     int max_n, int max_e, float* S, float* stats, float* losses, int32_t* ticket,
+                                     float* partials, float* grads, int32_t* flag, void* stream_) {
+  return scn_step_impl(1, (const float*)x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_rel, b_rel, W_root,
+                       W_mlp, b_mlp, g_mc, g_o, max_n, max_e, S, stats, losses, ticket, partials, grads, flag, stream_);
 }
 // IEEE-half storage of the node features x and of the saved hidden activation y (include/hscn.h); S, the
 // statistics, the exported aggregation A_hat x (an accumulator output) and every gradient stay float.

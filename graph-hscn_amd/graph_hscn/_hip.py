@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -64,6 +64,9 @@ _SIGNATURES = {
                                       c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "hscn_scn_resident_bwd": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P, P, P,
                                       P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
+    "hscn_scn_resident_train_step_supported": (c_int, [c_int] * 5),
+    "hscn_scn_resident_train_step": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P,
+                                             P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
     "hscn_resident_supported": (c_int, [c_int] * 8),
     "hscn_resident_param_count": (c_int64, [c_int] * 4),
     "hscn_resident_fwd": (c_int, [P, P, P, c_int64, P, c_int64, P, c_int64, P, P, P, P, P, c_int64, c_int64,
@@ -85,7 +88,8 @@ _SIGNATURES = {
 }
 # IEEE-half storage twins (include/hscn.h: hscn_resident_*_f16): same argument lists
 for _n in ("hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual", "hscn_resident_bwd_with_virtual",
-           "hscn_scn_resident_fwd", "hscn_scn_resident_bwd", "hscn_resident_train_step"):
+           "hscn_scn_resident_fwd", "hscn_scn_resident_bwd", "hscn_resident_train_step",
+           "hscn_scn_resident_train_step"):
     _SIGNATURES[_n + "_f16"] = _SIGNATURES[_n]
 
 

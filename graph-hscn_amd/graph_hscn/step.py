@@ -258,7 +258,10 @@ class ScnTrainStep:
     Outputs refreshed by ``run()``: ``S`` [N,K] (softmax assignment), ``losses`` [3] = {mincut, ortho, their sum},
     ``grads`` (flat: W_rel, b_rel, W_root, W_mlp, b_mlp)."""
 
-    def __init__(self, model, data, workspace: Optional[ScnWorkspace] = None):
+    def __init__(self, model, data, workspace: Optional[ScnWorkspace] = None, one_launch: Optional[bool] = None):
+        """``one_launch``: forward, losses and backward of a graph in ONE workgroup program
+        (``hscn_scn_resident_train_step``; bit-identical to the pair of launches).  Default: whenever the graphs
+        fit; ``False`` keeps the forward / backward pair."""
         from .model.hscn import SCN
         if not isinstance(model, SCN):
             raise TypeError("ScnTrainStep drives graph_hscn.model.hscn.SCN")
@@ -279,6 +282,10 @@ class ScnTrainStep:
         H, K = conv.lin_rel.weight.shape[0], lin.weight.shape[0]
         B, E = meta.num_graphs, self.ei.size(1)
         self.dims = (N, F, H, K, B, E)
+        fits = bool(_hip.lib().hscn_scn_resident_train_step_supported(F, H, K, meta.max_n, meta.max_e))
+        if one_launch and not fits:
+            raise RuntimeError("one_launch=True: a graph of this batch does not fit the one-launch stage-A step")
+        self.one_launch = fits if one_launch is None else bool(one_launch)
         ws = workspace if workspace is not None else ScnWorkspace(dev, N, E, B, F, H, K, self.x.dtype)
         if N > ws.cap[0] or E > ws.cap[1] or B > ws.cap[2] or ws.y.dtype != self.x.dtype:
             raise ValueError("the shared workspace is smaller than this step (or of another storage type)")
@@ -311,6 +318,12 @@ class ScnTrainStep:
         W_rel, b_rel, W_root, W_mlp, b_mlp = (p.contiguous() for p in self._mp)
         st = stream()
         eip = ptr(self.ei) if E else None
+        if self.one_launch:
+            call("hscn_scn_resident_train_step" + self._sfx, ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H,
+                 K, self.act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), ptr(self.one),
+                 ptr(self.one), m.max_n, m.max_e, ptr(self.S), ptr(self.stats), ptr(self.losses), ptr(m.ticket),
+                 ptr(self.partials), ptr(self.grads), ptr(m.flag), st)
+            return self.losses[2]
         call("hscn_scn_resident_fwd" + self._sfx, ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
              ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), m.max_n, m.max_e, ptr(self.S), ptr(self.y),
              ptr(self.stats), ptr(self.ss), ptr(self.losses), ptr(m.ticket), *[ptr(t) for t in self.ex], ptr(m.flag), st)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 5
+#define HSCN_ABI_VERSION 6
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -579,6 +579,29 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
                           const int32_t* ex_rowptr_d, const int32_t* ex_col_d, const int32_t* ex_rowptr_s,
                           const int32_t* ex_col_s, const float* ex_agg, const float* ex_dout, int max_n, int max_e,
                           float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+
+/* The stage-A step in ONE launch: optimizer.zero_grad(); S, mc, o = model(x, ei, adj); (mc + o).backward() of
+ * train/train_clustering.py:37-49 for a batch of raw graphs -- hscn_scn_resident_fwd and hscn_scn_resident_bwd with
+ * everything the first exported for the second (CSRs, agg, y, S, S^T S, statistics) staying in the workgroup's LDS.
+ * Bit-identical to the pair of launches.  S [N,K] may be NULL (a training step does not need the assignments);
+ * stats [B,4], losses [3], ticket as in hscn_scn_resident_fwd; g_mc / g_o as in hscn_scn_resident_bwd.  With
+ * B == 1 (the reference's trajectory, one graph per optimizer step) the workgroup writes grads [P] itself and
+ * partials may be NULL; with B > 1 the ordered fold of partials [B,P] is the launch behind it.
+ * hscn_scn_resident_train_step_supported: the pair's conditions and max_n <= 512. */
+int hscn_scn_resident_train_step_supported(int F, int H, int K, int max_n, int max_e);
+int hscn_scn_resident_train_step(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                                 const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                                 const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
+                                 const float* b_mlp, const float* g_mc /*[1] or NULL*/, const float* g_o /*[1] or NULL*/,
+                                 int max_n, int max_e, float* S /*[N,K] or NULL*/, float* stats /*[B,4]*/,
+                                 float* losses /*[3]*/, int32_t* ticket /*[1] or NULL*/, float* partials /*[B,P]*/,
+                                 float* grads /*[P]*/, int32_t* flag, void* stream);
+int hscn_scn_resident_train_step_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
+                                     const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
+                                     const float* W_rel, const float* b_rel, const float* W_root,
+                                     const float* W_mlp, const float* b_mlp, const float* g_mc, const float* g_o,
+                                     int max_n, int max_e, float* S, float* stats, float* losses, int32_t* ticket,
+                                     float* partials, float* grads, int32_t* flag, void* stream);
 
 int hscn_resident_train_step_f16(const hscn_half* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                                  const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C,

@@ -44,6 +44,21 @@ def main():
                 prev = st[i, k]
                 print(f"   {names[k]:34s} {d:8d} cyc  {100.0 * d / total[i]:5.1f}%")
 
+    if "step" in sys.argv[1:]:
+        from graph_hscn.step import ScnTrainStep
+        st = ScnTrainStep(scn, big, one_launch=True)
+        for _ in range(3):
+            st.run()
+        torch.cuda.synchronize()
+        buf.zero_()
+        st.run()
+        torch.cuda.synchronize()
+        show(buf.cpu().numpy(), {0: "start", 1: "requests + park", 2: "two CSRs + degrees", 3: "aggregate",
+                                 4: "y = act(W agg + W x), x/agg -> regs", 5: "logits + softmax",
+                                 6: "neighbour terms + S^T S", 7: "norms", 13: "Gss",
+                                 14: "backward tiles (dS..dW partials)", 15: "park partials", 62: "fold -> HBM",
+                                 63: "publish statistics (ticket)"}, "scn step")
+        return
     for _ in range(3):
         scn.zero_grad(set_to_none=True)
         t = scn.forward_graphs(big, with_total=True)[3]
@@ -54,8 +69,8 @@ def main():
     buf.zero_()
     t.backward()
     torch.cuda.synchronize()
-    show(buf.cpu().numpy(), {0: "start", 1: "requests + park", 2: "<Gq, ss>", 3: "Gss", 4: "dS -> dlogits",
-                             5: "dW_mlp + db_mlp", 6: "dz", 63: "dW_rel, dW_root, db_rel"}, "scn bwd")
+    show(buf.cpu().numpy(), {0: "start", 1: "requests + park", 12: "<Gq, ss>", 13: "Gss", 14: "dS -> dlogits",
+                             15: "dW_mlp + db_mlp", 16: "dz", 63: "dW_rel, dW_root, db_rel"}, "scn bwd")
 
 
 if __name__ == "__main__":
