@@ -555,7 +555,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   const int F = A.F;
 
   // wave groups: with the virtual branch on, the upper half of the waves works on it
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: "tiles of this wave" loops stay uniform)
   // structure build always splits when the virtual branch is on; a virtual-only launch keeps a
   // quarter of the waves for streaming the next layer's local activations in
   const int NA = cv ? (vonly ? (NW >= 4 ? NW / 4 : 1) : NW / 2) : NW;
@@ -1333,7 +1333,7 @@ __device__ __forceinline__ void hscn_bwd_body(const BwdArgs& A, const int g) {
   float *red = fb + Y.red, *bred = fb + Y.bred, *wl = fb + Y.wl, *headw = fb + Y.headw;
   int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
   const int L = A.L;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (scalar: "tiles of this wave" loops stay uniform)
   const Grp ALL{(int)threadIdx.x, RT, wave, NW};
   (void)ib;
 

@@ -22,6 +22,10 @@
 
 namespace {
 
+// the wave's index in the workgroup as a SCALAR: the compiler takes threadIdx.x >> 6 for a per-lane value and turns
+// every "tiles of this wave" loop into a divergent loop (exec masks, vector compares, vector addresses)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 constexpr int SRT = 1024;  // threads per workgroup (16 waves: latency hiding for the many short phases)
 constexpr int FP = 16;    // input features are zero padded to 16 in LDS
 
@@ -112,7 +116,7 @@ template <int NW>
 __device__ void gram_mfma(const float* Am, int lda, int O, const float* Bm, int ldb, int Kc, int n, float* scratch,
                           float* out, int ldo, int kmax) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lj = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = wave_id(), li = lane & 15, lj = lane >> 4;
   const int TO = (O + 15) >> 4, TK = (Kc + 15) >> 4, NT = TO * TK;
   const int TPP = NT < NW ? NT : NW, RG = NW / TPP;
   for (int t0 = 0; t0 < NT; t0 += TPP) {
@@ -151,7 +155,7 @@ __device__ void gram_mfma(const float* Am, int lda, int O, const float* Bm, int 
 // waves through `scratch` [NW][C] in wave order.  Contains one workgroup barrier.
 template <int NW>
 __device__ void col_sum(const float* M, int ld, int C, int n, float* out, float* scratch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   if ((C & 3) != 0 || (64 % (C / 4)) != 0 || (ld & 3) != 0) {   // odd widths: wave per column, lanes split rows
     for (int c = wave; c < C; c += NW) {
       float s_ = 0.f;
@@ -242,7 +246,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   float* bml = WmT + (size_t)H * K;
   int *ek = ib + Y.ek, *eo = ib + Y.eo;
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
-  const int wave = threadIdx.x >> 6;
+  const int wave = wave_id();
   const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
   // ---- requests ----
   constexpr int WPT = (FP * H + SRT - 1) / SRT;
@@ -390,6 +394,31 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
 // ---- forward middle: shared by the forward launch and the one-launch step -------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// e^x for x <= 0 (softmax arguments, the negative side of ELU) in 6 VALU operations: 2^t off the hardware
+// exponential (1 ulp) with t = rn(x log2 e), corrected by the product's rounding error and the low part of
+// log2 e, which keeps ~2 ulp over the whole range (the library expf spends ~25 operations, most of them on ranges
+// that cannot occur here; a graph's n x K softmax runs on ONE CU, where every VALU operation of the phase costs
+// n K / 64 issue slots).  Underflows to 0 below ~ -87.
+__device__ __forceinline__ float exp_nonpos(float x) {
+  const float L2E = 1.4426950408889634f;
+  const float t = x * L2E;
+  float e = fmaf(x, L2E, -t);
+  e = fmaf(x, 1.925963033500011e-08f, e);             // log2 e - (float)log2 e
+  const float p = __builtin_amdgcn_exp2f(t);
+  return fmaf(p, e * 0.6931471805599453f, p);         // 2^(t + e) = 2^t (1 + e ln 2 + O(e^2)), |e| < 2^-17
+}
+
+// the hidden activation (model/hscn.py: SCN's mp_act).  ELU's negative side is e^x - 1 from exp_nonpos:
+// absolute error <= 1 ulp of 1.0 (expm1f is relatively exact near 0 and five times the operations).
+__device__ __forceinline__ float scn_act(float v, int act) {
+  switch (act) {
+    case HSCN_ACT_RELU: return v > 0.f ? v : 0.f;
+    case HSCN_ACT_ELU: return v > 0.f ? v : exp_nonpos(v) - 1.0f;
+    case HSCN_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
 // One 16 x 16 output tile on v_mfma_f32_16x16x4_f32: acc[r] <-> (tile row 4 * lj + r, tile column li)
 //   acc += sum_{k' < Kc} A[li][k'] * B[k'][bcol]
 // The contraction index is dealt to the four lane groups in contiguous runs (lane group lj: k' in
@@ -443,7 +472,7 @@ __device__ __forceinline__ void scn_hidden_tile(const ScnArgs& A, int rt, const 
     for (int r = 0; r < 4; ++r) {
       const int row = r0 + lj * 4 + r;
       if (row < n) {
-        const float v = rnd<TS>(apply_act((a1[r] + b) + a2[r], A.act));   // the hidden activation as its storage type holds it
+        const float v = rnd<TS>(scn_act((a1[r] + b) + a2[r], A.act));   // the hidden activation as its storage type holds it
         yl[row * H + ct * 16 + li] = v;
         if (A.y) stf(reinterpret_cast<TS*>(A.y), (size_t)(n0 + row) * H + ct * 16 + li, v);
       }
@@ -466,7 +495,7 @@ __device__ __forceinline__ void scn_hidden(const ScnArgs& A, const float* xs, co
   constexpr int NW = SRT / 64;
   const int ntile = (n + 15) >> 4;
   float d0[4], d1[4];
-  for (int rt = threadIdx.x >> 6; rt < ntile; rt += NW)
+  for (int rt = wave_id(); rt < ntile; rt += NW)
     scn_hidden_tile<H, TS, false>(A, rt, xs, agg, yl, WrT, WoT, brl, n0, n, d0, d1);
 }
 
@@ -484,7 +513,7 @@ __device__ __forceinline__ void scn_softmax(const ScnArgs& A, const float* yl, f
   const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
   const int ntile = (n + 15) >> 4;
   f32x4 ssacc = {0.f, 0.f, 0.f, 0.f};
-  for (int rt = threadIdx.x >> 6; rt < ntile; rt += NW) {
+  for (int rt = wave_id(); rt < ntile; rt += NW) {
     const int r0 = rt * 16;
     const float* yr = r0 + li < n ? yl + (r0 + li) * H : nullptr;
     float sc[4][4];
@@ -506,16 +535,17 @@ __device__ __forceinline__ void scn_softmax(const ScnArgs& A, const float* yl, f
       float ex[4], sum = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        ex[nt] = (nt < NT && nt * 16 + li < K) ? expf(sc[nt][r] - m) : 0.f;
+        ex[nt] = (nt < NT && nt * 16 + li < K) ? exp_nonpos(sc[nt][r] - m) : 0.f;
         sum += ex[nt];
       }
       sum = row16_sum(sum);
+      const float rs = __builtin_amdgcn_rcpf(sum);   // (1 ulp; sum in [1, K])
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int col = nt * 16 + li;
         float v = 0.f;
         if (nt < NT && col < K && row < n) {
-          v = ex[nt] / sum;
+          v = ex[nt] * rs;
           Sl[row * K + col] = v;
           if (A.S) A.S[(size_t)(n0 + row) * K + col] = v;
         }
@@ -523,9 +553,9 @@ __device__ __forceinline__ void scn_softmax(const ScnArgs& A, const float* yl, f
       }
     }
   }
-  if (NT == 1 && (int)(threadIdx.x >> 6) < ntile) {
+  if (NT == 1 && (int)(wave_id()) < ntile) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ss_part[(threadIdx.x >> 6) * 256 + (lj * 4 + r) * 16 + li] = ssacc[r];
+    for (int r = 0; r < 4; ++r) ss_part[(wave_id()) * 256 + (lj * 4 + r) * 16 + li] = ssacc[r];
   }
 }
 
@@ -619,7 +649,7 @@ __device__ __forceinline__ void scn_stats(const ScnArgs& A, const float* Sl, con
                                           const int* rowptr_d, const int* col_d, const float* dout, float* red,
                                           float* scratch, float* ssl, ScnStats& R, float* as_out, int n, int g) {
   const int K = A.K, KK = K * K;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = wave_id(), lane = threadIdx.x & 63;
   {
     float num = 0.f, den = 0.f;
     if ((K & 3) == 0) {
@@ -905,7 +935,7 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
                                               float* part, float num, float den) {
   constexpr int NW = SRT / 64, TD = H / 16;
   const int K = A.K, NT = (K + 15) >> 4;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+  const int wave = wave_id(), lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
   const int ntile = (n + 15) >> 4;
   const float gmc = (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
   const float c_num = -gmc / den, c_den = gmc * num / (den * den);
@@ -1205,13 +1235,10 @@ __global__ void __launch_bounds__(SRT) k_scn_step(const ScnArgs A) {
   float* ssl = fb + Y.ssl;
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
-#ifdef HSCN_REPEAT   // diagnostic: the body twice, the stamps of the second (instruction cache warm) pass survive
-  for (int rep = 0; rep < 2; ++rep) {
-#endif
   STAMP(0);
   scn_front<H, TS>(A, Y, fb, ib, n0, n, e0, ne, g);
   // (K % 4 == 0: hscn_scn_resident_train_step_supported)
-  const int wave = threadIdx.x >> 6, ntile = (n + 15) >> 4;
+  const int wave = wave_id(), ntile = (n + 15) >> 4;
   float xb[2][4], ab[2][4];    // x / agg of the wave's own tiles as B operands of the backward half
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -1242,20 +1269,13 @@ __global__ void __launch_bounds__(SRT) k_scn_step(const ScnArgs A) {
   }
   lds_barrier();
   STAMP(13);
+  // the statistics go out (write-through stores, drained, then the ticket) from the LAST wave, which owns at most
+  // one tile where the first ones own two: the drain hides behind the other waves' second tile
+  if (wave == NW - 1) scn_stats_publish(A, g, num, den, nrm, o);
   // (column tiles x hidden tiles <= 2: more accumulators than that do not fit the register file of 16 waves)
   if (H == 32 || K <= 16) scn_bwd_tiles<H, TS, 1>(A, n, Sl, yl, DL, dout, WmT, Gss, xb, ab, fb + Y.R1, part, num, den);
   else if constexpr (H == 16) scn_bwd_tiles<H, TS, 2>(A, n, Sl, yl, DL, dout, WmT, Gss, xb, ab, fb + Y.R1, part, num, den);
-  STAMP(62);
-#ifdef HSCN_REPEAT
   STAMP(63);
-  lds_barrier();
-  if (rep == 0) continue;
-#endif
-  if (threadIdx.x < 64) scn_stats_publish(A, g, num, den, nrm, o);   // off the critical path: after the backward half
-  STAMP(63);
-#ifdef HSCN_REPEAT
-  }
-#endif
 }
 
 __global__ void k_scn_losses(const float* __restrict__ stats, float* __restrict__ losses, int G) {

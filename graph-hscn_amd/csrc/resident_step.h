@@ -163,7 +163,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   float *dinv = fb + Y.dinv, *wt = fb + Y.wt, *headw = fb + Y.headw, *partp = fb + Y.part, *vec = fb + Y.vec;
   float* red = fb + Y.red;
   int *rowptr = ib + Y.rowptr, *col = ib + Y.col, *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (scalar: "tiles of this wave" loops stay uniform)
   const Grp ALL{(int)threadIdx.x, RT, wave, NW};
   constexpr int WL = H * H + H;   // words per layer in wt
 

@@ -56,8 +56,7 @@ def main():
         show(buf.cpu().numpy(), {0: "start", 1: "requests + park", 2: "two CSRs + degrees", 3: "aggregate",
                                  4: "y = act(W agg + W x), x/agg -> regs", 5: "logits + softmax",
                                  6: "neighbour terms + S^T S", 7: "norms", 13: "Gss",
-                                 14: "backward tiles (dS..dW partials)", 15: "park partials", 62: "fold -> HBM",
-                                 63: "publish statistics (ticket)"}, "scn step")
+                                 14: "backward tiles (dS..dW partials)", 15: "park partials", 63: "fold -> HBM"}, "scn step")
         return
     for _ in range(3):
         scn.zero_grad(set_to_none=True)
