@@ -383,7 +383,8 @@ def stage_a_main(args):
         st = ScnTrainStep(scn, big)
         g = capture(st.run)
         step = g.replay
-        issue = "hipGraph replay of the two fused launches (graph_hscn.step.ScnTrainStep)"
+        issue = ("hipGraph replay of the one-launch stage-A step + ordered fold (graph_hscn.step.ScnTrainStep)" if st.one_launch
+                 else "hipGraph replay of the forward / backward launch pair + ordered fold (graph_hscn.step.ScnTrainStep)")
     else:
         one = torch.ones((), device=dev)
 
@@ -702,7 +703,7 @@ def main():
         bigd = Batch.from_data_list(graphs).to(dev)
         bigd.x = bigd.x.half() if args.dtype == "f16" else bigd.x.float()
         if scn.resident_ok(bigd):
-            a_step = ScnTrainStep(scn, bigd)      # (mc + o).backward() as two launches, no autograd in the capture
+            a_step = ScnTrainStep(scn, bigd)      # (mc + o).backward() as ONE launch + the ordered fold, no autograd in the capture
             ga = capture(a_step.run)
             for _ in range(20):
                 ga.replay()
@@ -713,7 +714,8 @@ def main():
             torch.cuda.synchronize()
             ta = (time.perf_counter() - t0) / args.steps
             a_step.check()
-            stage_a = {"what": "gcn_norm + SCN fwd + (mincut+ortho) bwd, batched, graph-resident kernels",
+            stage_a = {"what": "gcn_norm + SCN fwd + (mincut+ortho) bwd, batched, graph-resident "
+                               + ("one-launch step" if a_step.one_launch else "launch pair"),
                        "ms_per_step": ta * 1e3, "graphs_per_s": B / ta,
                        "combined_A_plus_C_graphs_per_s": B / (ta + dt / args.steps)}
 

@@ -413,7 +413,7 @@ __device__ __forceinline__ float exp_nonpos(float x) {
 __device__ __forceinline__ float scn_act(float v, int act) {
   switch (act) {
     case HSCN_ACT_RELU: return v > 0.f ? v : 0.f;
-    case HSCN_ACT_ELU: return v > 0.f ? v : exp_nonpos(v) - 1.0f;
+    case HSCN_ACT_ELU: { const float e = exp_nonpos(fminf(v, 0.f)) - 1.0f; return v > 0.f ? v : e; }   // (branch free: the four rows of a lane interleave)
     case HSCN_ACT_TANH: return tanhf(v);
     default: return v;
   }
@@ -468,7 +468,7 @@ __device__ __forceinline__ void scn_hidden_tile(const ScnArgs& A, int rt, const 
     const f32x4 a1 = tile_mm(ar, FP, WrT, H, 1, ct * 16 + li, true, z);
     const f32x4 a2 = tile_mm(xr, FP, WoT, H, 1, ct * 16 + li, true, z);
     const float b = brl[ct * 16 + li];
-#pragma unroll
+  #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r0 + lj * 4 + r;
       if (row < n) {
