@@ -22,6 +22,7 @@ DEV = "cuda"
 
 
 FLIPS = [0, 0]      # [id flips tolerated as near-ties, nodes compared]
+ONE = [0]           # cases that also ran through the one-launch step
 
 
 def run(cases, seed, verbose=True):
@@ -77,6 +78,28 @@ def run(cases, seed, verbose=True):
             ok, d = close(pd.grad, po.grad, 2e-5, 3e-3)
             if not ok:
                 msgs.append(f"grad {n_} maxdiff {d:.2e} (ref max {float(po.grad.abs().max()):.2e})")
+        # the one-launch step (mc + o, the loop's loss) where the shape fits it, against the oracle's gradient of the same
+        from graph_hscn.step import ScnTrainStep
+        one = ScnTrainStep(pm, big.to(DEV))
+        if one.one_launch:
+            ONE[0] += 1
+            om.zero_grad()
+            for g in graphs:
+                _, mc_o, o_o, *_ = OM.scn_step_single_graph(om, g.x, g.edge_index)
+                ((mc_o + o_o) / B).backward()
+            one.run()
+            torch.cuda.synchronize()
+            one.check()
+            if not torch.equal(one.S, S_d.detach()):
+                msgs.append("one-launch S differs from the launch pair's")
+            if abs(float(one.losses[0]) - np.mean(mcs)) > 1e-5 or abs(float(one.losses[1]) - np.mean(os_)) > 1e-5:
+                msgs.append("one-launch losses")
+            names = {id(p_): n_ for n_, p_ in pm.named_parameters()}
+            ref = dict(om.named_parameters())
+            for p_, gview in one.param_grads:
+                ok, d = close(gview, ref[names[id(p_)]].grad, 2e-5, 3e-3)
+                if not ok:
+                    msgs.append(f"one-launch grad {names[id(p_)]} maxdiff {d:.2e}")
         bad += bool(msgs)
         if verbose:
             print(f"{'BAD' if msgs else 'ok '} case {case}: H={H} K={K} F={F} B={B} act={act} n={[g.num_nodes for g in graphs]} {'; '.join(msgs)}",
@@ -89,5 +112,6 @@ if __name__ == "__main__":
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad, refused = run(cases, seed)
     print(f"{cases - bad - refused}/{cases} cases match the oracle, {refused} refused, {bad} mismatch; "
-          f"cluster-id flips on near-ties (margin <= 1e-5): {FLIPS[0]} of {FLIPS[1]} nodes")
+          f"cluster-id flips on near-ties (margin <= 1e-5): {FLIPS[0]} of {FLIPS[1]} nodes; "
+          f"{ONE[0]} cases also through the one-launch step")
     sys.exit(1 if bad else 0)
