@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -67,6 +67,8 @@ _SIGNATURES = {
     "hscn_scn_resident_train_step_supported": (c_int, [c_int] * 5),
     "hscn_scn_resident_train_step": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P,
                                              P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "hscn_adam_step": (c_int, [P, P, c_int, P, P, P, c_int64, P, P, P, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                               ctypes.c_double, c_int, P]),
     "hscn_resident_supported": (c_int, [c_int] * 8),
     "hscn_resident_param_count": (c_int64, [c_int] * 4),
     "hscn_resident_fwd": (c_int, [P, P, P, c_int64, P, c_int64, P, c_int64, P, P, P, P, P, c_int64, c_int64,

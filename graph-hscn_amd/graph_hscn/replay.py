@@ -209,8 +209,10 @@ class CapturedStep:
         ``pre``: a callable captured in front of the step that refreshes the static buffers from device-side
         state only (``DeviceHeteroDataset.gather_next``); note that the warm-up iterations and the capture call
         it too (rewind with ``new_epoch`` afterwards).
-        ``optimizer``: a ``torch.optim`` optimizer built with ``capturable=True`` (``fused=True`` keeps it to one
-        launch); its ``step()`` is captured behind the backward, so a replay is a whole training iteration.
+        ``optimizer``: a ``torch.optim`` optimizer built with ``capturable=True`` (``fused=True`` keeps it to two
+        launches), or a callable ``step -> optim.FlatAdam`` (built on the step's flat gradient buffer: ONE launch;
+        afterwards ``self.optimizer``); its ``step()`` is captured behind the backward, so a replay is a whole
+        training iteration.
         The ``warmup`` eager iterations that precede the capture run the optimizer too (PyTorch's whole-network
         capture recipe); parameters and optimizer state are put back afterwards, IN PLACE (the captured launches
         hold their addresses): state that existed before is restored, state the warm-up created is zeroed (the
@@ -218,10 +220,12 @@ class CapturedStep:
         from .step import ResidentTrainStep
         self.model, self.static, self.loss_fn, self.optimizer = model, static, loss_fn, optimizer
         snap_p = snap_s = None
+        make_flat = callable(optimizer) and not hasattr(optimizer, "step")     # ``lambda step: optim.FlatAdam(...)``
         if optimizer is not None:
             snap_p = [p.detach().clone() for p in model.parameters()]
-            snap_s = {id(p): {k: v.clone() for k, v in st.items() if isinstance(v, Tensor)}
-                      for p, st in optimizer.state.items()}
+            if not make_flat:
+                snap_s = {id(p): {k: v.clone() for k, v in st.items() if isinstance(v, Tensor)}
+                          for p, st in optimizer.state.items()}
         hb = static.batch
         if "y" not in hb["local"]:
             raise ValueError("the static batch carries no targets")
@@ -232,6 +236,8 @@ class CapturedStep:
                                "work by tensor shapes, which a static-capacity batch does not carry): " + str(e)) from e
         self.step.bind_grads()
         model.last_engine = "resident"
+        if make_flat:          # built here: it needs the step's flat gradient buffer
+            optimizer = self.optimizer = optimizer(self.step)
 
         def step():
             if pre is not None:
@@ -259,11 +265,14 @@ class CapturedStep:
             with torch.no_grad():
                 for p, s0 in zip(model.parameters(), snap_p):
                     p.copy_(s0)
-                for p, st in optimizer.state.items():
-                    for k, v in st.items():
-                        if isinstance(v, Tensor):
-                            old = snap_s.get(id(p), {}).get(k)
-                            v.copy_(old) if old is not None else v.zero_()
+                if make_flat:
+                    optimizer.reset_state()
+                else:
+                    for p, st in optimizer.state.items():
+                        for k, v in st.items():
+                            if isinstance(v, Tensor):
+                                old = snap_s.get(id(p), {}).get(k)
+                                v.copy_(old) if old is not None else v.zero_()
 
     def replay(self) -> Tensor:
         self.graph.replay()

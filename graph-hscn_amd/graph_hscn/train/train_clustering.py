@@ -59,13 +59,16 @@ def _forward(model: SCN, graphs: Sequence, device, cache: dict = None, key=None)
     return model(big.x.to(device).float(), ei, ew, node_ptr=ptr), big.ptr
 
 
-def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, batch_graphs: int, device):
+def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, batch_graphs: int, device,
+                             flat_optimizer: bool = True):
     """The same loop with every step issued as direct C-ABI launches (``step.ScnTrainStep`` on one shared workspace:
-    forward launch, backward launch + ordered reduction) followed by ONE replay of the captured optimizer step --
-    three host calls per step instead of an autograd graph and an eager ``optimizer.step()`` (~170 us of Python per
-    graph).  Same schedule, same arithmetic: the reference's trajectory (tests/test_gpu_pipeline.py::
+    one launch for forward + losses + backward where the shape fits, else the launch pair + ordered reduction)
+    followed by the optimizer step as one more launch (``optim.FlatAdam``; a replay of torch's captured step for
+    optimizers it does not cover) -- two host calls per step instead of an autograd graph and an eager
+    ``optimizer.step()`` (~170 us of Python per graph).  Same schedule, same arithmetic: the reference's trajectory (tests/test_gpu_pipeline.py::
     test_stage_a_driver_follows_the_reference_trajectory).  Returns None when the model / optimizer / graphs do not
     qualify (the caller then takes the autograd loop)."""
+    from ..optim import FlatAdam
     from ..replay import capture_optimizer_step
     from ..step import ScnTrainStep, ScnWorkspace
     n = len(dataset)
@@ -89,13 +92,19 @@ def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, 
         d.x = d.x.float()
         steps.append(ScnTrainStep(model, d, workspace=ws))
     steps[0].bind_grads()                    # one set of gradient buffers for every step
-    opt_graph = capture_optimizer_step(model.parameters(), optimizer)
+    # Adam / AdamW: torch's update from the flat gradient buffer as ONE launch (optim.FlatAdam); other optimizers:
+    # one replay of torch's captured step
+    flat = FlatAdam.from_config(optim_cfg.optim_type, steps[0].param_grads, ws.grads, optim_cfg.lr,
+                                optim_cfg.weight_decay) if flat_optimizer else None
+    opt_step = flat.step if flat is not None else capture_optimizer_step(model.parameters(), optimizer).replay
     for epoch in range(model_cfg.cluster_epochs):
         if logger is not None:
             logger.info(f"Fitting clustering, epoch {epoch}...")
         for st in steps:                     # train_clustering.py:36-50: one optimizer step per graph (or per batch)
             st.run()
-            opt_graph.replay()
+            opt_step()
+    if flat is not None:
+        flat.check()
     if logger is not None:
         logger.info("Generating cluster assignments...")
     ids_dev = []

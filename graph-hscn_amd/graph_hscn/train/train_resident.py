@@ -24,7 +24,8 @@ from .train import eval_epoch, is_eval_epoch
 
 
 def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroData], eval_loaders: Sequence, model,
-                 batch_size: int, metric_fn: Optional[Callable] = None, seed: int = 0, reducer=None) -> List[tuple]:
+                 batch_size: int, metric_fn: Optional[Callable] = None, seed: int = 0, reducer=None,
+                 flat_optimizer: bool = True) -> List[tuple]:
     """Returns ``[(mean train loss, train metric), ...]`` per epoch, like ``train.train``.  ``eval_loaders`` =
     ``[validation, test]`` loaders of host batches (evaluated with ``train.eval_epoch``).
 
@@ -50,11 +51,17 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
     ds = DeviceHeteroDataset(train_graphs, dev, B)
     opt_cls = OPTIM_DICT[optim_cfg.optim_type]
     kw = dict(lr=optim_cfg.lr, weight_decay=optim_cfg.weight_decay)
-    try:
-        optimizer = opt_cls(model.parameters(), capturable=True, fused=True, **kw)
-    except (TypeError, RuntimeError):          # (Adagrad has neither switch: its step stays outside the graph)
-        optimizer = opt_cls(model.parameters(), **kw)
-    capturable = bool(optimizer.defaults.get("capturable", False))
+    flat = flat_optimizer and optim_cfg.optim_type in ("adam", "adamW")   # optim.FlatAdam: the update as ONE launch
+    if flat:
+        from ..optim import FlatAdam
+        optimizer = lambda st: FlatAdam.from_config(optim_cfg.optim_type, st.param_grads, st.grads, **kw)  # noqa: E731
+        capturable = True
+    else:
+        try:
+            optimizer = opt_cls(model.parameters(), capturable=True, fused=True, **kw)
+        except (TypeError, RuntimeError):          # (Adagrad has neither switch: its step stays outside the graph)
+            optimizer = opt_cls(model.parameters(), **kw)
+        capturable = bool(optimizer.defaults.get("capturable", False))
     in_graph = capturable      # the whole iteration -- backward, gradient all-reduce (if any), optimizer step -- is one graph
     gen = torch.Generator(device=dev).manual_seed(seed)
     model.train()
@@ -63,6 +70,8 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
     # the gather of the next permutation slice is captured in front of the step: a replay = next batch + iteration
     step = CapturedStep(model, ds.static, training_cfg.loss_fn, optimizer=optimizer if in_graph else None,
                         pre=ds.gather_next, reducer=reducer if in_graph else None)
+    if flat:
+        optimizer = step.optimizer
     steps, tail = G // B, G % B
     C = ds.C
     loss_log = torch.zeros(steps + (1 if tail else 0), dtype=torch.float32, device=dev)
@@ -93,7 +102,7 @@ def fit_resident(logger, optim_cfg, training_cfg, train_graphs: Sequence[HeteroD
             loss.backward()
             if reducer is not None:
                 reducer.reduce(float(tail), float(tail * reducer.world_size))
-            optimizer.step()
+            optimizer.step_from_autograd() if flat else optimizer.step()
             loss_log[steps].copy_(loss.detach())
             if metric_fn:
                 scores[steps * B:].copy_(score.detach())

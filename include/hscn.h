@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 6
+#define HSCN_ABI_VERSION 7
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -628,6 +628,22 @@ int hscn_scn_resident_bwd_f16(const hscn_half* x, const int64_t* edge_index, int
                               const int32_t* ex_col_d, const int32_t* ex_rowptr_s, const int32_t* ex_col_s,
                               const float* ex_agg, const float* ex_dout, int max_n, int max_e,
                               float* partials /*[B,P]*/, float* grads /*[P]*/, int32_t* flag, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * The optimizer step behind a resident training step as ONE launch: torch.optim.Adam / AdamW (the optimizers
+ * train/train.py:82 and train/train_clustering.py:30-33 build from config.py's OPTIM_DICT), single-tensor formulas
+ * operation for operation (torch/optim/adam.py::_single_tensor_adam), on parameters whose gradients lie in one flat
+ * buffer (what the resident steps produce).  params_host: HOST array of the nseg device pointers of the parameter
+ * tensors in flat order, seg_off_host: HOST int32 [nseg + 1] element offsets (0 .. P; both travel in the kernel
+ * arguments); exp_avg / exp_avg_sq [P] zero before the first step;
+ * step_dev: device float counter (incremented here); beta_pows_dev: device double [2] = {1, 1} before the first step
+ * (beta1^t, beta2^t, kept as running products); lr_dev: device double (a scheduler may rewrite it);
+ * decoupled != 0: AdamW's p *= 1 - lr * weight_decay instead of Adam's g += weight_decay * p.
+ * nseg <= 32; one workgroup (the model family has a few thousand parameters in ~10 tensors).
+ * ------------------------------------------------------------------------- */
+int hscn_adam_step(float* const* params_host, const int32_t* seg_off_host, int nseg, const float* grads,
+                   float* exp_avg, float* exp_avg_sq, int64_t P, float* step_dev, double* beta_pows_dev,
+                   const double* lr_dev, double beta1, double beta2, double eps, double weight_decay, int decoupled, void* stream);
 
 #ifdef __cplusplus
 }

@@ -167,6 +167,15 @@ def test_resident_training_loop_learns_and_visits_every_graph():
     assert len(hist) == 12                                          # 3 captured steps + a 2-graph eager tail per epoch
     assert all(np.isfinite(l) and 0.0 <= p <= 1.0 for l, p in hist)
     assert hist[-1][0] < hist[0][0]
+    # the update as one launch (optim.FlatAdam, the default for Adam / AdamW) against torch's captured fused AdamW:
+    # the same trajectory (eager ragged tail included) to float rounding
+    torch.manual_seed(0)
+    model3 = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, 10, 3).to("cuda")
+    hist3 = fit_resident(None, OptimConfig("adamW", lr=0.01), tc, hs[:50], loaders, model3, batch_size=16,
+                         metric_fn=eval_ap, flat_optimizer=False)
+    assert abs(hist3[-1][0] - hist[-1][0]) <= 1e-4 * max(1.0, abs(hist[-1][0]))
+    for a, b in zip(model.parameters(), model3.parameters()):
+        assert float((a - b).detach().abs().max()) <= 2e-4 * max(1.0, float(b.detach().abs().max()))
     # an optimizer without a capturable step (Adagrad) is stepped outside the graph on the captured gradients
     torch.manual_seed(0)
     model2 = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, 10, 3).to("cuda")

@@ -332,3 +332,55 @@ def test_one_launch_step_against_the_launch_pair_at_full_occupancy(name, B, K, H
             assert grads_close(one.grads[:-1], pair.grads[:-1]) and torch.equal(one.grads[-1], pair.grads[-1])
         assert torch.equal(one.grads, first), it          # bitwise reproducible
     one.check()
+
+
+@pytest.mark.parametrize("kind,wd", [("adam", 0.0), ("adam", 0.01), ("adamW", 0.01)])
+def test_flat_adam_is_torch_adam(kind, wd):
+    """optim.FlatAdam (one launch on the flat gradient buffer, hscn_adam_step) against torch.optim.Adam / AdamW on
+    the CPU (single-tensor implementation, the oracle's optimizer) fed the same gradients for 60 steps, with a
+    learning-rate change on the way: parameters agree to float rounding at every step (1e-6 of the parameter scale --
+    the two sides differ only in fma contraction and the association of addcdiv)."""
+    from graph_hscn.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes = [(16, 9), (16,), (16, 9), (16, 16), (16,), (7, 3, 5)]
+    cpu_p = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    dev_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in cpu_p]
+    P = sum(p.numel() for p in cpu_p)
+    flat = torch.zeros(P + 1, device=dev)        # (+ 1: the resident steps keep a loss column behind the gradients)
+    views, off = [], 0
+    for p in dev_p:
+        views.append((p, flat[off: off + p.numel()].view_as(p)))
+        off += p.numel()
+    opt_cls = torch.optim.Adam if kind == "adam" else torch.optim.AdamW
+    ref = opt_cls(cpu_p, lr=0.01, weight_decay=wd)
+    mine = FlatAdam.from_config(kind, views, flat, 0.01, wd)
+    assert FlatAdam.from_config("adagrad", views, flat, 0.01, wd) is None
+    g = torch.cuda.CUDAGraph()
+    mine.step()                                  # warm-up launch, undone below
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for p, q in zip(dev_p, cpu_p):
+            p.copy_(q)
+    mine.reset_state()
+    with torch.cuda.graph(g):
+        mine.step()
+    with torch.no_grad():                        # (the capture does not execute)
+        assert all(torch.equal(p.cpu(), q) for p, q in zip(dev_p, cpu_p))
+    for it in range(60):
+        if it == 30:
+            for grp in ref.param_groups:
+                grp["lr"] = 0.003
+            mine.set_lr(0.003)
+        grads = [torch.randn(s) * (0.1 + it % 3) for s in shapes]
+        for p, gr in zip(cpu_p, grads):
+            p.grad = gr
+        flat[:P].copy_(torch.cat([gr.reshape(-1) for gr in grads]))
+        ref.step()
+        g.replay() if it % 2 else mine.step()
+        torch.cuda.synchronize()
+        for p, q in zip(dev_p, cpu_p):
+            scale = max(1.0, float(q.abs().max()))
+            assert float((p.detach().cpu() - q.detach()).abs().max()) <= 1e-6 * scale, (it, kind)
+    assert float(mine.step_count) == 60.0
+    mine.check()

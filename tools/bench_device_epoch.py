@@ -39,17 +39,20 @@ def main(G=4096, B=128, K=16, epochs=5):
     ds.new_epoch(gen)
     step = CapturedStep(model, ds.static, "cross_entropy", pre=ds.gather_next)     # gather + step in one graph
     step_opt = CapturedStep(model, ds.static, "cross_entropy", optimizer=opt, pre=ds.gather_next)   # + AdamW
+    from graph_hscn.optim import FlatAdam
+    step_flat = CapturedStep(model, ds.static, "cross_entropy", pre=ds.gather_next,      # + AdamW as ONE launch
+                             optimizer=lambda st: FlatAdam.from_config("adamW", st.param_grads, st.grads, 1e-3, 0.01))
     steps = G // B
 
     def epoch(with_opt):
         ds.new_epoch(gen)
-        st = step_opt if with_opt else step
+        st = {False: step, True: step_opt, "flat": step_flat}[with_opt]
         for i in range(steps):
             st.replay()
 
     out = {"graphs": G, "graphs_per_batch": B, "dataset_bytes": ds.nbytes, "static_buffer_bytes": ds.static.nbytes,
            "host_transform_s": t_host_transform, "dataset_build_s": t_build}
-    for with_opt in (False, True):
+    for with_opt in (False, True, "flat"):
         epoch(with_opt)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -57,7 +60,7 @@ def main(G=4096, B=128, K=16, epochs=5):
             epoch(with_opt)
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / (epochs * steps)
-        key = "with_fused_adamw_in_graph" if with_opt else "fwd_loss_bwd"
+        key = {False: "fwd_loss_bwd", True: "with_fused_adamw_in_graph", "flat": "with_flat_adamw_in_graph"}[with_opt]
         out[key] = {"ms_per_step": t * 1e3, "graphs_per_s": B / t}
     ds.check()
     print(json.dumps(out))

@@ -41,9 +41,12 @@ def main(G=1024, epochs=5, K=16):
         torch.cuda.synchronize()
         t2 = time.perf_counter() - t0
         per_visit = (t2 - t) / (2 * epochs * G)
+        # (batched: 8 steps per epoch -- the difference of two runs is within the noise of their setup; only the
+        # whole-run figure is reported)
+        steady = per_visit > 0 and bg == 1
         out[f"batch_graphs={bg}"] = {"seconds": t, "graph_visits_per_s": G * (epochs + 1) / t,
-                                     "steady_state_us_per_graph_visit": per_visit * 1e6,
-                                     "steady_state_graphs_per_s": 1.0 / per_visit}
+                                     "steady_state_us_per_graph_visit": per_visit * 1e6 if steady else None,
+                                     "steady_state_graphs_per_s": 1.0 / per_visit if steady else None}
     print(json.dumps(out))
 
 
