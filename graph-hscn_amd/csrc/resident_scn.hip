@@ -41,6 +41,7 @@ struct ScnArgs {
   // exported (graph g: rowptr at nptr[g] + g, columns at eptr[g]) and loaded by the backward launch
   int32_t *ex_rowptr_d, *ex_col_d, *ex_rowptr_s, *ex_col_s;
   float *ex_agg, *ex_dout;  // [N,FP], [N]
+  int pre;                  // one-launch step: the ex_* arrays hold this batch's structure already (loaded, not built)
   // forward only: losses [3] = {mean mincut, mean ortho, their sum}; with a ticket counter (zero before
   // the first launch, left at zero) the workgroup that finishes last reduces the per-graph statistics
   float* losses;
@@ -48,6 +49,13 @@ struct ScnArgs {
   int32_t* flag;
   int64_t N;
   int F, K, act, max_n, max_e, B, P;
+  // one-launch step with ONE graph: the optimizer step (torch's single-tensor Adam / AdamW, csrc/optim.hip) in the
+  // tail of the same launch -- the workgroup holds the whole gradient.  adam_m == NULL: no update.
+  float *adam_m, *adam_v, *adam_step;
+  double* adam_pows;
+  const double* adam_lr;
+  double adam_b1, adam_b2, adam_eps, adam_wd;
+  int adam_decoupled;
 };
 
 struct ScnLayout {
@@ -277,13 +285,32 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   }
   if (wbase < H) vb = A.b_rel[threadIdx.x < H ? threadIdx.x : 0];
   if (wbase < K) vm = A.b_mlp[(int)threadIdx.x < K ? threadIdx.x : 0];
+  const bool pre = A.pre != 0;   // the structure of an earlier visit of this batch (ex_*): loaded, not rebuilt
+  constexpr int RPT = 2;
+  int rdp[RPT], rsp[RPT], cdp[EPT], csp[EPT];
+  float dop[RPT], agr[XPT];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     const int e = threadIdx.x + i * SRT;
-    rd[i] = 0; rs[i] = 0;
+    rd[i] = 0; rs[i] = 0; cdp[i] = 0; csp[i] = 0;
     if (wbase + i * SRT < ne) {
-      rd[i] = A.dst[e < ne ? e0 + e : e0];
-      rs[i] = A.src[e < ne ? e0 + e : e0];
+      if (!pre) {
+        rd[i] = A.dst[e < ne ? e0 + e : e0];
+        rs[i] = A.src[e < ne ? e0 + e : e0];
+      } else {
+        cdp[i] = A.ex_col_d[(size_t)e0 + (e < ne ? e : 0)];
+        csp[i] = A.ex_col_s[(size_t)e0 + (e < ne ? e : 0)];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int idx = threadIdx.x + i * SRT;
+    rdp[i] = 0; rsp[i] = 0; dop[i] = 0.f;
+    if (pre && wbase + i * SRT <= n) {
+      rdp[i] = A.ex_rowptr_d[(size_t)n0 + g + (idx <= n ? idx : 0)];
+      rsp[i] = A.ex_rowptr_s[(size_t)n0 + g + (idx <= n ? idx : 0)];
+      dop[i] = A.ex_dout[(size_t)n0 + (idx < n ? idx : 0)];
     }
   }
 #pragma unroll
@@ -291,10 +318,11 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
     const int idx = threadIdx.x + i * SRT;
     const int r = idx / FP, k = idx - r * FP;
     const bool ok = idx < n * FP && k < F;
-    xr[i] = 0.f;
+    xr[i] = 0.f; agr[i] = 0.f;
     if (wbase + i * SRT < n * FP) {
       const float t = ldf(xg, ok ? (size_t)(n0 + r) * F + k : 0);
       xr[i] = ok ? t : 0.f;
+      if (pre) agr[i] = A.ex_agg[(size_t)n0 * FP + (idx < n * FP ? idx : 0)];
     }
   }
   // ---- park ----
@@ -306,13 +334,42 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
     ek[e] = k;
     eo[e] = o;
   };
+  if (!pre) {
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int e = threadIdx.x + i * SRT;
-    if (e < ne) stage_edge(e, rd[i], rs[i]);
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * SRT;
+      if (e < ne) stage_edge(e, rd[i], rs[i]);
+    }
+    for (int e = threadIdx.x + EPT * SRT; e < ne; e += SRT) stage_edge(e, A.dst[e0 + e], A.src[e0 + e]);
+    if (bad && A.flag) atomicOr(A.flag, 2);
+  } else {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = threadIdx.x + i * SRT;
+      if (e < ne) { col_d[e] = cdp[i]; col_s[e] = csp[i]; }
+    }
+    for (int e = threadIdx.x + EPT * SRT; e < ne; e += SRT) {
+      col_d[e] = A.ex_col_d[(size_t)e0 + e];
+      col_s[e] = A.ex_col_s[(size_t)e0 + e];
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int idx = threadIdx.x + i * SRT;
+      if (idx <= n) { rowptr_d[idx] = rdp[i]; rowptr_s[idx] = rsp[i]; }
+      if (idx < n) dout[idx] = dop[i];
+    }
+    for (int idx = threadIdx.x + RPT * SRT; idx <= n; idx += SRT) {
+      rowptr_d[idx] = A.ex_rowptr_d[(size_t)n0 + g + idx];
+      rowptr_s[idx] = A.ex_rowptr_s[(size_t)n0 + g + idx];
+      if (idx < n) dout[idx] = A.ex_dout[(size_t)n0 + idx];
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int idx = threadIdx.x + i * SRT;
+      if (idx < n * FP) agg[idx] = agr[i];
+    }
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = A.ex_agg[(size_t)n0 * FP + idx];
   }
-  for (int e = threadIdx.x + EPT * SRT; e < ne; e += SRT) stage_edge(e, A.dst[e0 + e], A.src[e0 + e]);
-  if (bad && A.flag) atomicOr(A.flag, 2);
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int idx = threadIdx.x + i * SRT;
@@ -340,6 +397,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   }
   lds_barrier();
   STAMP(1);
+  if (pre) { STAMP(2); STAMP(3); return; }   // CSRs, out-degrees and A_hat x are in place
   // ---- structure: the two CSRs side by side (same barrier sequence in both wave groups) ----
   {
     const bool second = wave >= NW / 2;
@@ -1074,6 +1132,37 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
     float v = 0.f;
     for (int w = 0; w < NWA; ++w) v += scratch[(size_t)w * WSZ + off];
     part[p] = v;
+    if (A.adam_m) {   // B == 1: v IS the gradient of parameter element p -- the Adam step of csrc/optim.hip, same operations
+      float* pp = p < obrel ? const_cast<float*>(A.W_rel) + p
+                : p < oWroot ? const_cast<float*>(A.b_rel) + (p - obrel)
+                : p < oWmlp ? const_cast<float*>(A.W_root) + (p - oWroot)
+                : p < obmlp ? const_cast<float*>(A.W_mlp) + (p - oWmlp) : const_cast<float*>(A.b_mlp) + (p - obmlp);
+      const double lr = A.adam_lr[0];
+      const double b1t = A.adam_pows[0] * A.adam_b1, b2t = A.adam_pows[1] * A.adam_b2;
+      const float step_size = (float)(lr / (1.0 - b1t)), bc2_sqrt = (float)sqrt(1.0 - b2t);
+      const float w1 = (float)(1.0 - A.adam_b1), w2 = (float)(1.0 - A.adam_b2), b2f = (float)A.adam_b2;
+      float pv = *pp, g_ = v, m = A.adam_m[p], vv = A.adam_v[p];
+      if (A.adam_wd != 0.0) {
+        if (A.adam_decoupled) pv = pv * (float)(1.0 - lr * A.adam_wd);
+        else g_ = g_ + (float)A.adam_wd * pv;
+      }
+      m = m + w1 * (g_ - m);
+      vv = vv * b2f;
+      vv = vv + (w2 * g_) * g_;
+      const float denom = sqrtf(vv) / bc2_sqrt + (float)A.adam_eps;
+      pv = pv + (-step_size) * (m / denom);
+      *pp = pv;
+      A.adam_m[p] = m;
+      A.adam_v[p] = vv;
+    }
+  }
+  if (A.adam_m) {
+    lds_barrier();   // every thread has read the counters
+    if (threadIdx.x == 0) {
+      A.adam_step[0] = A.adam_step[0] + 1.0f;
+      A.adam_pows[0] = A.adam_pows[0] * A.adam_b1;
+      A.adam_pows[1] = A.adam_pows[1] * A.adam_b2;
+    }
   }
 }
 
@@ -1338,8 +1427,15 @@ static int scn_step_impl(int f16, const float* x, const int64_t* edge_index, int
                          const float* b_rel, const float* W_root, const float* W_mlp, const float* b_mlp,
                          const float* g_mc, const float* g_o, int max_n, int max_e, float* S, float* stats,
                          float* losses, int32_t* ticket, float* partials, float* grads, int32_t* flag,
-                         void* stream_) {
+                         const hscn_adam* opt, const hscn_scn_structure* cache, void* stream_) {
   if (B < 1 || N < 0 || E < 0) return HSCN_E_BADARG;
+  if (cache && (!cache->rowptr_d || !cache->rowptr_s || !cache->agg || !cache->dout ||
+                (E > 0 && (!cache->col_d || !cache->col_s))))
+    return HSCN_E_BADARG;
+  if (opt && (B != 1 || !opt->exp_avg || !opt->exp_avg_sq || !opt->step || !opt->beta_pows || !opt->lr ||
+              !(opt->beta1 >= 0.0 && opt->beta1 < 1.0 && opt->beta2 >= 0.0 && opt->beta2 < 1.0) || !(opt->eps >= 0.0) ||
+              !(opt->weight_decay >= 0.0)))
+    return HSCN_E_BADARG;
   if (!hscn_scn_resident_train_step_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
   if (!x || !nptr || !eptr || !W_rel || !b_rel || !W_root || !W_mlp || !b_mlp || !stats || !losses || !grads ||
       (B > 1 && !partials) || (E > 0 && !edge_index))
@@ -1351,6 +1447,15 @@ static int scn_step_impl(int f16, const float* x, const int64_t* edge_index, int
   A.losses = losses; A.ticket = ticket;
   A.max_n = max_n; A.max_e = max_e; A.B = (int)B; A.P = (int)scn_param_count(F, H, K);
   A.partials = B == 1 ? grads : partials;   // one graph: its partials are the gradients
+  if (cache) {   // ready: load the structure an earlier visit exported; else build it and export
+    A.ex_rowptr_d = cache->rowptr_d; A.ex_col_d = cache->col_d; A.ex_rowptr_s = cache->rowptr_s;
+    A.ex_col_s = cache->col_s; A.ex_agg = cache->agg; A.ex_dout = cache->dout; A.pre = cache->ready != 0;
+  }
+  if (opt) {
+    A.adam_m = opt->exp_avg; A.adam_v = opt->exp_avg_sq; A.adam_step = opt->step; A.adam_pows = opt->beta_pows;
+    A.adam_lr = opt->lr; A.adam_b1 = opt->beta1; A.adam_b2 = opt->beta2; A.adam_eps = opt->eps;
+    A.adam_wd = opt->weight_decay; A.adam_decoupled = opt->decoupled;
+  }
   hipStream_t st = hscn_stream(stream_);
   int rc = f16 ? (H == 16 ? launch_scn<16, half_t>(A, 2, st) : launch_scn<32, half_t>(A, 2, st))
                : (H == 16 ? launch_scn<16, float>(A, 2, st) : launch_scn<32, float>(A, 2, st));
@@ -1458,18 +1563,21 @@ int hscn_scn_resident_train_step(const float* x, const int64_t* edge_index, int6
                                  const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,
                                  const float* b_mlp, const float* g_mc, const float* g_o, int max_n, int max_e,
                                  float* S, float* stats, float* losses, int32_t* ticket, float* partials,
-                                 float* grads, int32_t* flag, void* stream_) {
+                                 float* grads, int32_t* flag, const hscn_adam* opt,
+                                 const hscn_scn_structure* cache, void* stream_) {
   return scn_step_impl(0, x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_rel, b_rel, W_root, W_mlp, b_mlp, g_mc,
-                       g_o, max_n, max_e, S, stats, losses, ticket, partials, grads, flag, stream_);
+                       g_o, max_n, max_e, S, stats, losses, ticket, partials, grads, flag, opt, cache, stream_);
 }
 int hscn_scn_resident_train_step_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                                      const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                                      const float* W_rel, const float* b_rel, const float* W_root,
                                      const float* W_mlp, const float* b_mlp, const float* g_mc, const float* g_o,
                                      int max_n, int max_e, float* S, float* stats, float* losses, int32_t* ticket,
-                                     float* partials, float* grads, int32_t* flag, void* stream_) {
+                                     float* partials, float* grads, int32_t* flag, const hscn_adam* opt,
+                                     const hscn_scn_structure* cache, void* stream_) {
   return scn_step_impl(1, (const float*)x, edge_index, E, nptr, eptr, N, B, F, H, K, act, W_rel, b_rel, W_root,
-                       W_mlp, b_mlp, g_mc, g_o, max_n, max_e, S, stats, losses, ticket, partials, grads, flag, stream_);
+                       W_mlp, b_mlp, g_mc, g_o, max_n, max_e, S, stats, losses, ticket, partials, grads, flag, opt,
+                       cache, stream_);
 }
 // IEEE-half storage of the node features x and of the saved hidden activation y (include/hscn.h); S, the
 // statistics, the exported aggregation A_hat x (an accumulator output) and every gradient stay float.

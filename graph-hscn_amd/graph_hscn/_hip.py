@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 7
+ABI_VERSION = 9
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -66,7 +66,7 @@ _SIGNATURES = {
                                       P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "hscn_scn_resident_train_step_supported": (c_int, [c_int] * 5),
     "hscn_scn_resident_train_step": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P,
-                                             P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
+                                             P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_adam_step": (c_int, [P, P, c_int, P, P, P, c_int64, P, P, P, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                ctypes.c_double, c_int, P]),
     "hscn_resident_supported": (c_int, [c_int] * 8),

@@ -20,6 +20,13 @@ from torch import Tensor
 from . import _hip
 
 
+class _AdamC(ctypes.Structure):        # include/hscn.h: hscn_adam
+    _fields_ = [("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("step", ctypes.c_void_p),
+                ("beta_pows", ctypes.c_void_p), ("lr", ctypes.c_void_p), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double),
+                ("decoupled", ctypes.c_int)]
+
+
 class FlatAdam:
     """``param_grads``: ``[(parameter, view of its gradient inside flat_grads)]`` in flat order -- what
     ``ResidentTrainStep.param_grads`` / ``ScnTrainStep.param_grads`` hold.  ``decoupled=True`` is ``AdamW``.
@@ -57,6 +64,16 @@ class FlatAdam:
         self._beta_pows = torch.ones(2, dtype=torch.float64, device=dev)      # beta1^t, beta2^t (running products)
         self._lr = torch.tensor([float(lr)], dtype=torch.float64, device=dev)
         self.lr = float(lr)
+
+    @property
+    def c(self) -> _AdamC:
+        """The state as ``hscn_adam`` (for a step that applies the update in its own launch:
+        ``ScnTrainStep.run(opt=...)``)."""
+        if not hasattr(self, "_c"):
+            self._c = _AdamC(_hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq), _hip.ptr(self.step_count),
+                             _hip.ptr(self._beta_pows), _hip.ptr(self._lr), self.betas[0], self.betas[1], self.eps,
+                             self.weight_decay, int(self.decoupled))
+        return self._c
 
     def set_lr(self, lr: float) -> None:
         """A scheduler's new learning rate (one tiny copy; the captured launch reads the device value)."""

@@ -250,6 +250,36 @@ class ScnWorkspace:
         self.flag = torch.zeros(1, **i32)
 
 
+class _ScnStructC(ctypes.Structure):      # include/hscn.h: hscn_scn_structure
+    _fields_ = [("rowptr_d", ctypes.c_void_p), ("col_d", ctypes.c_void_p), ("rowptr_s", ctypes.c_void_p),
+                ("col_s", ctypes.c_void_p), ("agg", ctypes.c_void_p), ("dout", ctypes.c_void_p), ("ready", ctypes.c_int)]
+
+
+class ScnStructurePool:
+    """HBM for the per-batch structure (``hscn_scn_structure``) of every step of a stage-A loop, allocated once:
+    ``take(N, E, B)`` hands a step its slices.  What it holds is derived from the graphs and the input features
+    alone, so a step builds it on its first visit and loads it on the others (train/train_clustering.py:34 revisits
+    every graph ``cluster_epochs`` times)."""
+
+    def __init__(self, device, total_nodes: int, total_edges: int, total_graphs: int):
+        i32 = dict(dtype=torch.int32, device=device)
+        self._rp = [torch.empty(max(total_nodes + total_graphs, 1), **i32) for _ in range(2)]
+        self._col = [torch.empty(max(total_edges, 1), **i32) for _ in range(2)]
+        # (node-indexed arrays are sliced at the row-pointer offsets, which count one more word per graph)
+        self._agg = torch.empty(max(total_nodes + total_graphs, 1), 16, dtype=torch.float32, device=device)
+        self._dout = torch.empty(max(total_nodes + total_graphs, 1), dtype=torch.float32, device=device)
+        self._n = self._e = 0
+
+    def take(self, N: int, E: int, B: int) -> _ScnStructC:
+        n, e = self._n, self._e
+        if n + N + B > self._rp[0].numel() or e + E > self._col[0].numel():
+            raise ValueError("the structure pool is smaller than the loop's graphs")
+        self._n, self._e = n + N + B, e + E
+        p = _hip.ptr
+        return _ScnStructC(p(self._rp[0][n:]), p(self._col[0][e:]), p(self._rp[1][n:]), p(self._col[1][e:]),
+                           p(self._agg[n:]), p(self._dout[n:]), 0)
+
+
 class ScnTrainStep:
     """``optimizer.zero_grad(); S, mc, o = model.forward_graphs(data); (mc + o).backward()`` -- the body of
     the reference's clustering loop (train/train_clustering.py:37-49) for one ``Data`` graph or a block-diagonal
@@ -258,10 +288,12 @@ class ScnTrainStep:
     Outputs refreshed by ``run()``: ``S`` [N,K] (softmax assignment), ``losses`` [3] = {mincut, ortho, their sum},
     ``grads`` (flat: W_rel, b_rel, W_root, W_mlp, b_mlp)."""
 
-    def __init__(self, model, data, workspace: Optional[ScnWorkspace] = None, one_launch: Optional[bool] = None):
+    def __init__(self, model, data, workspace: Optional[ScnWorkspace] = None, one_launch: Optional[bool] = None,
+                 structure_pool: Optional["ScnStructurePool"] = None):
         """``one_launch``: forward, losses and backward of a graph in ONE workgroup program
-        (``hscn_scn_resident_train_step``; bit-identical to the pair of launches).  Default: whenever the graphs
-        fit; ``False`` keeps the forward / backward pair."""
+        (``hscn_scn_resident_train_step``).  Default: whenever the graphs fit; ``False`` keeps the forward /
+        backward pair.  ``structure_pool``: keep this batch's CSRs, out-degrees and ``A_hat x`` in HBM after the first
+        ``run()`` and load them on later visits (one-launch step only; same results bit for bit)."""
         from .model.hscn import SCN
         if not isinstance(model, SCN):
             raise TypeError("ScnTrainStep drives graph_hscn.model.hscn.SCN")
@@ -303,6 +335,8 @@ class ScnTrainStep:
             off += p.numel()
         assert off == P
         self.param_grads = views
+        self._one_args = {}
+        self._cache = structure_pool.take(N, E, B) if (structure_pool is not None and self.one_launch) else None
 
     @property
     def loss(self) -> Tensor:
@@ -312,17 +346,57 @@ class ScnTrainStep:
         for p, g in self.param_grads:
             p.grad = g
 
-    def run(self) -> Tensor:
+    def fuses_optimizer(self, opt) -> bool:
+        """``run(opt=opt)`` can apply ``opt`` (an ``optim.FlatAdam`` over THIS step's ``param_grads``) inside the
+        step's own launch: one graph per step, the one-launch kernel, parameters that are their own storage."""
+        return (self.one_launch and self.dims[4] == 1 and opt is not None and getattr(opt, "grads", None) is self.grads
+                and all(p.is_contiguous() for p in self._mp)
+                and [id(p) for p in getattr(opt, "params", [])] == [id(p) for p in self._mp])
+
+    def run(self, opt=None) -> Tensor:
+        """``opt``: ``optimizer.step()`` (train/train_clustering.py:50) in the tail of the same launch -- see
+        ``fuses_optimizer``; the parameters are updated in place, ``grads`` still receives the gradient."""
+        if self.one_launch:
+            # the argument list of a step is the same every visit (device pointers of buffers allocated once, the
+            # parameters' own storage): built on the first call, per optimizer; a visit is then ONE foreign call
+            key = id(opt)
+            hit = self._one_args.get(key)
+            if hit is None or hit[0] != tuple(p.data_ptr() for p in self._mp):
+                if opt is not None and not self.fuses_optimizer(opt):
+                    raise ValueError("this step cannot carry the optimizer step (see ScnTrainStep.fuses_optimizer)")
+                N, F, H, K, B, E = self.dims
+                m = self.meta
+                W = [p if p.is_contiguous() else None for p in self._mp]
+                if any(w is None for w in W):
+                    hit = None          # (non-contiguous parameters: the slow path below makes copies every call)
+                else:
+                    hit = (tuple(p.data_ptr() for p in self._mp),
+                           (ptr(self.x), ptr(self.ei) if E else None, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K,
+                            self.act, *[ptr(w) for w in W], ptr(self.one), ptr(self.one), m.max_n, m.max_e,
+                            ptr(self.S), ptr(self.stats), ptr(self.losses), ptr(m.ticket), ptr(self.partials),
+                            ptr(self.grads), ptr(m.flag), ctypes.byref(opt.c) if opt is not None else None,
+                            ctypes.byref(self._cache) if self._cache is not None else None))
+                    self._one_args[key] = hit
+            if hit is not None:
+                call("hscn_scn_resident_train_step" + self._sfx, *hit[1], stream())
+                if self._cache is not None:
+                    self._cache.ready = 1          # (read at issue time: the launch in flight saw 0 and exports)
+                return self.losses[2]
         N, F, H, K, B, E = self.dims
         m = self.meta
         W_rel, b_rel, W_root, W_mlp, b_mlp = (p.contiguous() for p in self._mp)
         st = stream()
         eip = ptr(self.ei) if E else None
+        if opt is not None:
+            raise ValueError("this step cannot carry the optimizer step (see ScnTrainStep.fuses_optimizer)")
         if self.one_launch:
             call("hscn_scn_resident_train_step" + self._sfx, ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H,
                  K, self.act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), ptr(self.one),
                  ptr(self.one), m.max_n, m.max_e, ptr(self.S), ptr(self.stats), ptr(self.losses), ptr(m.ticket),
-                 ptr(self.partials), ptr(self.grads), ptr(m.flag), st)
+                 ptr(self.partials), ptr(self.grads), ptr(m.flag), None,
+                 ctypes.byref(self._cache) if self._cache is not None else None, st)
+            if self._cache is not None:
+                self._cache.ready = 1
             return self.losses[2]
         call("hscn_scn_resident_fwd" + self._sfx, ptr(self.x), eip, E, ptr(m.nptr), ptr(m.eptr), N, B, F, H, K, self.act,
              ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), m.max_n, m.max_e, ptr(self.S), ptr(self.y),

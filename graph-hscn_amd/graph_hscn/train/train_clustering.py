@@ -70,7 +70,7 @@ def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, 
     qualify (the caller then takes the autograd loop)."""
     from ..optim import FlatAdam
     from ..replay import capture_optimizer_step
-    from ..step import ScnTrainStep, ScnWorkspace
+    from ..step import ScnStructurePool, ScnTrainStep, ScnWorkspace
     n = len(dataset)
     groups = [[dataset[j] for j in range(i, min(i + batch_graphs, n))] for i in range(0, n, batch_graphs)]
     datas = [g[0] if len(g) == 1 else Batch.from_data_list(g) for g in groups]
@@ -86,23 +86,31 @@ def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, 
     K = lin.weight.shape[0]
     ws = ScnWorkspace(device, max(int(d.num_nodes) for d in datas), max(int(d.edge_index.size(1)) for d in datas),
                       max(len(g) for g in groups), F, H, K)
+    # CSRs, out-degrees and A_hat x of every step stay in HBM after the first epoch (built from the graph and the
+    # input features alone): later visits load them
+    pool = ScnStructurePool(device, sum(int(d.num_nodes) for d in datas), sum(int(d.edge_index.size(1)) for d in datas),
+                            sum(len(g) for g in groups)) if model_cfg.cluster_epochs > 1 else None
     steps = []
     for d in datas:                          # the graphs go to the device once (the loop revisits them every epoch)
         d = d.to(device)
         d.x = d.x.float()
-        steps.append(ScnTrainStep(model, d, workspace=ws))
+        steps.append(ScnTrainStep(model, d, workspace=ws, structure_pool=pool))
     steps[0].bind_grads()                    # one set of gradient buffers for every step
     # Adam / AdamW: torch's update from the flat gradient buffer as ONE launch (optim.FlatAdam); other optimizers:
     # one replay of torch's captured step
     flat = FlatAdam.from_config(optim_cfg.optim_type, steps[0].param_grads, ws.grads, optim_cfg.lr,
                                 optim_cfg.weight_decay) if flat_optimizer else None
     opt_step = flat.step if flat is not None else capture_optimizer_step(model.parameters(), optimizer).replay
-    for epoch in range(model_cfg.cluster_epochs):
+    fused = [flat is not None and st.fuses_optimizer(flat) for st in steps]   # one graph per step: the update rides
+    for epoch in range(model_cfg.cluster_epochs):                            # in the tail of the step's own launch
         if logger is not None:
             logger.info(f"Fitting clustering, epoch {epoch}...")
-        for st in steps:                     # train_clustering.py:36-50: one optimizer step per graph (or per batch)
-            st.run()
-            opt_step()
+        for st, fu in zip(steps, fused):     # train_clustering.py:36-50: one optimizer step per graph (or per batch)
+            if fu:
+                st.run(opt=flat)
+            else:
+                st.run()
+                opt_step()
     if flat is not None:
         flat.check()
     if logger is not None:

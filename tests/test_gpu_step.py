@@ -384,3 +384,53 @@ def test_flat_adam_is_torch_adam(kind, wd):
             assert float((p.detach().cpu() - q.detach()).abs().max()) <= 1e-6 * scale, (it, kind)
     assert float(mine.step_count) == 60.0
     mine.check()
+
+
+@pytest.mark.parametrize("kind,wd,dtype", [("adam", 0.0, torch.float32), ("adamW", 0.01, torch.float32),
+                                           ("adam", 0.01, torch.float16)])
+def test_scn_step_with_the_optimizer_in_its_tail(kind, wd, dtype):
+    """One graph per step (the reference's trajectory, train_clustering.py:36-50): ``ScnTrainStep.run(opt=FlatAdam)``
+    -- forward, losses, backward AND optimizer.step() in one launch -- against the same step followed by
+    ``FlatAdam.step()`` as its own launch, over 12 visits of 3 graphs, with and without the per-graph structure cache:
+    parameters, moments, gradients and losses bit for bit."""
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import SCN
+    from graph_hscn.optim import FlatAdam
+    from graph_hscn.step import ScnTrainStep, ScnWorkspace
+    dev = torch.device("cuda:0")
+    graphs = [g.to(dev) for g in make_dataset("peptides_func", 3, seed=9)]
+    for g in graphs:
+        g.x = g.x.to(dtype)
+
+    def run(fuse, cache=False):
+        from graph_hscn.step import ScnStructurePool
+        torch.manual_seed(4)
+        scn = SCN([16], "elu", 9, 16).to(dev)
+        ws = ScnWorkspace(dev, max(g.num_nodes for g in graphs), max(g.edge_index.size(1) for g in graphs), 1, 9, 16, 16,
+                          dtype)
+        pool = ScnStructurePool(dev, sum(g.num_nodes for g in graphs), sum(g.edge_index.size(1) for g in graphs),
+                                len(graphs)) if cache else None
+        steps = [ScnTrainStep(scn, g, workspace=ws, structure_pool=pool) for g in graphs]
+        opt = FlatAdam.from_config(kind, steps[0].param_grads, ws.grads, 0.01, wd)
+        assert all(st.fuses_optimizer(opt) for st in steps)
+        losses = []
+        for _ in range(4):
+            for st in steps:
+                if fuse:
+                    st.run(opt=opt)
+                else:
+                    st.run()
+                    opt.step()
+                losses.append(st.losses.clone())
+        torch.cuda.synchronize()
+        steps[0].check()
+        return [p.detach().clone() for p in scn.parameters()], opt.exp_avg.clone(), opt.exp_avg_sq.clone(), \
+            float(opt.step_count), ws.grads.clone(), torch.stack(losses)
+
+    b = run(False)
+    # ... and with the graphs' CSRs / out-degrees / A_hat x kept in HBM after the first visit (ScnStructurePool)
+    for a in (run(True), run(True, cache=True), run(False, cache=True)):
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] == 12.0
+        assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
