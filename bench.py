@@ -407,6 +407,26 @@ def stage_a_main(args):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    cached = None
+    if args.route == "sparse" and scn.resident_ok(big) and st.one_launch:
+        # second, labelled figure: the batch's CSRs / out-degrees / A_hat x kept in HBM after the first visit
+        # (hscn_scn_structure: what the stage-A loop does from its second epoch on; same results bit for bit)
+        from graph_hscn.step import ScnStructurePool
+        st2 = ScnTrainStep(scn, big, structure_pool=ScnStructurePool(dev, N, E, B))
+        st2.run()                                  # the visit that builds and stores the structure
+        g2 = capture(st2.run)
+        for _ in range(args.warmup):
+            g2.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g2.replay()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        st2.check()
+        assert torch.equal(st2.grads, st.grads) or st2.workspace is st.workspace
+        cached = {"structure_build": "cached after the first visit (hscn_scn_structure)", "ms_per_step": 1e3 * dt2 / args.steps,
+                  "graphs_per_s": B * args.steps / dt2}
     if args.route == "dense":
         # the dominant launch: A S (a [n,n] x [n,K] product per graph) inside hscn_mincut_dense_fwd -- time the C call
         n = fixed_n
@@ -451,6 +471,8 @@ def stage_a_main(args):
                       "route": args.route, "graphs_per_gpu": B, "num_clusters": K, "nodes_per_gpu": N,
                       "edges_per_gpu": E, "nodes_per_graph": fixed_n, "step_issue": issue, "parallelism": "dp1"},
            "roofline": roofline, "cpu_baseline": None}
+    if cached is not None:
+        out["structure_cached"] = cached
     print(json.dumps(out))
 
 
