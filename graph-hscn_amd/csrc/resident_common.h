@@ -82,6 +82,17 @@ __device__ long long* g_stamp_buf = nullptr;  // [grid][64]
 #define STAMP_T(k, tid) do {} while (0)
 #endif
 
+// A by-value kernel argument struct (at byte `offset` of the kernel-argument segment) as an object in the constant
+// address space behind a LAUNDERED pointer: its fields are scalar loads issued where they are used, not preloaded in
+// the kernel's entry block and carried (or spilled) from there.
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* late_args(int offset) {
+  typedef const __attribute__((address_space(4))) char* P;
+  P p = (P)__builtin_amdgcn_kernarg_segment_ptr() + offset;
+  asm volatile("" : "+s"(p));
+  return (const __attribute__((address_space(4))) T*)p;
+}
+
 // Workgroup barrier for phases that exchange data through LDS only.  __syncthreads() carries a
 // workgroup-scope fence, which on gfx9 drains the vector-memory counter as well: every barrier
 // would wait for the global stores (activations, CSR export, gradient partials) and prefetch loads

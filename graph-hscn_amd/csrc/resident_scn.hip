@@ -58,6 +58,13 @@ struct ScnArgs {
   int adam_decoupled;
 };
 
+// The kernel's argument block read LATE: the compiler loads every argument it finds loop-invariant at the top of the
+// kernel and keeps it in scalar registers; fields that only the last phase needs (the optimizer's) or only the first
+// (the structure cache's) then cost spills all the way through (each spill is a v_writelane / v_readlane pair on the
+// VALU).  The pointer is laundered through an empty asm so their loads stay where they are used.
+typedef const __attribute__((address_space(4))) ScnArgs* ScnArgsK;
+__device__ __forceinline__ ScnArgsK late_args() { return late_args<ScnArgs>(0); }
+
 struct ScnLayout {
   size_t R1, R2, R3, dinv, dout, wt, red, vecs, rowptr_d, col_d, rowptr_s, col_s, cursor, tmp, cursor2, tmp2, wsum, ek,
       eo, ssl, total;
@@ -240,7 +247,7 @@ __device__ __forceinline__ void scn_losses_wave(const float* stats, float* losse
 // source-keyed for A S) are built side by side by two wave groups between the same barriers, the
 // gcn_norm degrees follow from the row lengths, and agg = A_hat x is reduced in edge order, loop last.
 // Weights land transposed: WrT / WoT [FP][H] (rows k >= F zero), brl [H], WmT [H][K], bml [K].
-template <int H, typename TS>
+template <int H, typename TS, bool PRE>
 __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* ib, int n0, int n, int e0, int ne,
                           int g) {
   constexpr int NW = SRT / 64;
@@ -285,7 +292,8 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   }
   if (wbase < H) vb = A.b_rel[threadIdx.x < H ? threadIdx.x : 0];
   if (wbase < K) vm = A.b_mlp[(int)threadIdx.x < K ? threadIdx.x : 0];
-  const bool pre = A.pre != 0;   // the structure of an earlier visit of this batch (ex_*): loaded, not rebuilt
+  ScnArgsK KF = late_args();     // (the structure cache's fields: read here, not carried in scalar registers)
+  constexpr bool pre = PRE;   // the structure of an earlier visit of this batch (ex_*): loaded, not rebuilt
   constexpr int RPT = 2;
   int rdp[RPT], rsp[RPT], cdp[EPT], csp[EPT];
   float dop[RPT], agr[XPT];
@@ -298,8 +306,8 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
         rd[i] = A.dst[e < ne ? e0 + e : e0];
         rs[i] = A.src[e < ne ? e0 + e : e0];
       } else {
-        cdp[i] = A.ex_col_d[(size_t)e0 + (e < ne ? e : 0)];
-        csp[i] = A.ex_col_s[(size_t)e0 + (e < ne ? e : 0)];
+        cdp[i] = KF->ex_col_d[(size_t)e0 + (e < ne ? e : 0)];
+        csp[i] = KF->ex_col_s[(size_t)e0 + (e < ne ? e : 0)];
       }
     }
   }
@@ -308,9 +316,9 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
     const int idx = threadIdx.x + i * SRT;
     rdp[i] = 0; rsp[i] = 0; dop[i] = 0.f;
     if (pre && wbase + i * SRT <= n) {
-      rdp[i] = A.ex_rowptr_d[(size_t)n0 + g + (idx <= n ? idx : 0)];
-      rsp[i] = A.ex_rowptr_s[(size_t)n0 + g + (idx <= n ? idx : 0)];
-      dop[i] = A.ex_dout[(size_t)n0 + (idx < n ? idx : 0)];
+      rdp[i] = KF->ex_rowptr_d[(size_t)n0 + g + (idx <= n ? idx : 0)];
+      rsp[i] = KF->ex_rowptr_s[(size_t)n0 + g + (idx <= n ? idx : 0)];
+      dop[i] = KF->ex_dout[(size_t)n0 + (idx < n ? idx : 0)];
     }
   }
 #pragma unroll
@@ -322,7 +330,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
     if (wbase + i * SRT < n * FP) {
       const float t = ldf(xg, ok ? (size_t)(n0 + r) * F + k : 0);
       xr[i] = ok ? t : 0.f;
-      if (pre) agr[i] = A.ex_agg[(size_t)n0 * FP + (idx < n * FP ? idx : 0)];
+      if (pre) agr[i] = KF->ex_agg[(size_t)n0 * FP + (idx < n * FP ? idx : 0)];
     }
   }
   // ---- park ----
@@ -349,8 +357,8 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       if (e < ne) { col_d[e] = cdp[i]; col_s[e] = csp[i]; }
     }
     for (int e = threadIdx.x + EPT * SRT; e < ne; e += SRT) {
-      col_d[e] = A.ex_col_d[(size_t)e0 + e];
-      col_s[e] = A.ex_col_s[(size_t)e0 + e];
+      col_d[e] = KF->ex_col_d[(size_t)e0 + e];
+      col_s[e] = KF->ex_col_s[(size_t)e0 + e];
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -359,16 +367,16 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       if (idx < n) dout[idx] = dop[i];
     }
     for (int idx = threadIdx.x + RPT * SRT; idx <= n; idx += SRT) {
-      rowptr_d[idx] = A.ex_rowptr_d[(size_t)n0 + g + idx];
-      rowptr_s[idx] = A.ex_rowptr_s[(size_t)n0 + g + idx];
-      if (idx < n) dout[idx] = A.ex_dout[(size_t)n0 + idx];
+      rowptr_d[idx] = KF->ex_rowptr_d[(size_t)n0 + g + idx];
+      rowptr_s[idx] = KF->ex_rowptr_s[(size_t)n0 + g + idx];
+      if (idx < n) dout[idx] = KF->ex_dout[(size_t)n0 + idx];
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int idx = threadIdx.x + i * SRT;
       if (idx < n * FP) agg[idx] = agr[i];
     }
-    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = A.ex_agg[(size_t)n0 * FP + idx];
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = KF->ex_agg[(size_t)n0 * FP + idx];
   }
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
@@ -431,19 +439,19 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       a.x = add_rn(a.x, mul_rn(wl, v.x)); a.y = add_rn(a.y, mul_rn(wl, v.y));
       a.z = add_rn(a.z, mul_rn(wl, v.z)); a.w = add_rn(a.w, mul_rn(wl, v.w));
       *reinterpret_cast<float4*>(agg + i * FP + f) = a;
-      if (A.ex_agg) *reinterpret_cast<float4*>(A.ex_agg + (size_t)(n0 + i) * FP + f) = a;
+      if (KF->ex_agg) *reinterpret_cast<float4*>(KF->ex_agg + (size_t)(n0 + i) * FP + f) = a;
     }
   }
   // hand the structure to the backward launch
-  if (A.ex_rowptr_d) {
+  if (KF->ex_rowptr_d) {
     for (int i = threadIdx.x; i <= n; i += SRT) {
-      A.ex_rowptr_d[(size_t)n0 + g + i] = rowptr_d[i];
-      A.ex_rowptr_s[(size_t)n0 + g + i] = rowptr_s[i];
+      KF->ex_rowptr_d[(size_t)n0 + g + i] = rowptr_d[i];
+      KF->ex_rowptr_s[(size_t)n0 + g + i] = rowptr_s[i];
     }
     const int cd = rowptr_d[n], cs = rowptr_s[n];
-    for (int p = threadIdx.x; p < cd; p += SRT) A.ex_col_d[(size_t)e0 + p] = col_d[p];
-    for (int p = threadIdx.x; p < cs; p += SRT) A.ex_col_s[(size_t)e0 + p] = col_s[p];
-    for (int i = threadIdx.x; i < n; i += SRT) A.ex_dout[(size_t)n0 + i] = dout[i];
+    for (int p = threadIdx.x; p < cd; p += SRT) KF->ex_col_d[(size_t)e0 + p] = col_d[p];
+    for (int p = threadIdx.x; p < cs; p += SRT) KF->ex_col_s[(size_t)e0 + p] = col_s[p];
+    for (int i = threadIdx.x; i < n; i += SRT) KF->ex_dout[(size_t)n0 + i] = dout[i];
   }
   lds_barrier();
   STAMP(3);
@@ -827,7 +835,7 @@ __global__ void __launch_bounds__(SRT) k_scn_fwd(const ScnArgs A) {
   int *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
   STAMP(0);
-  scn_front<H, TS>(A, Y, fb, ib, n0, n, e0, ne, g);
+  scn_front<H, TS, false>(A, Y, fb, ib, n0, n, e0, ne, g);
   scn_hidden<H, TS>(A, xs, agg, yl, WrT, WoT, brl, n0, n);
   lds_barrier();
   STAMP(4);
@@ -1120,6 +1128,7 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
   lds_barrier();
   STAMP(15);
   // fold in wave order.  layout of part: W_rel [H*F], b_rel [H], W_root [H*F], W_mlp [K*H], b_mlp [K]
+  ScnArgsK KA = late_args();   // (the optimizer's fields: loaded here, not carried through the kernel)
   const int F = A.F;
   const int obrel = H * F, oWroot = obrel + H, oWmlp = oWroot + H * F, obmlp = oWmlp + K * H;
   for (int p = threadIdx.x; p < A.P; p += SRT) {
@@ -1132,36 +1141,36 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
     float v = 0.f;
     for (int w = 0; w < NWA; ++w) v += scratch[(size_t)w * WSZ + off];
     part[p] = v;
-    if (A.adam_m) {   // B == 1: v IS the gradient of parameter element p -- the Adam step of csrc/optim.hip, same operations
+    if (KA->adam_m) {   // B == 1: v IS the gradient of parameter element p -- the Adam step of csrc/optim.hip, same operations
       float* pp = p < obrel ? const_cast<float*>(A.W_rel) + p
                 : p < oWroot ? const_cast<float*>(A.b_rel) + (p - obrel)
                 : p < oWmlp ? const_cast<float*>(A.W_root) + (p - oWroot)
                 : p < obmlp ? const_cast<float*>(A.W_mlp) + (p - oWmlp) : const_cast<float*>(A.b_mlp) + (p - obmlp);
-      const double lr = A.adam_lr[0];
-      const double b1t = A.adam_pows[0] * A.adam_b1, b2t = A.adam_pows[1] * A.adam_b2;
+      const double lr = KA->adam_lr[0];
+      const double b1t = KA->adam_pows[0] * KA->adam_b1, b2t = KA->adam_pows[1] * KA->adam_b2;
       const float step_size = (float)(lr / (1.0 - b1t)), bc2_sqrt = (float)sqrt(1.0 - b2t);
-      const float w1 = (float)(1.0 - A.adam_b1), w2 = (float)(1.0 - A.adam_b2), b2f = (float)A.adam_b2;
-      float pv = *pp, g_ = v, m = A.adam_m[p], vv = A.adam_v[p];
-      if (A.adam_wd != 0.0) {
-        if (A.adam_decoupled) pv = pv * (float)(1.0 - lr * A.adam_wd);
-        else g_ = g_ + (float)A.adam_wd * pv;
+      const float w1 = (float)(1.0 - KA->adam_b1), w2 = (float)(1.0 - KA->adam_b2), b2f = (float)KA->adam_b2;
+      float pv = *pp, g_ = v, m = KA->adam_m[p], vv = KA->adam_v[p];
+      if (KA->adam_wd != 0.0) {
+        if (KA->adam_decoupled) pv = pv * (float)(1.0 - lr * KA->adam_wd);
+        else g_ = g_ + (float)KA->adam_wd * pv;
       }
       m = m + w1 * (g_ - m);
       vv = vv * b2f;
       vv = vv + (w2 * g_) * g_;
-      const float denom = sqrtf(vv) / bc2_sqrt + (float)A.adam_eps;
+      const float denom = sqrtf(vv) / bc2_sqrt + (float)KA->adam_eps;
       pv = pv + (-step_size) * (m / denom);
       *pp = pv;
-      A.adam_m[p] = m;
-      A.adam_v[p] = vv;
+      KA->adam_m[p] = m;
+      KA->adam_v[p] = vv;
     }
   }
-  if (A.adam_m) {
+  if (KA->adam_m) {
     lds_barrier();   // every thread has read the counters
     if (threadIdx.x == 0) {
-      A.adam_step[0] = A.adam_step[0] + 1.0f;
-      A.adam_pows[0] = A.adam_pows[0] * A.adam_b1;
-      A.adam_pows[1] = A.adam_pows[1] * A.adam_b2;
+      KA->adam_step[0] = KA->adam_step[0] + 1.0f;
+      KA->adam_pows[0] = KA->adam_pows[0] * KA->adam_b1;
+      KA->adam_pows[1] = KA->adam_pows[1] * KA->adam_b2;
     }
   }
 }
@@ -1297,7 +1306,7 @@ __global__ void __launch_bounds__(SRT) k_scn_bwd(const ScnArgs A) {
 // simply stays in LDS; x and agg move to registers before S takes their buffer.  Upstream gradients g_mc / g_o
 // (device scalars, the reference's loss = mincut + ortho has both = 1) are divided by B as in the backward launch.
 // With B == 1 the partials ARE the gradients (A.partials = grads): no fold launch.
-template <int H, typename TS>
+template <int H, typename TS, bool PRE>
 __global__ void __launch_bounds__(SRT) k_scn_step(const ScnArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NW = SRT / 64;
@@ -1325,7 +1334,7 @@ __global__ void __launch_bounds__(SRT) k_scn_step(const ScnArgs A) {
   int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
 
   STAMP(0);
-  scn_front<H, TS>(A, Y, fb, ib, n0, n, e0, ne, g);
+  scn_front<H, TS, PRE>(A, Y, fb, ib, n0, n, e0, ne, g);
   // (K % 4 == 0: hscn_scn_resident_train_step_supported)
   const int wave = wave_id(), ntile = (n + 15) >> 4;
   float xb[2][4], ab[2][4];    // x / agg of the wave's own tiles as B operands of the backward half
@@ -1377,10 +1386,14 @@ template <int H, typename TS>
 int launch_scn(ScnArgs& A, int bwd, hipStream_t st) {
   const size_t lds = scn_layout(H, A.K, A.max_n, A.max_e, bwd).total * 4;
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
-  if (bwd == 2) {
+  if (bwd == 2 && A.pre) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_scn_step<H, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_scn_step<H, TS><<<(unsigned)A.B, SRT, lds, st>>>(A);
+      (void)hipFuncSetAttribute((const void*)k_scn_step<H, TS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_scn_step<H, TS, true><<<(unsigned)A.B, SRT, lds, st>>>(A);
+  } else if (bwd == 2) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_scn_step<H, TS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_scn_step<H, TS, false><<<(unsigned)A.B, SRT, lds, st>>>(A);
   } else if (bwd) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_scn_bwd<H, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

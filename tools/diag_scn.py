@@ -46,7 +46,11 @@ def main():
 
     if "step" in sys.argv[1:]:
         from graph_hscn.step import ScnTrainStep
-        st = ScnTrainStep(scn, big, one_launch=True)
+        pool = None
+        if "cached" in sys.argv[1:]:
+            from graph_hscn.step import ScnStructurePool
+            pool = ScnStructurePool(dev, int(big.num_nodes), int(big.edge_index.size(1)), B)
+        st = ScnTrainStep(scn, big, one_launch=True, structure_pool=pool)
         for _ in range(3):
             st.run()
         torch.cuda.synchronize()
