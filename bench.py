@@ -408,6 +408,17 @@ def stage_a_main(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cached = None
+    if args.route == "sparse" and scn.resident_ok(big):
+        # SURVEY.md 8(d), "MinCUT sparse (per graph)": bytes 4(n+1) + 4(e+n) + 4nK, each array touched once, forward;
+        # the backward moves the same bytes again (x 2).  The step is latency-bound like stage C's (one workgroup per
+        # graph, the working set of a batch is a few MB): the fraction says how far from a bandwidth problem it is.
+        ab = 2.0 * (4.0 * (N + B) + 4.0 * (E + N) + 4.0 * N * K)
+        t_step = dt / args.steps
+        roofline = {"bound": "hbm", "kernel": "k_scn_step + k_param_reduce (hscn_scn_resident_train_step)" if st.one_launch
+                    else "k_scn_fwd + k_scn_bwd + k_param_reduce", "achieved": ab / t_step / 1e9, "peak": 8000.0,
+                    "unit": "GB/s", "frac": ab / t_step / 8e12, "traffic": None, "algorithmic_bytes_per_launch": ab,
+                    "avg_launch_us": t_step * 1e6,
+                    "note": "time = one replayed step (both launches); latency-bound, see DESIGN.md section 4"}
     if args.route == "sparse" and scn.resident_ok(big) and st.one_launch:
         # second, labelled figure: the batch's CSRs / out-degrees / A_hat x kept in HBM after the first visit
         # (hscn_scn_structure: what the stage-A loop does from its second epoch on; same results bit for bit)

@@ -42,10 +42,12 @@ __device__ __forceinline__ void slot_range(const int64_t* __restrict__ p, const 
 
 __global__ void __launch_bounds__(CT) k_collate_gather(const hscn_hetero_dataset D, const int64_t* __restrict__ ids,
                                                        int B, const hscn_hetero_batch_out O, int32_t* __restrict__ flag,
-                                                       const int32_t* __restrict__ cursor) {
+                                                       const int32_t* __restrict__ cursor,
+                                                       const int32_t* __restrict__ cursor_base) {
   __shared__ long long red[CT / 64];
   const int j = blockIdx.x, part = blockIdx.y;
-  if (cursor) ids += (int64_t)cursor[0] * B;   // batch number `cursor` of a permutation that lives on the device
+  // batch number `cursor` (- `cursor_base`) of a permutation that lives on the device
+  if (cursor) ids += (int64_t)(cursor[0] - (cursor_base ? cursor_base[0] : 0)) * B;
   const int64_t g = ids[j];
   if (g < 0 || g >= D.G) {              // (uniform per block)
     if (threadIdx.x == 0 && flag) atomicOr(flag, 8);
@@ -107,10 +109,11 @@ __global__ void __launch_bounds__(CT) k_collate_gather(const hscn_hetero_dataset
 __global__ void __launch_bounds__(CT) k_collate_structure(const hscn_hetero_dataset D, const hscn_structure S,
                                                           const int64_t* __restrict__ ids, int B,
                                                           const hscn_hetero_batch_out O, const hscn_structure T,
-                                                          int32_t* __restrict__ flag, const int32_t* __restrict__ cursor) {
+                                                          int32_t* __restrict__ flag, const int32_t* __restrict__ cursor,
+                                                          const int32_t* __restrict__ cursor_base) {
   __shared__ long long red[CT / 64];
   const int j = blockIdx.x, part = blockIdx.y;
-  if (cursor) ids += (int64_t)cursor[0] * B;
+  if (cursor) ids += (int64_t)(cursor[0] - (cursor_base ? cursor_base[0] : 0)) * B;
   const int64_t g = ids[j];
   if (g < 0 || g >= D.G) {
     if (threadIdx.x == 0 && flag) atomicOr(flag, 8);
@@ -151,13 +154,16 @@ __global__ void __launch_bounds__(CT) k_collate_structure(const hscn_hetero_data
 
 // after the gather of batch `cursor`: the next replay of the same captured launches takes the next slice.
 // (A launch of its own: letting the gather's last block advance the counter -- sign-off counter, device-scope
-// fence -- was measured at +23 us per step over 768 blocks; this costs ~3.)
+// fence -- was measured at +23 us per step over 768 blocks; this costs ~4.  With cursor_base the counter is one that
+// SOMEBODY ELSE advances once per step -- the epoch word of the one-launch training step's sync buffer -- and the
+// slice is counter - base: no launch at all.)
 __global__ void k_cursor_advance(int32_t* cursor) { cursor[0] += 1; }
 
 }  // namespace
 
 extern "C" int hscn_collate_gather(const hscn_hetero_dataset* ds, const int64_t* ids, int64_t B,
-                                   const hscn_hetero_batch_out* out, int32_t* flag, int32_t* cursor, void* stream_) {
+                                   const hscn_hetero_batch_out* out, int32_t* flag, int32_t* cursor,
+                                   const int32_t* cursor_base, void* stream_) {
   if (!ds || !out || B < 0 || B > 65535) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!ids || !ds->x_local || !ds->x_virtual || !ds->nptr || !ds->vptr || ds->F < 1 || ds->G < 1) return HSCN_E_BADARG;
@@ -167,9 +173,9 @@ extern "C" int hscn_collate_gather(const hscn_hetero_dataset* ds, const int64_t*
   for (int r = 0; r < 3; ++r)
     if (!ds->src[r] || !ds->dst[r] || !ds->eptr[r] || !out->ei[r] || !out->eptr32[r] || out->ecap[r] < 1) return HSCN_E_BADARG;
   if ((ds->y != nullptr) != (out->y != nullptr)) return HSCN_E_BADARG;
-  k_collate_gather<<<dim3((unsigned)B, 6), CT, 0, hscn_stream(stream_)>>>(*ds, ids, (int)B, *out, flag, cursor);
+  k_collate_gather<<<dim3((unsigned)B, 6), CT, 0, hscn_stream(stream_)>>>(*ds, ids, (int)B, *out, flag, cursor, cursor_base);
   HSCN_RETURN_IF_LAUNCH_FAILED();
-  if (cursor) {
+  if (cursor && !cursor_base) {
     k_cursor_advance<<<1, 1, 0, hscn_stream(stream_)>>>(cursor);
     HSCN_RETURN_IF_LAUNCH_FAILED();
   }
@@ -178,7 +184,8 @@ extern "C" int hscn_collate_gather(const hscn_hetero_dataset* ds, const int64_t*
 
 extern "C" int hscn_collate_gather_structure(const hscn_hetero_dataset* ds, const hscn_structure* dss, const int64_t* ids,
                                              int64_t B, const hscn_hetero_batch_out* out, const hscn_structure* outs,
-                                             int32_t* flag, const int32_t* cursor, void* stream_) {
+                                             int32_t* flag, const int32_t* cursor, const int32_t* cursor_base,
+                                             void* stream_) {
   if (!ds || !dss || !out || !outs || B < 0 || B > 65535) return HSCN_E_BADARG;
   if (B == 0) return 0;
   if (!ids || !ds->nptr || !ds->vptr || ds->G < 1) return HSCN_E_BADARG;
@@ -189,7 +196,7 @@ extern "C" int hscn_collate_gather_structure(const hscn_hetero_dataset* ds, cons
     if (!q->ll_rowptr_d || !q->ll_col_d || !q->ll_rowptr_s || !q->ll_col_s || !q->ll_dinv || !q->lv_rowptr ||
         !q->lv_col || !q->vv_rowptr || !q->vv_col || !q->vv_dinv)
       return HSCN_E_BADARG;
-  k_collate_structure<<<dim3((unsigned)B, 4), CT, 0, hscn_stream(stream_)>>>(*ds, *dss, ids, (int)B, *out, *outs, flag, cursor);
+  k_collate_structure<<<dim3((unsigned)B, 4), CT, 0, hscn_stream(stream_)>>>(*ds, *dss, ids, (int)B, *out, *outs, flag, cursor, cursor_base);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -33,26 +33,43 @@ struct AdamArgs {
 };
 
 __global__ void __launch_bounds__(1024) k_adam_flat(const AdamArgs A) {
-  // the segment that holds element i: a select chain over the argument tables (constant indices after unrolling, so
-  // the tables arrive as a few wide scalar loads issued before anything else -- no table in memory or LDS, no
-  // dependent load in front of the update)
-  auto addr = [&](int i) -> float* {
-    float* base = A.params[0];
-    int start = 0;
+  // The segment tables go from the kernel arguments to LDS through ONE vector load per table entry (lane k reads
+  // entry k of the argument block as plain memory), requested together with the thread's gradients and moments; a
+  // thread then finds its element's tensor by a 5-step binary search in LDS.  (A select chain over the arguments
+  // costs ~150 VALU operations per element -- 4 us on one CU; a scalar loop over them one dependent load per entry.)
+  __shared__ int soff[ADAM_MAXSEG + 1];
+  __shared__ float* sp[ADAM_MAXSEG];
+  {
+    const AdamArgs* kp = reinterpret_cast<const AdamArgs*>(
+        (const char*)__builtin_amdgcn_kernarg_segment_ptr());   // (generic pointer: a vector load, per-lane index)
+    if (threadIdx.x <= ADAM_MAXSEG) soff[threadIdx.x] = (int)threadIdx.x <= A.nseg ? kp->off[threadIdx.x] : 0x7fffffff;
+    if (threadIdx.x < ADAM_MAXSEG) sp[threadIdx.x] = (int)threadIdx.x < A.nseg ? kp->params[threadIdx.x] : nullptr;
+  }
+  constexpr int EPT = 4;   // (a model of this family is a few thousand parameters: one batch of requests)
+  float g0[EPT], m0[EPT], v0[EPT];
 #pragma unroll
-    for (int k = 1; k < ADAM_MAXSEG; ++k) {
-      const bool in = k < A.nseg && i >= A.off[k];
-      base = in ? A.params[k] : base;
-      start = in ? A.off[k] : start;
+  for (int u = 0; u < EPT; ++u) {
+    const int i = threadIdx.x + u * 1024;
+    const bool has = i < A.P;
+    g0[u] = A.grads[has ? i : 0]; m0[u] = A.m[has ? i : 0]; v0[u] = A.v[has ? i : 0];
+  }
+  __syncthreads();
+  auto addr = [&](int i) -> float* {
+    int lo = 0, hi = A.nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (soff[mid] <= i) lo = mid; else hi = mid - 1;
     }
-    return base + (i - start);
+    return sp[lo] + (i - soff[lo]);
   };
-  // one round trip: the counter, the learning rate and the thread's first element are requested together; the
-  // step's scalars are formed while they travel
-  const int i0 = threadIdx.x;
-  const bool has0 = i0 < A.P;
-  float* pp0 = addr(has0 ? i0 : 0);
-  const float p0 = *pp0, g0 = A.grads[has0 ? i0 : 0], m0 = A.m[has0 ? i0 : 0], v0 = A.v[has0 ? i0 : 0];
+  float* pp0[EPT];
+  float p0[EPT];
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int i = threadIdx.x + u * 1024;
+    pp0[u] = addr(i < A.P ? i : 0);
+    p0[u] = *pp0[u];
+  }
   const float t = A.step[0] + 1.0f;
   const double lr = A.lr[0];
   const double b1t = A.pows[0] * A.beta1, b2t = A.pows[1] * A.beta2;
@@ -75,8 +92,12 @@ __global__ void __launch_bounds__(1024) k_adam_flat(const AdamArgs A) {
     A.m[i] = m;
     A.v[i] = v;
   };
-  if (has0) update(pp0, i0, p0, g0, m0, v0);
-  for (int i = threadIdx.x + 1024; i < A.P; i += 1024) {
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int i = threadIdx.x + u * 1024;
+    if (i < A.P) update(pp0[u], i, p0[u], g0[u], m0[u], v0[u]);
+  }
+  for (int i = threadIdx.x + EPT * 1024; i < A.P; i += 1024) {
     float* pp = addr(i);
     update(pp, i, *pp, A.grads[i], A.m[i], A.v[i]);
   }

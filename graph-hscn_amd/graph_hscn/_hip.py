@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -55,7 +55,7 @@ _SIGNATURES = {
     "hscn_build_hetero_count": (c_int, [P, c_int, P, P, c_int64, c_int, c_int, P, P, P, P, P]),
     "hscn_build_hetero_scan": (c_int, [P, c_int64, P, P, P, P, P, P, P]),
     "hscn_build_hetero_emit": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, c_int64, c_int64, P, P, P, P, P]),
-    "hscn_collate_gather": (c_int, [P, P, c_int64, P, P, P, P]),
+    "hscn_collate_gather": (c_int, [P, P, c_int64, P, P, P, P, P]),
     "hscn_criterion_fwd": (c_int, [P, P, c_int64, c_int, P, P, P, P]),
     "hscn_scale": (c_int, [P, P, P, c_int64, P]),
     "hscn_scn_resident_supported": (c_int, [c_int] * 5),
@@ -86,7 +86,7 @@ _SIGNATURES = {
                                          P, P, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, P]),
     "hscn_resident_structure": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, P, P, c_int64, c_int, c_int, c_int,
                                         c_int, P, P, P]),
-    "hscn_collate_gather_structure": (c_int, [P, P, P, c_int64, P, P, P, P, P]),
+    "hscn_collate_gather_structure": (c_int, [P, P, P, c_int64, P, P, P, P, P, P]),
 }
 # IEEE-half storage twins (include/hscn.h: hscn_resident_*_f16): same argument lists
 for _n in ("hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual", "hscn_resident_bwd_with_virtual",

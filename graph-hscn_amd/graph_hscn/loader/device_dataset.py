@@ -100,6 +100,7 @@ class DeviceHeteroDataset:
             torch.cuda.synchronize(dev)                                   # (the int64 COO copy of `whole` may go now)
         self._perm: Optional[Tensor] = None
         self._cursor: Optional[Tensor] = None
+        self._counters: dict = {}      # id(step) -> (the step's per-step device counter, its value at epoch start, step)
         t = self._t
         p = _hip.ptr
         self._ds = _Dataset(p(t["x_local"]), p(t["x_virtual"]), p(t["y"]), p(t["nptr"]), p(t["vptr"]),
@@ -128,9 +129,9 @@ class DeviceHeteroDataset:
         if self.structure is not None:
             _hip.call("hscn_collate_gather_structure", ctypes.byref(self._ds), ctypes.byref(self.structure.c),
                       _hip.ptr(ids), self.batch_size, ctypes.byref(self._out), ctypes.byref(self._out_structure.c),
-                      _hip.ptr(self.flag), None, _hip.stream())
+                      _hip.ptr(self.flag), None, None, _hip.stream())
         _hip.call("hscn_collate_gather", ctypes.byref(self._ds), _hip.ptr(ids), self.batch_size,
-                  ctypes.byref(self._out), _hip.ptr(self.flag), None, _hip.stream())
+                  ctypes.byref(self._out), _hip.ptr(self.flag), None, None, _hip.stream())
         return self.static.batch
 
     # ---- an epoch that walks by itself: the permutation and a batch counter live on the device ----------------
@@ -144,20 +145,34 @@ class DeviceHeteroDataset:
             self._cursor = torch.zeros(1, dtype=torch.int32, device=self.device)
         torch.randperm(self.num_graphs, device=self.device, generator=generator, out=self._perm)
         self._cursor.zero_()
+        for counter, base, _ in self._counters.values():   # steps with a counter of their own: this epoch's slices
+            base.copy_(counter)                            # count from its value now
         return self._perm
 
-    def gather_next(self) -> HeteroBatch:
-        """Gather the next batch of the current epoch's permutation and advance the device-side counter: two
-        launches with no host argument that changes from step to step, so they can be CAPTURED in front of the
-        training step (``CapturedStep(..., pre=ds.gather_next)``) -- a replay is then "next batch + iteration"."""
+    def gather_next(self, step=None) -> HeteroBatch:
+        """Gather the next batch of the current epoch's permutation and advance the device-side counter, with no
+        host argument that changes from step to step, so the launches can be CAPTURED in front of the training step
+        (``CapturedStep(..., pre=ds.gather_next)``) -- a replay is then "next batch + iteration".
+        ``step``: the ``ResidentTrainStep`` the gather is captured with (``CapturedStep`` passes it).  When that step
+        keeps a per-step counter on the device (word 0 of the one-launch step's sync buffer, advanced by its gradient
+        fold), the gather reads its slice number off THAT counter (minus its value when the epoch began) and the
+        launch that would advance a counter of our own (4.5 us per iteration) does not exist."""
         if self._perm is None:
             raise RuntimeError("call new_epoch() first")
+        sync = getattr(step, "_sync", None) if step is not None else None
+        if sync is not None and getattr(step, "advances_sync", False):
+            ent = self._counters.get(id(step))
+            if ent is None:                      # (uint32 counter read as int32; the base is this epoch's start)
+                ent = self._counters[id(step)] = (sync[:1], sync[:1].clone(), step)
+            cur, base = _hip.ptr(ent[0]), _hip.ptr(ent[1])
+        else:
+            cur, base = _hip.ptr(self._cursor), None
         if self.structure is not None:        # (before the gather proper: that call advances the cursor)
             _hip.call("hscn_collate_gather_structure", ctypes.byref(self._ds), ctypes.byref(self.structure.c),
                       _hip.ptr(self._perm), self.batch_size, ctypes.byref(self._out),
-                      ctypes.byref(self._out_structure.c), _hip.ptr(self.flag), _hip.ptr(self._cursor), _hip.stream())
+                      ctypes.byref(self._out_structure.c), _hip.ptr(self.flag), cur, base, _hip.stream())
         _hip.call("hscn_collate_gather", ctypes.byref(self._ds), _hip.ptr(self._perm), self.batch_size,
-                  ctypes.byref(self._out), _hip.ptr(self.flag), _hip.ptr(self._cursor), _hip.stream())
+                  ctypes.byref(self._out), _hip.ptr(self.flag), cur, base, _hip.stream())
         return self.static.batch
 
     def check(self) -> None:

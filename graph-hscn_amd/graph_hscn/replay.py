@@ -239,9 +239,17 @@ class CapturedStep:
         if make_flat:          # built here: it needs the step's flat gradient buffer
             optimizer = self.optimizer = optimizer(self.step)
 
+        pre_takes_step = False
+        if pre is not None:
+            import inspect
+            try:
+                pre_takes_step = "step" in inspect.signature(pre).parameters
+            except (TypeError, ValueError):
+                pass
+
         def step():
             if pre is not None:
-                pre()
+                pre(self.step) if pre_takes_step else pre()      # (DeviceHeteroDataset.gather_next(step))
             self.step.run()
             if reducer is not None:
                 reducer.reduce(float(static.num_graphs), float(static.num_graphs * reducer.world_size))

@@ -180,6 +180,14 @@ class ResidentTrainStep:
                                    ctypes.cast(self._table, ctypes.c_void_p), ptr(xv_out), V, m.max_v, m.max_evv,
                                    self.slope, *([ptr(t) for t in self._state] if self._state is not None else [None] * 6))
 
+    @property
+    def advances_sync(self) -> bool:
+        """Every ``run()`` adds one to word 0 of ``_sync`` on the device (the one-launch step with the virtual branch
+        on its own workgroups does: its gradient fold advances the hand-off epoch) -- a per-step counter that a
+        captured batch gather can read its slice number from (``DeviceHeteroDataset.gather_next(step)``)."""
+        return bool(self.one_launch and self.idle_cus and self.virtual is not None and self.dims[4] >= 2
+                    and self._sync is not None)
+
     def run(self) -> Tensor:
         """Issue the step on the current stream; returns ``loss`` (valid once the stream has run)."""
         N, V, F, H, L, C, B = self.dims

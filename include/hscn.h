@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 9
+#define HSCN_ABI_VERSION 10
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -307,7 +307,10 @@ typedef struct hscn_hetero_batch_out {
 } hscn_hetero_batch_out;
 int hscn_collate_gather(const hscn_hetero_dataset* dataset, const int64_t* ids /*[B] device*/, int64_t B,
                         const hscn_hetero_batch_out* out, int32_t* flag, int32_t* cursor /*device [1] or NULL*/,
-                        void* stream);
+                        const int32_t* cursor_base /*device [1] or NULL*/, void* stream);
+/* cursor_base != NULL: `cursor` is a counter that somebody else advances once per training step -- word 0 of the
+ * sync buffer of hscn_resident_train_step -- and the slice taken is cursor[0] - cursor_base[0]; the call then issues
+ * no launch of its own to advance anything (cursor_base is set to the counter's value when an epoch starts). */
 
 /* ------------------------------------------------------------------------- *
  * Loss tail (reference graph_hscn/loss.py:6-19, called at train/train.py:82) on the
@@ -461,7 +464,7 @@ int hscn_resident_structure(const int64_t* ei_ll, int64_t E_ll, const int64_t* e
 int hscn_collate_gather_structure(const hscn_hetero_dataset* dataset, const hscn_structure* ds_structure,
                                   const int64_t* ids, int64_t B, const hscn_hetero_batch_out* out_batch,
                                   const hscn_structure* out_structure, int32_t* flag, const int32_t* cursor,
-                                  void* stream);
+                                  const int32_t* cursor_base, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * a10 + f3  the whole training iteration of stage C in ONE launch (+ the ordered parameter reduction):
