@@ -1571,6 +1571,71 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
                       ex_rowptr_d, ex_col_d, ex_rowptr_s, ex_col_s, ex_agg, ex_dout, max_n, max_e, partials, grads,
                       flag, stream_);
 }
+// A whole run of the reference's stage-A loop (train/train_clustering.py:34-50) from ONE call: `visits` graph visits
+// in dataset order, each the one-launch step of ONE graph with the optimizer in its tail and the cached structure
+// (hscn_scn_resident_train_step(B = 1, opt, cache) on graph v mod G of a dataset laid out as one batch), issued
+// back to back by this host loop -- no Python between two visits.  (The same chain as ONE launch of one persistent
+// workgroup -- weights in LDS, moments in registers -- was built and measured: 19.1 us per visit against 12.7 for the
+// launches below; the visit loop around the phases drove the kernel to 145 scalar / 130 vector register spills.)
+static int scn_epoch_impl(int f16, const float* x, const int32_t* nptr, const int32_t* eptr, int64_t N, int64_t G,
+                          int64_t visits, int F, int H, int K, int act, float* W_rel, float* b_rel, float* W_root,
+                          float* W_mlp, float* b_mlp, const float* g_mc, const float* g_o, int max_n, int max_e,
+                          const hscn_scn_structure* cache, const hscn_adam* opt, float* grads, float* stats,
+                          float* losses, int32_t* ticket, int32_t* flag, void* stream_) {
+  if (G < 1 || N < 0 || visits < 0) return HSCN_E_BADARG;
+  if (!hscn_scn_resident_train_step_supported(F, H, K, max_n, max_e)) return HSCN_E_UNSUPPORTED;
+  if (!x || !nptr || !eptr || !W_rel || !b_rel || !W_root || !W_mlp || !b_mlp || !grads || !stats || !losses || !ticket ||
+      !cache || !opt)
+    return HSCN_E_BADARG;
+  if (!cache->ready || !cache->rowptr_d || !cache->rowptr_s || !cache->agg || !cache->dout || !cache->col_d ||
+      !cache->col_s)
+    return HSCN_E_BADARG;
+  if (!opt->exp_avg || !opt->exp_avg_sq || !opt->step || !opt->beta_pows || !opt->lr ||
+      !(opt->beta1 >= 0.0 && opt->beta1 < 1.0 && opt->beta2 >= 0.0 && opt->beta2 < 1.0) || !(opt->eps >= 0.0) ||
+      !(opt->weight_decay >= 0.0))
+    return HSCN_E_BADARG;
+  ScnArgs A{};
+  A.x = x;
+  A.W_rel = W_rel; A.b_rel = b_rel; A.W_root = W_root; A.W_mlp = W_mlp; A.b_mlp = b_mlp;
+  A.stats = stats; A.losses = losses; A.ticket = ticket; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
+  A.g_mc = g_mc; A.g_o = g_o;
+  A.max_n = max_n; A.max_e = max_e; A.B = 1; A.P = (int)scn_param_count(F, H, K); A.partials = grads;
+  A.ex_col_d = cache->col_d; A.ex_col_s = cache->col_s; A.ex_agg = cache->agg; A.ex_dout = cache->dout; A.pre = 1;
+  A.adam_m = opt->exp_avg; A.adam_v = opt->exp_avg_sq; A.adam_step = opt->step; A.adam_pows = opt->beta_pows;
+  A.adam_lr = opt->lr; A.adam_b1 = opt->beta1; A.adam_b2 = opt->beta2; A.adam_eps = opt->eps;
+  A.adam_wd = opt->weight_decay; A.adam_decoupled = opt->decoupled;
+  hipStream_t st = hscn_stream(stream_);
+  for (int64_t v = 0; v < visits; ++v) {
+    const int64_t g = v % G;
+    // the kernel sees a batch of one graph whose ranges are entries g, g + 1 of the dataset's; the dataset-level
+    // structure keeps graph g's row pointers at nptr[g] + g: the + g travels in the base pointers
+    A.nptr = nptr + g; A.eptr = eptr + g;
+    A.ex_rowptr_d = cache->rowptr_d + g; A.ex_rowptr_s = cache->rowptr_s + g;
+    int rc = f16 ? (H == 16 ? launch_scn<16, half_t>(A, 2, st) : launch_scn<32, half_t>(A, 2, st))
+                 : (H == 16 ? launch_scn<16, float>(A, 2, st) : launch_scn<32, float>(A, 2, st));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int hscn_scn_resident_train_epoch(const float* x, const int32_t* nptr, const int32_t* eptr, int64_t N, int64_t G,
+                                  int64_t visits, int F, int H, int K, int act, float* W_rel, float* b_rel,
+                                  float* W_root, float* W_mlp, float* b_mlp, const float* g_mc, const float* g_o,
+                                  int max_n, int max_e, const hscn_scn_structure* cache, const hscn_adam* opt,
+                                  float* grads, float* stats, float* losses, int32_t* ticket, int32_t* flag,
+                                  void* stream_) {
+  return scn_epoch_impl(0, x, nptr, eptr, N, G, visits, F, H, K, act, W_rel, b_rel, W_root, W_mlp, b_mlp, g_mc, g_o,
+                        max_n, max_e, cache, opt, grads, stats, losses, ticket, flag, stream_);
+}
+int hscn_scn_resident_train_epoch_f16(const hscn_half* x, const int32_t* nptr, const int32_t* eptr, int64_t N, int64_t G,
+                                      int64_t visits, int F, int H, int K, int act, float* W_rel, float* b_rel,
+                                      float* W_root, float* W_mlp, float* b_mlp, const float* g_mc,
+                                      const float* g_o, int max_n, int max_e, const hscn_scn_structure* cache,
+                                      const hscn_adam* opt, float* grads, float* stats, float* losses,
+                                      int32_t* ticket, int32_t* flag, void* stream_) {
+  return scn_epoch_impl(1, (const float*)x, nptr, eptr, N, G, visits, F, H, K, act, W_rel, b_rel, W_root, W_mlp, b_mlp,
+                        g_mc, g_o, max_n, max_e, cache, opt, grads, stats, losses, ticket, flag, stream_);
+}
 int hscn_scn_resident_train_step(const float* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                                  const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                                  const float* W_rel, const float* b_rel, const float* W_root, const float* W_mlp,

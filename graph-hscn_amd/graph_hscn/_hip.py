@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -67,6 +67,8 @@ _SIGNATURES = {
     "hscn_scn_resident_train_step_supported": (c_int, [c_int] * 5),
     "hscn_scn_resident_train_step": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P,
                                              P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
+    "hscn_scn_resident_train_epoch": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, P, P, P, P, P,
+                                              P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
     "hscn_adam_step": (c_int, [P, P, c_int, P, P, P, c_int64, P, P, P, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                ctypes.c_double, c_int, P]),
     "hscn_resident_supported": (c_int, [c_int] * 8),
@@ -91,7 +93,7 @@ _SIGNATURES = {
 # IEEE-half storage twins (include/hscn.h: hscn_resident_*_f16): same argument lists
 for _n in ("hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual", "hscn_resident_bwd_with_virtual",
            "hscn_scn_resident_fwd", "hscn_scn_resident_bwd", "hscn_resident_train_step",
-           "hscn_scn_resident_train_step"):
+           "hscn_scn_resident_train_step", "hscn_scn_resident_train_epoch"):
     _SIGNATURES[_n + "_f16"] = _SIGNATURES[_n]
 
 

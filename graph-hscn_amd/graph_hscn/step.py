@@ -427,3 +427,100 @@ class ScnTrainStep:
 
     def check(self) -> None:
         self.meta.check()
+
+
+class ScnEpochRunner:
+    """The reference's stage-A loop (train/train_clustering.py:34-69: one optimizer step per graph, graph after
+    graph, ``cluster_epochs`` times, then the assignment pass) driven from ONE foreign call
+    (``hscn_scn_resident_train_epoch``): the dataset lies in HBM as one block-diagonal ``Batch``, ONE forward launch
+    over it builds every graph's CSRs / out-degrees / ``A_hat x`` (``hscn_scn_structure``), the library then issues
+    one launch per graph visit (step + optimizer in its tail, structure loaded) back to back, and ONE more forward
+    launch over the dataset is the assignment pass.  The arithmetic of ``ScnTrainStep.run(opt=...)`` per graph, bit
+    for bit; no per-graph Python objects, uploads or calls.
+
+    ``eligible(...)`` says whether a model / dataset / optimizer qualifies (Adam or AdamW, the one-launch step's
+    shapes)."""
+
+    @staticmethod
+    def eligible(model, big, optim_type: str) -> bool:
+        from .model.hscn import SCN
+        if not isinstance(model, SCN) or optim_type not in ("adam", "adamW") or not model.resident_ok(big):
+            return False
+        conv, lin = model.mp.module_0, list(model.mlp)[0]
+        H, F = conv.lin_rel.weight.shape
+        K = lin.weight.shape[0]
+        meta = _engine.scn_meta(big, conv.lin_rel.weight.device)
+        P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
+        return bool(_hip.lib().hscn_scn_resident_train_step_supported(F, H, K, meta.max_n, meta.max_e))
+
+    def __init__(self, model, big, optim_type: str, lr: float, weight_decay: float):
+        from .optim import FlatAdam
+        conv, lin = model.mp.module_0, list(model.mlp)[0]
+        dev = conv.lin_rel.weight.device
+        self.model = model
+        self.meta = meta = _engine.scn_meta(big, dev)
+        x = big.x if big.x.is_cuda else big.x.to(dev)
+        self.x = (x if x.dtype == torch.float16 else x.float()).contiguous()
+        self._sfx = _engine.storage_suffix(self.x.dtype)
+        self.ei = (big.edge_index if big.edge_index.is_cuda else big.edge_index.to(dev)).contiguous()
+        self.act = _engine.ACT[model.mp.act]
+        self._mp = [conv.lin_rel.weight, conv.lin_rel.bias, conv.lin_root.weight, lin.weight, lin.bias]
+        if not all(p.is_contiguous() for p in self._mp):
+            raise ValueError("the epoch kernel updates the parameters in their own storage: they must be contiguous")
+        N, F = self.x.shape
+        H, K = conv.lin_rel.weight.shape[0], lin.weight.shape[0]
+        G, E = meta.num_graphs, self.ei.size(1)
+        self.dims = (N, F, H, K, G, E)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.S = torch.empty(N, K, **f32)
+        self._y = torch.empty(N, H, dtype=self.x.dtype, device=dev)
+        self._stats = torch.empty(G, 4, **f32)
+        self._ss = torch.empty(G, K, K, **f32)
+        self.losses = torch.zeros(3, **f32)
+        self._ticket = torch.zeros(1, **i32)
+        self._one = torch.ones(1, **f32)
+        self._cache_t = (torch.empty(N + G, **i32), torch.empty(max(E, 1), **i32), torch.empty(N + G, **i32),
+                         torch.empty(max(E, 1), **i32), torch.empty(max(N, 1), 16, **f32), torch.empty(max(N, 1), **f32))
+        P = int(_hip.lib().hscn_scn_resident_param_count(F, H, K))
+        self.grads = torch.zeros(P, **f32)
+        views, off = [], 0
+        for p_ in self._mp:
+            views.append((p_, self.grads[off: off + p_.numel()].view_as(p_)))
+            off += p_.numel()
+        self.param_grads = views
+        self.optimizer = FlatAdam.from_config(optim_type, views, self.grads, lr, weight_decay)
+        self._forward(export=True)                      # one launch: every graph's structure
+        c = self._cache_t
+        self._cache = _ScnStructC(ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(c[5]), 1)
+
+    def _forward(self, export: bool) -> None:
+        N, F, H, K, G, E = self.dims
+        m = self.meta
+        W_rel, b_rel, W_root, W_mlp, b_mlp = self._mp
+        ex = [ptr(t) for t in self._cache_t] if export else [None] * 6
+        call("hscn_scn_resident_fwd" + self._sfx, ptr(self.x), ptr(self.ei) if E else None, E, ptr(m.nptr), ptr(m.eptr),
+             N, G, F, H, K, self.act, ptr(W_rel), ptr(b_rel), ptr(W_root), ptr(W_mlp), ptr(b_mlp), m.max_n, m.max_e,
+             ptr(self.S), ptr(self._y), ptr(self._stats), ptr(self._ss), ptr(self.losses), ptr(self._ticket), *ex,
+             ptr(m.flag), stream())
+
+    def run(self, visits: int) -> None:
+        """``visits`` graph visits in dataset order (visit v takes graph v mod G).  One call; the launches are
+        asynchronous."""
+        N, F, H, K, G, E = self.dims
+        m = self.meta
+        call("hscn_scn_resident_train_epoch" + self._sfx, ptr(self.x), ptr(m.nptr), ptr(m.eptr), N, G, int(visits), F, H,
+             K, self.act, *[ptr(p_) for p_ in self._mp], ptr(self._one), ptr(self._one), m.max_n, m.max_e,
+             ctypes.byref(self._cache),
+             ctypes.byref(self.optimizer.c), ptr(self.grads), ptr(self._stats), ptr(self.losses), ptr(self._ticket),
+             ptr(m.flag), stream())
+
+    def assign(self) -> Tensor:
+        """The assignment pass (train/train_clustering.py:57-69) as ONE forward launch over the dataset: the soft
+        assignments ``S`` [N, K] of all graphs with the weights as they are now."""
+        self._forward(export=False)
+        return self.S
+
+    def check(self) -> None:
+        self.meta.check()
+        self.optimizer.check()

@@ -60,7 +60,7 @@ def _forward(model: SCN, graphs: Sequence, device, cache: dict = None, key=None)
 
 
 def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, batch_graphs: int, device,
-                             flat_optimizer: bool = True):
+                             flat_optimizer: bool = True, epoch_kernel: bool = True):
     """The same loop with every step issued as direct C-ABI launches (``step.ScnTrainStep`` on one shared workspace:
     one launch for forward + losses + backward where the shape fits, else the launch pair + ordered reduction)
     followed by the optimizer step as one more launch (``optim.FlatAdam``; a replay of torch's captured step for
@@ -70,8 +70,27 @@ def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, 
     qualify (the caller then takes the autograd loop)."""
     from ..optim import FlatAdam
     from ..replay import capture_optimizer_step
-    from ..step import ScnStructurePool, ScnTrainStep, ScnWorkspace
+    from ..step import ScnEpochRunner, ScnStructurePool, ScnTrainStep, ScnWorkspace
     n = len(dataset)
+    if batch_graphs == 1 and epoch_kernel and flat_optimizer and n > 0 and \
+            not any(getattr(dataset[j], "edge_weight", None) is not None for j in range(n)):
+        # the reference's own form -- one optimizer step per graph -- with the whole chain of visits issued by ONE call
+        big = Batch.from_data_list([dataset[j] for j in range(n)])
+        big.x = big.x.float()                     # (as the per-visit loop below: float features)
+        if ScnEpochRunner.eligible(model, big, optim_cfg.optim_type):
+            runner = ScnEpochRunner(model, big.to(device), optim_cfg.optim_type, optim_cfg.lr, optim_cfg.weight_decay)
+            if logger is not None:
+                logger.info(f"Fitting clustering, {model_cfg.cluster_epochs} epochs in one call...")
+            runner.run(model_cfg.cluster_epochs * n)
+            if logger is not None:
+                logger.info("Generating cluster assignments...")
+            ids = _assign(runner.assign())
+            torch.cuda.synchronize(device)
+            runner.check()
+            ids = ids.cpu().numpy()
+            p_ = big.ptr.cpu().numpy()
+            model.last_engine = "resident"
+            return [ids[p_[k]:p_[k + 1]] for k in range(n)]
     groups = [[dataset[j] for j in range(i, min(i + batch_graphs, n))] for i in range(0, n, batch_graphs)]
     datas = [g[0] if len(g) == 1 else Batch.from_data_list(g) for g in groups]
     if any(getattr(d, "edge_weight", None) is not None for d in datas) or not all(model.resident_ok(d) for d in datas):
@@ -135,12 +154,13 @@ def _train_clustering_direct(logger, dataset, model: SCN, model_cfg, optim_cfg, 
 
 
 def train_clustering(logger, dataset, model: SCN, model_cfg, optim_cfg, training_cfg,
-                     batch_graphs: int = 1, direct: bool = True) -> List[np.ndarray]:
+                     batch_graphs: int = 1, direct: bool = True, epoch_kernel: bool = True) -> List[np.ndarray]:
     device = next(model.parameters()).device
     if device.type != "cuda":
         raise RuntimeError("train_clustering runs on the MI355X HIP path: move the SCN to 'cuda'")
     if direct:
-        done = _train_clustering_direct(logger, dataset, model, model_cfg, optim_cfg, batch_graphs, device)
+        done = _train_clustering_direct(logger, dataset, model, model_cfg, optim_cfg, batch_graphs, device,
+                                        epoch_kernel=epoch_kernel)
         if done is not None:
             return done
     optimizer = OPTIM_DICT[optim_cfg.optim_type](lr=optim_cfg.lr, weight_decay=optim_cfg.weight_decay,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 10
+#define HSCN_ABI_VERSION 11
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -633,6 +633,28 @@ int hscn_scn_resident_train_step(const float* x, const int64_t* edge_index, int6
                                  float* losses /*[3]*/, int32_t* ticket /*[1] or NULL*/, float* partials /*[B,P]*/,
                                  float* grads /*[P]*/, int32_t* flag, const hscn_adam* opt /*or NULL*/,
                                  const hscn_scn_structure* cache /*or NULL*/, void* stream);
+/* A whole run of the reference's stage-A loop (train/train_clustering.py:34-50: one optimizer step per graph, graph
+ * after graph, epoch after epoch) from ONE call: `visits` graph visits in dataset order (visit v takes graph v mod G
+ * of a dataset laid out as one block-diagonal batch: nptr / eptr [G+1]), each the launch of
+ * hscn_scn_resident_train_step(B = 1, opt, cache) on that graph, issued back to back by the library (no host
+ * language between two visits).  cache: REQUIRED and ready -- the structure of ALL G graphs in the batch layout (one
+ * hscn_scn_resident_fwd launch over the dataset with its ex_* outputs builds it); opt: REQUIRED; W_rel .. b_mlp and
+ * opt's state are updated in place by every visit; g_mc / g_o: the upstream gradients of the two losses (device
+ * scalars; the loop's loss mincut + ortho has both = 1); grads [P], stats [4], losses [3]: the last visit's; ticket:
+ * a zeroed device int32.  hscn_scn_resident_train_step_supported says whether the shapes qualify. */
+int hscn_scn_resident_train_epoch(const float* x, const int32_t* nptr, const int32_t* eptr, int64_t N, int64_t G,
+                                  int64_t visits, int F, int H, int K, int act, float* W_rel, float* b_rel,
+                                  float* W_root, float* W_mlp, float* b_mlp, const float* g_mc /*[1]*/,
+                                  const float* g_o /*[1]*/, int max_n, int max_e,
+                                  const hscn_scn_structure* cache, const hscn_adam* opt, float* grads /*[P]*/,
+                                  float* stats /*[4]*/, float* losses /*[3]*/, int32_t* ticket, int32_t* flag,
+                                  void* stream);
+int hscn_scn_resident_train_epoch_f16(const hscn_half* x, const int32_t* nptr, const int32_t* eptr, int64_t N,
+                                      int64_t G, int64_t visits, int F, int H, int K, int act, float* W_rel,
+                                      float* b_rel, float* W_root, float* W_mlp, float* b_mlp, const float* g_mc,
+                                      const float* g_o, int max_n, int max_e, const hscn_scn_structure* cache,
+                                      const hscn_adam* opt, float* grads, float* stats, float* losses,
+                                      int32_t* ticket, int32_t* flag, void* stream);
 int hscn_scn_resident_train_step_f16(const hscn_half* x, const int64_t* edge_index, int64_t E, const int32_t* nptr,
                                      const int32_t* eptr, int64_t N, int64_t B, int F, int H, int K, int act,
                                      const float* W_rel, const float* b_rel, const float* W_root,

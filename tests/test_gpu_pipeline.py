@@ -259,3 +259,34 @@ def test_stage_a_driver_follows_the_reference_trajectory(optim):
         flips += int((want != got).sum())
         sure_nodes += int(sure.sum())
     print(f"stage-A trajectory ({optim}): ids equal on all {sure_nodes} nodes with margin > 1e-5; flips on nearer ties: {flips}")
+
+
+@pytest.mark.parametrize("kind", ["adam", "adamW"])
+def test_stage_a_epoch_kernel_is_the_per_visit_loop_bit_for_bit(kind):
+    """The reference's stage-A loop from ONE call (hscn_scn_resident_train_epoch: the dataset as one batch in HBM, its
+    structure built by one forward launch, the visits issued back to back by the library, the assignment pass one
+    more launch) against the same loop issued visit by visit from Python (ScnTrainStep.run(opt=...) on per-graph
+    objects): identical parameters and cluster ids after 3 epochs over 24 graphs of very different sizes."""
+    import numpy as np
+    from graph_hscn.config.config import HSCNConfig, OptimConfig, TrainingConfig
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import SCN
+    from graph_hscn.train.train_clustering import train_clustering
+    graphs = make_dataset("peptides_func", 24, seed=13)
+    mc = HSCNConfig("relu", num_clusters=16, cluster_epochs=3)
+    oc = OptimConfig(kind, lr=0.01, weight_decay=0.01 if kind == "adamW" else 0.0)
+    tc = TrainingConfig("hscn", "cross_entropy", "ap")
+
+    def run(epoch_kernel):
+        torch.manual_seed(5)
+        scn = SCN([16], "elu", 9, 16).to("cuda")
+        ids = train_clustering(None, graphs, scn, mc, oc, tc, batch_graphs=1, epoch_kernel=epoch_kernel)
+        return [p.detach().clone() for p in scn.parameters()], ids
+
+    pa, ia = run(True)
+    pb, ib = run(False)
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y), float((x - y).abs().max())
+    assert len(ia) == len(ib) == 24
+    for x, y in zip(ia, ib):
+        assert np.array_equal(x, y)

@@ -32,21 +32,33 @@ def main(G=1024, epochs=5, K=16):
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         assert len(ids) == G
-        # steady state: the difference of two runs that differ in the number of epochs only (setup -- uploading the
-        # graphs, building the per-step objects, capturing the optimizer step -- cancels)
-        mc2 = HSCNConfig("relu", num_clusters=K, cluster_epochs=3 * epochs)
+        # (whole-driver figure: upload of the graphs, structure launch, the chain of visits, assignment pass.  The cost
+        # of ONE visit is measured with device timers below and, per issue form, by tools/bench_stage_a_visits.py; an
+        # earlier version of this tool derived it from the difference of two runs with different epoch counts and
+        # read ~30 % low)
+        out[f"batch_graphs={bg}"] = {"seconds": t, "graph_visits_per_s": G * (epochs + 1) / t}
+    # the chain of visits alone (hscn_scn_resident_train_epoch: one call, one launch per graph visit), device timers
+    from graph_hscn.data import Batch
+    from graph_hscn.step import ScnEpochRunner
+    big = Batch.from_data_list(graphs)
+    big.x = big.x.float()
+    torch.manual_seed(0)
+    scn = SCN(mc.mp_units, "elu", 9, K).to("cuda")
+    if ScnEpochRunner.eligible(scn, big, "adam"):
+        r = ScnEpochRunner(scn, big.to("cuda"), "adam", 0.01, 0.0)
+        r.run(G)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        train_clustering(None, graphs, scn, mc2, oc, tc, batch_graphs=bg)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter() - t0
-        per_visit = (t2 - t) / (2 * epochs * G)
-        # (batched: 8 steps per epoch -- the difference of two runs is within the noise of their setup; only the
-        # whole-run figure is reported)
-        steady = per_visit > 0 and bg == 1
-        out[f"batch_graphs={bg}"] = {"seconds": t, "graph_visits_per_s": G * (epochs + 1) / t,
-                                     "steady_state_us_per_graph_visit": per_visit * 1e6 if steady else None,
-                                     "steady_state_graphs_per_s": 1.0 / per_visit if steady else None}
+        per = []
+        for _ in range(3):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            r.run(10 * G)
+            e_.record()
+            torch.cuda.synchronize()
+            per.append(s_.elapsed_time(e_) * 1e3 / (10 * G))
+        r.check()
+        out["visit_chain"] = {"us_per_graph_visit": sorted(per)[1], "graphs_per_s": 1e6 / sorted(per)[1],
+                              "runs_us": per, "visits_per_run": 10 * G}
     print(json.dumps(out))
 
 

@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 be
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/stage_a_kernel_stats.csv \;
 rm -rf $OUT/trace
 timeout -k 10 300 python3 tools/bench_train_clustering.py > $OUT/stage_a_driver.json 2> $OUT/driver.err || exit 1
+timeout -k 10 600 python3 tools/bench_stage_a_visits.py > $OUT/stage_a_visits.json 2>> $OUT/driver.err || exit 1
 if [ -f graph-hscn_amd/graph_hscn/lib/libhscn_diag.so ]; then
   HSCN_LIB=graph-hscn_amd/graph_hscn/lib/libhscn_diag.so timeout -k 10 200 python3 tools/diag_scn.py step > $OUT/diag_scn_step.txt 2>&1 || exit 1
 fi
