@@ -41,6 +41,7 @@ struct ScnArgs {
   // exported (graph g: rowptr at nptr[g] + g, columns at eptr[g]) and loaded by the backward launch
   int32_t *ex_rowptr_d, *ex_col_d, *ex_rowptr_s, *ex_col_s;
   float *ex_agg, *ex_dout;  // [N,FP], [N]
+  float* ex_xpad;           // [N,FP] or NULL: the features padded to FP columns as LDS holds them (float4 loads in the cached front)
   int pre;                  // one-launch step: the ex_* arrays hold this batch's structure already (loaded, not built)
   // forward only: losses [3] = {mean mincut, mean ortho, their sum}; with a ticket counter (zero before
   // the first launch, left at zero) the workgroup that finishes last reduces the per-graph statistics
@@ -321,13 +322,28 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       dop[i] = KF->ex_dout[(size_t)n0 + (idx < n ? idx : 0)];
     }
   }
+  // cached front with padded features: x and A_hat x arrive as 16-byte pieces (n * FP / 4 of them each, at most two
+  // per thread for n <= 512) instead of eight words per thread each
+  constexpr int QPT = 2;
+  const bool wide = pre && KF->ex_xpad != nullptr && n * (FP / 4) <= QPT * SRT;
+  float4 xq[QPT], aq[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    xq[i] = make_float4(0.f, 0.f, 0.f, 0.f); aq[i] = xq[i];
+    const int i4 = threadIdx.x + i * SRT;
+    if (wide && wbase + i * SRT < n * (FP / 4)) {
+      const size_t at = (size_t)n0 * (FP / 4) + (i4 < n * (FP / 4) ? i4 : 0);
+      xq[i] = reinterpret_cast<const float4*>(KF->ex_xpad)[at];
+      aq[i] = reinterpret_cast<const float4*>(KF->ex_agg)[at];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int idx = threadIdx.x + i * SRT;
     const int r = idx / FP, k = idx - r * FP;
     const bool ok = idx < n * FP && k < F;
     xr[i] = 0.f; agr[i] = 0.f;
-    if (wbase + i * SRT < n * FP) {
+    if (!wide && wbase + i * SRT < n * FP) {
       const float t = ldf(xg, ok ? (size_t)(n0 + r) * F + k : 0);
       xr[i] = ok ? t : 0.f;
       if (pre) agr[i] = KF->ex_agg[(size_t)n0 * FP + (idx < n * FP ? idx : 0)];
@@ -371,21 +387,34 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       rowptr_s[idx] = KF->ex_rowptr_s[(size_t)n0 + g + idx];
       if (idx < n) dout[idx] = KF->ex_dout[(size_t)n0 + idx];
     }
+    if (!wide) {
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int idx = threadIdx.x + i * SRT;
+        if (idx < n * FP) agg[idx] = agr[i];
+      }
+      for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = KF->ex_agg[(size_t)n0 * FP + idx];
+    }
+  }
+  if (wide) {
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+      const int i4 = threadIdx.x + i * SRT;
+      if (i4 < n * (FP / 4)) {
+        reinterpret_cast<float4*>(xs)[i4] = xq[i];
+        reinterpret_cast<float4*>(agg)[i4] = aq[i];
+      }
+    }
+  } else {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int idx = threadIdx.x + i * SRT;
-      if (idx < n * FP) agg[idx] = agr[i];
+      if (idx < n * FP) xs[idx] = xr[i];
     }
-    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) agg[idx] = KF->ex_agg[(size_t)n0 * FP + idx];
-  }
-#pragma unroll
-  for (int i = 0; i < XPT; ++i) {
-    const int idx = threadIdx.x + i * SRT;
-    if (idx < n * FP) xs[idx] = xr[i];
-  }
-  for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
-    const int i = idx / FP, k = idx - i * FP;
-    xs[idx] = k < F ? ldf(xg, (size_t)(n0 + i) * F + k) : 0.f;
+    for (int idx = threadIdx.x + XPT * SRT; idx < n * FP; idx += SRT) {
+      const int i = idx / FP, k = idx - i * FP;
+      xs[idx] = k < F ? ldf(xg, (size_t)(n0 + i) * F + k) : 0.f;
+    }
   }
 #pragma unroll
   for (int i = 0; i < WPT; ++i) {
@@ -440,6 +469,7 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       a.z = add_rn(a.z, mul_rn(wl, v.z)); a.w = add_rn(a.w, mul_rn(wl, v.w));
       *reinterpret_cast<float4*>(agg + i * FP + f) = a;
       if (KF->ex_agg) *reinterpret_cast<float4*>(KF->ex_agg + (size_t)(n0 + i) * FP + f) = a;
+      if (KF->ex_xpad) *reinterpret_cast<float4*>(KF->ex_xpad + (size_t)(n0 + i) * FP + f) = v;   // (x_i, padded)
     }
   }
   // hand the structure to the backward launch
@@ -1462,7 +1492,8 @@ static int scn_step_impl(int f16, const float* x, const int64_t* edge_index, int
   A.partials = B == 1 ? grads : partials;   // one graph: its partials are the gradients
   if (cache) {   // ready: load the structure an earlier visit exported; else build it and export
     A.ex_rowptr_d = cache->rowptr_d; A.ex_col_d = cache->col_d; A.ex_rowptr_s = cache->rowptr_s;
-    A.ex_col_s = cache->col_s; A.ex_agg = cache->agg; A.ex_dout = cache->dout; A.pre = cache->ready != 0;
+    A.ex_col_s = cache->col_s; A.ex_agg = cache->agg; A.ex_dout = cache->dout; A.ex_xpad = cache->xpad;
+    A.pre = cache->ready != 0;
   }
   if (opt) {
     A.adam_m = opt->exp_avg; A.adam_v = opt->exp_avg_sq; A.adam_step = opt->step; A.adam_pows = opt->beta_pows;
@@ -1600,7 +1631,8 @@ static int scn_epoch_impl(int f16, const float* x, const int32_t* nptr, const in
   A.stats = stats; A.losses = losses; A.ticket = ticket; A.flag = flag; A.N = N; A.F = F; A.K = K; A.act = act;
   A.g_mc = g_mc; A.g_o = g_o;
   A.max_n = max_n; A.max_e = max_e; A.B = 1; A.P = (int)scn_param_count(F, H, K); A.partials = grads;
-  A.ex_col_d = cache->col_d; A.ex_col_s = cache->col_s; A.ex_agg = cache->agg; A.ex_dout = cache->dout; A.pre = 1;
+  A.ex_col_d = cache->col_d; A.ex_col_s = cache->col_s; A.ex_agg = cache->agg; A.ex_dout = cache->dout;
+  A.ex_xpad = cache->xpad; A.pre = 1;
   A.adam_m = opt->exp_avg; A.adam_v = opt->exp_avg_sq; A.adam_step = opt->step; A.adam_pows = opt->beta_pows;
   A.adam_lr = opt->lr; A.adam_b1 = opt->beta1; A.adam_b2 = opt->beta2; A.adam_eps = opt->eps;
   A.adam_wd = opt->weight_decay; A.adam_decoupled = opt->decoupled;

@@ -260,7 +260,8 @@ class ScnWorkspace:
 
 class _ScnStructC(ctypes.Structure):      # include/hscn.h: hscn_scn_structure
     _fields_ = [("rowptr_d", ctypes.c_void_p), ("col_d", ctypes.c_void_p), ("rowptr_s", ctypes.c_void_p),
-                ("col_s", ctypes.c_void_p), ("agg", ctypes.c_void_p), ("dout", ctypes.c_void_p), ("ready", ctypes.c_int)]
+                ("col_s", ctypes.c_void_p), ("agg", ctypes.c_void_p), ("dout", ctypes.c_void_p), ("xpad", ctypes.c_void_p),
+                ("ready", ctypes.c_int)]
 
 
 class ScnStructurePool:
@@ -276,6 +277,7 @@ class ScnStructurePool:
         # (node-indexed arrays are sliced at the row-pointer offsets, which count one more word per graph)
         self._agg = torch.empty(max(total_nodes + total_graphs, 1), 16, dtype=torch.float32, device=device)
         self._dout = torch.empty(max(total_nodes + total_graphs, 1), dtype=torch.float32, device=device)
+        self._xpad = torch.empty(max(total_nodes + total_graphs, 1), 16, dtype=torch.float32, device=device)
         self._n = self._e = 0
 
     def take(self, N: int, E: int, B: int) -> _ScnStructC:
@@ -285,7 +287,7 @@ class ScnStructurePool:
         self._n, self._e = n + N + B, e + E
         p = _hip.ptr
         return _ScnStructC(p(self._rp[0][n:]), p(self._col[0][e:]), p(self._rp[1][n:]), p(self._col[1][e:]),
-                           p(self._agg[n:]), p(self._dout[n:]), 0)
+                           p(self._agg[n:]), p(self._dout[n:]), p(self._xpad[n:]), 0)
 
 
 class ScnTrainStep:
@@ -492,7 +494,9 @@ class ScnEpochRunner:
         self.optimizer = FlatAdam.from_config(optim_type, views, self.grads, lr, weight_decay)
         self._forward(export=True)                      # one launch: every graph's structure
         c = self._cache_t
-        self._cache = _ScnStructC(ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(c[5]), 1)
+        self._xpad = torch.zeros(max(N, 1), 16, **f32)  # the features as LDS holds them: float, 16 columns
+        self._xpad[:N, :F] = self.x.float()
+        self._cache = _ScnStructC(ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(c[5]), ptr(self._xpad), 1)
 
     def _forward(self, export: bool) -> None:
         N, F, H, K, G, E = self.dims

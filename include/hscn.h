@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 11
+#define HSCN_ABI_VERSION 13
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -610,6 +610,7 @@ typedef struct hscn_scn_structure {
   int32_t* col_s;    /* [E] */
   float* agg;        /* [N, 16] */
   float* dout;       /* [N] */
+  float* xpad;       /* [N, 16] or NULL: the input features zero-padded to 16 columns (16-byte loads on later visits) */
   int ready;
 } hscn_scn_structure;
 

@@ -89,6 +89,21 @@ def main(G=1024, K=16):
     scn = SCN([16], "elu", 9, K).to(dev)
     r = ScnEpochRunner(scn, big.to(dev), "adam", 0.01, 0.0)
     out["one call"] = timed(lambda: r.run(G), G)
+    # the same pass captured once as a hipGraph of G kernel nodes and replayed (what ScnEpochRunner.run does per epoch)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        r.run(G)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg):
+        r.run(G)
+    torch.cuda.synchronize()
+    t_cap = time.perf_counter() - t0
+    out["one call, captured pass replayed"] = timed(cg.replay, G)
+    out["one call, captured pass replayed"]["capture_seconds"] = t_cap
     r.check()
     for k, v in out.items():
         if isinstance(v, dict):
