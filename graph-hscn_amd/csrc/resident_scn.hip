@@ -17,6 +17,7 @@
 // Existing self loops in the input (none in LRGB) become the unit self loop, as
 // add_remaining_self_loops does for unit weights.
 // Ordered reductions only; per-graph parameter-gradient partials + one ordered fold.
+#include <cstdlib>
 #include "hscn_common.h"
 #include "resident_common.h"
 
@@ -43,6 +44,7 @@ struct ScnArgs {
   float *ex_agg, *ex_dout;  // [N,FP], [N]
   float* ex_xpad;           // [N,FP] or NULL: the features padded to FP columns as LDS holds them (float4 loads in the cached front)
   int pre;                  // one-launch step: the ex_* arrays hold this batch's structure already (loaded, not built)
+  long long visits, visit0; // k_scn_epoch: graph visits of the launch, number of the first one
   // forward only: losses [3] = {mean mincut, mean ortho, their sum}; with a ticket counter (zero before
   // the first launch, left at zero) the workgroup that finishes last reduces the per-graph statistics
   float* losses;
@@ -250,7 +252,7 @@ __device__ __forceinline__ void scn_losses_wave(const float* stats, float* losse
 // Weights land transposed: WrT / WoT [FP][H] (rows k >= F zero), brl [H], WmT [H][K], bml [K].
 template <int H, typename TS, bool PRE>
 __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* ib, int n0, int n, int e0, int ne,
-                          int g) {
+                          int g, bool load_w = true) {   // load_w = false: the weights in LDS are current (k_scn_epoch)
   constexpr int NW = SRT / 64;
   const TS* const xg = reinterpret_cast<const TS*>(A.x);   // node features in their storage type (float or half)
   const int K = A.K, F = A.F;
@@ -272,27 +274,32 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
   long long rd[EPT], rs[EPT];
   float xr[XPT];
 #pragma unroll
-  for (int i = 0; i < WPT; ++i) {
-    const int d = threadIdx.x + i * SRT;          // slot k*H + o
-    const int k = d / H, o = d - k * H;
-    const bool ok = d < FP * H && k < F;
-    const float a = A.W_rel[ok ? o * F + k : 0], b = A.W_root[ok ? o * F + k : 0];
-    wr[i] = ok ? a : 0.f;
-    wo[i] = ok ? b : 0.f;
-  }
+  for (int i = 0; i < WPT; ++i) { wr[i] = 0.f; wo[i] = 0.f; }
 #pragma unroll
-  for (int i = 0; i < MPT; ++i) {
-    const int d = threadIdx.x + i * SRT;          // slot h*K + k
-    const int h = d / K, k = d - h * K;
-    const bool ok = d < H * K;
-    wm[i] = 0.f;
-    if (wbase + i * SRT < H * K) {
-      const float t = A.W_mlp[ok ? k * H + h : 0];
-      wm[i] = ok ? t : 0.f;
+  for (int i = 0; i < MPT; ++i) wm[i] = 0.f;
+  if (load_w) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int d = threadIdx.x + i * SRT;          // slot k*H + o
+      const int k = d / H, o = d - k * H;
+      const bool ok = d < FP * H && k < F;
+      const float a = A.W_rel[ok ? o * F + k : 0], b = A.W_root[ok ? o * F + k : 0];
+      wr[i] = ok ? a : 0.f;
+      wo[i] = ok ? b : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < MPT; ++i) {
+      const int d = threadIdx.x + i * SRT;          // slot h*K + k
+      const int h = d / K, k = d - h * K;
+      const bool ok = d < H * K;
+      if (wbase + i * SRT < H * K) {
+        const float t = A.W_mlp[ok ? k * H + h : 0];
+        wm[i] = ok ? t : 0.f;
+      }
+    }
+    if (wbase < H) vb = A.b_rel[threadIdx.x < H ? threadIdx.x : 0];
+    if (wbase < K) vm = A.b_mlp[(int)threadIdx.x < K ? threadIdx.x : 0];
   }
-  if (wbase < H) vb = A.b_rel[threadIdx.x < H ? threadIdx.x : 0];
-  if (wbase < K) vm = A.b_mlp[(int)threadIdx.x < K ? threadIdx.x : 0];
   ScnArgsK KF = late_args();     // (the structure cache's fields: read here, not carried in scalar registers)
   constexpr bool pre = PRE;   // the structure of an earlier visit of this batch (ex_*): loaded, not rebuilt
   constexpr int RPT = 2;
@@ -416,18 +423,20 @@ __device__ void scn_front(const ScnArgs& A, const ScnLayout& Y, float* fb, int* 
       xs[idx] = k < F ? ldf(xg, (size_t)(n0 + i) * F + k) : 0.f;
     }
   }
+  if (load_w) {
 #pragma unroll
-  for (int i = 0; i < WPT; ++i) {
-    const int d = threadIdx.x + i * SRT;
-    if (d < FP * H) { WrT[d] = wr[i]; WoT[d] = wo[i]; }
-  }
+    for (int i = 0; i < WPT; ++i) {
+      const int d = threadIdx.x + i * SRT;
+      if (d < FP * H) { WrT[d] = wr[i]; WoT[d] = wo[i]; }
+    }
 #pragma unroll
-  for (int i = 0; i < MPT; ++i) {
-    const int d = threadIdx.x + i * SRT;
-    if (d < H * K) WmT[d] = wm[i];
+    for (int i = 0; i < MPT; ++i) {
+      const int d = threadIdx.x + i * SRT;
+      if (d < H * K) WmT[d] = wm[i];
+    }
+    if (threadIdx.x < H) brl[threadIdx.x] = vb;
+    if ((int)threadIdx.x < K) bml[threadIdx.x] = vm;
   }
-  if (threadIdx.x < H) brl[threadIdx.x] = vb;
-  if ((int)threadIdx.x < K) bml[threadIdx.x] = vm;
   for (int i = threadIdx.x; i <= n; i += SRT) {   // the CSR builds count in these (and hand them back zeroed)
     (ib + Y.cursor)[i] = 0;
     (ib + Y.cursor2)[i] = 0;
@@ -1024,16 +1033,25 @@ __device__ __forceinline__ void scn_bwd_tail(const ScnArgs& A, int n0, int n, fl
 // The per-wave partial tiles and bias sums are parked in the (then dead) S | y | dlogits buffers behind ONE
 // barrier and folded in wave order: three barriers for the whole backward half.
 // T = as_in [n][K] (aliases DL: an element is read by the lane that overwrites it).
+// k_scn_epoch's optimizer state: the thread that folds parameter element p (P <= SRT) keeps its moments in registers
+// across the visits, the counters travel as values; the updated weights go to global memory AND to their transposed
+// slots in LDS, where the next visit reads them.
+struct ScnEpochState {
+  float m, v, step;
+  double b1t, b2t;
+};
 template <int H, typename TS, int NTC>
 __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const float* Sl, const float* yl, float* DL,
                                               const float* dout, const float* WmT, const float* Gss,
                                               const float (&xb)[2][4], const float (&ab)[2][4], float* scratch,
-                                              float* part, float num, float den) {
+                                              float* part, float num, float den, ScnEpochState* ES = nullptr,
+                                              float* wl = nullptr) {
   constexpr int NW = SRT / 64, TD = H / 16;
   const int K = A.K, NT = (K + 15) >> 4;
   const int wave = wave_id(), lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
   const int ntile = (n + 15) >> 4;
-  const float gmc = (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
+  // (the epoch kernel: loss = mincut + ortho of ONE graph, train_clustering.py:48 -- both upstream gradients are 1)
+  const float gmc = ES ? 1.0f : (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = ES ? 1.0f : (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
   const float c_num = -gmc / den, c_den = gmc * num / (den * den);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 gWm[NTC][TD], gWr[TD], gWo[TD];
@@ -1177,10 +1195,20 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
                 : p < oWmlp ? const_cast<float*>(A.W_root) + (p - oWroot)
                 : p < obmlp ? const_cast<float*>(A.W_mlp) + (p - oWmlp) : const_cast<float*>(A.b_mlp) + (p - obmlp);
       const double lr = KA->adam_lr[0];
-      const double b1t = KA->adam_pows[0] * KA->adam_b1, b2t = KA->adam_pows[1] * KA->adam_b2;
+      const double b1t = (ES ? ES->b1t : KA->adam_pows[0]) * KA->adam_b1, b2t = (ES ? ES->b2t : KA->adam_pows[1]) * KA->adam_b2;
       const float step_size = (float)(lr / (1.0 - b1t)), bc2_sqrt = (float)sqrt(1.0 - b2t);
       const float w1 = (float)(1.0 - KA->adam_b1), w2 = (float)(1.0 - KA->adam_b2), b2f = (float)KA->adam_b2;
-      float pv = *pp, g_ = v, m = KA->adam_m[p], vv = KA->adam_v[p];
+      float pv, m, vv;
+      const int K_ = A.K;
+      int wslot;   // the element's slot in the LDS weight block: WrT [FP*H] | WoT [FP*H] | brl [H] | WmT [H*K] | bml [K]
+      if (p < obrel) { const int o_ = p / F, f = p - o_ * F; wslot = f * H + o_; }
+      else if (p < oWroot) wslot = 2 * FP * H + (p - obrel);
+      else if (p < oWmlp) { const int q = p - oWroot, o_ = q / F, f = q - o_ * F; wslot = FP * H + f * H + o_; }
+      else if (p < obmlp) { const int q = p - oWmlp, k_ = q / H, h = q - k_ * H; wslot = 2 * FP * H + H + h * K_ + k_; }
+      else wslot = 2 * FP * H + H + H * K_ + (p - obmlp);
+      if (ES) { pv = wl[wslot]; m = ES->m; vv = ES->v; }   // weights current in LDS, moments in this thread's registers
+      else { pv = *pp; m = KA->adam_m[p]; vv = KA->adam_v[p]; }
+      float g_ = v;
       if (KA->adam_wd != 0.0) {
         if (KA->adam_decoupled) pv = pv * (float)(1.0 - lr * KA->adam_wd);
         else g_ = g_ + (float)KA->adam_wd * pv;
@@ -1191,11 +1219,15 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
       const float denom = sqrtf(vv) / bc2_sqrt + (float)KA->adam_eps;
       pv = pv + (-step_size) * (m / denom);
       *pp = pv;
-      KA->adam_m[p] = m;
-      KA->adam_v[p] = vv;
+      if (ES) { wl[wslot] = pv; ES->m = m; ES->v = vv; }
+      else { KA->adam_m[p] = m; KA->adam_v[p] = vv; }
     }
   }
-  if (KA->adam_m) {
+  if (ES) {   // (every thread carries the counters)
+    ES->b1t = ES->b1t * KA->adam_b1;
+    ES->b2t = ES->b2t * KA->adam_b2;
+    ES->step += 1.0f;
+  } else if (KA->adam_m) {
     lds_barrier();   // every thread has read the counters
     if (threadIdx.x == 0) {
       KA->adam_step[0] = KA->adam_step[0] + 1.0f;
@@ -1406,6 +1438,102 @@ __global__ void __launch_bounds__(SRT) k_scn_step(const ScnArgs A) {
   STAMP(63);
 }
 
+// ---- the chain of visits as ONE launch of one persistent workgroup -------------------------------------------------
+// train/train_clustering.py:34-50 is a chain: every visit needs the weights the previous one left.  One workgroup walks
+// `visits` graphs (g = v mod G): the weights live in LDS (the optimizer's tail updates them there, transposed slots
+// included), the Adam moments in the registers of the threads that fold the gradient (P <= 1024), the counters as
+// values; per visit it loads the graph's features and cached structure and runs exactly the phases of k_scn_step.
+// The shape arguments every phase derives its index arithmetic from are laundered at the top of each visit: the
+// compiler otherwise hoists all of it out of the visit loop and spills (145 scalar / 130 vector registers, measured).
+template <int H, typename TS>
+__global__ void __launch_bounds__(SRT) k_scn_epoch(const ScnArgs A0) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NW = SRT / 64;
+  ScnArgsK KA = late_args();
+  ScnEpochState ES;
+  {
+    const int p = threadIdx.x;
+    ES.m = p < A0.P ? KA->adam_m[p] : 0.f;
+    ES.v = p < A0.P ? KA->adam_v[p] : 0.f;
+    ES.step = KA->adam_step[0];
+    ES.b1t = KA->adam_pows[0];
+    ES.b2t = KA->adam_pows[1];
+  }
+  float num = 0.f, den = 1.f, nrm = 0.f, o = 0.f;
+  bool have_w = false;
+  for (long long v = A0.visit0; v < A0.visit0 + A0.visits; ++v) {
+    ScnArgs A = A0;
+    {   // per-visit opaque copies of what the phases' index arithmetic is derived from
+      int K_ = A.K, F_ = A.F, mn = A.max_n, me = A.max_e, P_ = A.P;
+      asm volatile("" : "+s"(K_), "+s"(F_), "+s"(mn), "+s"(me), "+s"(P_));
+      A.K = K_; A.F = F_; A.max_n = mn; A.max_e = me; A.P = P_;
+    }
+    const int K = A.K;
+    const ScnLayout Y = scn_layout(H, K, A.max_n, A.max_e, 2);
+    float* fb = reinterpret_cast<float*>(smem);
+    int* ib = reinterpret_cast<int*>(smem);
+    float *xs = fb + Y.R1, *agg = xs + (size_t)A.max_n * FP, *Sl = fb + Y.R1, *yl = fb + Y.R2, *DL = fb + Y.R3;
+    float *dout = fb + Y.dout, *red = fb + Y.red;
+    float* WrT = fb + Y.wt;
+    float* WoT = WrT + FP * H;
+    float* brl = WoT + FP * H;
+    float* WmT = brl + H;
+    float* bml = WmT + (size_t)H * K;
+    float* Gss = bml + K;
+    float* ssl = fb + Y.ssl;
+    int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
+    const int wave = wave_id();
+    const int g = (int)(v % A.B);
+    const int n0 = A.nptr[g], n = A.nptr[g + 1] - n0;
+    const int e0 = A.eptr[g], ne = A.eptr[g + 1] - e0;
+    if (n > A.max_n || ne > A.max_e || n < 1 || ne < 0) {   // (uniform) skipped: no step for this graph
+      if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
+      continue;
+    }
+    scn_front<H, TS, true>(A, Y, fb, ib, n0, n, e0, ne, g, !have_w);
+    have_w = true;
+    const int ntile = (n + 15) >> 4;
+    float xb[2][4], ab[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) { xb[t][s_] = 0.f; ab[t][s_] = 0.f; }
+      const int rt = wave + t * NW;
+      if (rt < ntile) scn_hidden_tile<H, TS, true>(A, rt, xs, agg, yl, WrT, WoT, brl, n0, n, xb[t], ab[t]);
+    }
+    lds_barrier();
+    scn_softmax<H>(A, yl, Sl, WmT, bml, n0, n, Sl + (size_t)A.max_n * K);
+    lds_barrier();
+    ScnStats R;
+    scn_stats<NW, true>(A, Sl, rowptr_s, col_s, rowptr_d, col_d, dout, red, Sl + (size_t)A.max_n * K, ssl, R, DL, n, g);
+    num = R.num; den = R.den; nrm = R.nrm; o = R.o;
+    {
+      const float inner = R.inner;
+      const float isk = 1.0f / sqrtf((float)K);
+      for (int i = threadIdx.x; i < K * K; i += SRT) {
+        const int a = i / K, b = i - a * K;
+        const float gq = o > 0.f ? (ssl[i] / nrm - (a == b ? isk : 0.f)) / o : 0.f;
+        Gss[i] = (gq - inner / (nrm * nrm) * ssl[i]) / nrm;
+      }
+    }
+    lds_barrier();
+    if (H == 32 || K <= 16)
+      scn_bwd_tiles<H, TS, 1>(A, n, Sl, yl, DL, dout, WmT, Gss, xb, ab, fb + Y.R1, A.partials, num, den, &ES, fb + Y.wt);
+    else if constexpr (H == 16)
+      scn_bwd_tiles<H, TS, 2>(A, n, Sl, yl, DL, dout, WmT, Gss, xb, ab, fb + Y.R1, A.partials, num, den, &ES, fb + Y.wt);
+    lds_barrier();   // the updated weights (LDS) before the next visit reads them; the parked partials are dead
+  }
+  {
+    const int p = threadIdx.x;
+    if (p < A0.P) { KA->adam_m[p] = ES.m; KA->adam_v[p] = ES.v; }
+    if (p == 0) {
+      KA->adam_step[0] = ES.step; KA->adam_pows[0] = ES.b1t; KA->adam_pows[1] = ES.b2t;
+      if (A0.stats) { A0.stats[0] = num; A0.stats[1] = den; A0.stats[2] = nrm; A0.stats[3] = o; }
+      if (A0.losses) { const float a = -(num / den); A0.losses[0] = a; A0.losses[1] = o; A0.losses[2] = a + o; }
+    }
+  }
+}
+
 __global__ void k_scn_losses(const float* __restrict__ stats, float* __restrict__ losses, int G) {
   scn_losses_wave(stats, losses, G);
 }
@@ -1605,9 +1733,8 @@ int hscn_scn_resident_bwd(const float* x, const int64_t* edge_index, int64_t E, 
 // A whole run of the reference's stage-A loop (train/train_clustering.py:34-50) from ONE call: `visits` graph visits
 // in dataset order, each the one-launch step of ONE graph with the optimizer in its tail and the cached structure
 // (hscn_scn_resident_train_step(B = 1, opt, cache) on graph v mod G of a dataset laid out as one batch), issued
-// back to back by this host loop -- no Python between two visits.  (The same chain as ONE launch of one persistent
-// workgroup -- weights in LDS, moments in registers -- was built and measured: 19.1 us per visit against 12.7 for the
-// launches below; the visit loop around the phases drove the kernel to 145 scalar / 130 vector register spills.)
+// back to back by this host loop -- no Python between two visits -- or, when the model has at most 1024 parameters,
+// walked by ONE persistent workgroup (k_scn_epoch: weights in LDS, Adam moments in registers).
 static int scn_epoch_impl(int f16, const float* x, const int32_t* nptr, const int32_t* eptr, int64_t N, int64_t G,
                           int64_t visits, int F, int H, int K, int act, float* W_rel, float* b_rel, float* W_root,
                           float* W_mlp, float* b_mlp, const float* g_mc, const float* g_o, int max_n, int max_e,
@@ -1637,6 +1764,31 @@ static int scn_epoch_impl(int f16, const float* x, const int32_t* nptr, const in
   A.adam_lr = opt->lr; A.adam_b1 = opt->beta1; A.adam_b2 = opt->beta2; A.adam_eps = opt->eps;
   A.adam_wd = opt->weight_decay; A.adam_decoupled = opt->decoupled;
   hipStream_t st = hscn_stream(stream_);
+  // the chain as launches of ONE persistent workgroup (k_scn_epoch; P <= 1024: a thread per parameter element), in
+  // slices of 32 768 visits (~0.5 s) so that no launch runs long enough to look hung; HSCN_PERSISTENT_EPOCH=0 keeps the
+  // launch per visit below (the same arithmetic, bit for bit)
+  const char* pe = getenv("HSCN_PERSISTENT_EPOCH");
+  if (A.P <= SRT && !(pe && pe[0] == '0')) {
+    A.nptr = nptr; A.eptr = eptr; A.ex_rowptr_d = cache->rowptr_d; A.ex_rowptr_s = cache->rowptr_s;
+    A.B = (int)G;
+    const size_t lds = scn_layout(H, K, max_n, max_e, 2).total * 4;
+#define HSCN_EPOCH(H_, TS_)                                                                                    \
+  do {                                                                                                         \
+    if (lds > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute((const void*)k_scn_epoch<H_, TS_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                     \
+    k_scn_epoch<H_, TS_><<<1, SRT, lds, st>>>(A);                                                              \
+  } while (0)
+    for (int64_t v0 = 0; v0 < visits; v0 += 32768) {
+      A.visit0 = v0;
+      A.visits = visits - v0 < 32768 ? visits - v0 : 32768;
+      if (f16) { if (H == 16) HSCN_EPOCH(16, half_t); else HSCN_EPOCH(32, half_t); }
+      else { if (H == 16) HSCN_EPOCH(16, float); else HSCN_EPOCH(32, float); }
+      HSCN_RETURN_IF_LAUNCH_FAILED();
+    }
+#undef HSCN_EPOCH
+    return 0;
+  }
   for (int64_t v = 0; v < visits; ++v) {
     const int64_t g = v % G;
     // the kernel sees a batch of one graph whose ranges are entries g, g + 1 of the dataset's; the dataset-level

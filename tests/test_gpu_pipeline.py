@@ -262,10 +262,11 @@ def test_stage_a_driver_follows_the_reference_trajectory(optim):
 
 
 @pytest.mark.parametrize("kind", ["adam", "adamW"])
-def test_stage_a_epoch_kernel_is_the_per_visit_loop_bit_for_bit(kind):
+def test_stage_a_epoch_kernel_is_the_per_visit_loop_bit_for_bit(kind, monkeypatch):
     """The reference's stage-A loop from ONE call (hscn_scn_resident_train_epoch: the dataset as one batch in HBM, its
-    structure built by one forward launch, the visits issued back to back by the library, the assignment pass one
-    more launch) against the same loop issued visit by visit from Python (ScnTrainStep.run(opt=...) on per-graph
+    structure built by one forward launch, the visits walked by one persistent workgroup -- or issued back to back
+    by the library, HSCN_PERSISTENT_EPOCH=0 --, the assignment pass one more launch) against the same loop issued
+    visit by visit from Python (ScnTrainStep.run(opt=...) on per-graph
     objects): identical parameters and cluster ids after 3 epochs over 24 graphs of very different sizes."""
     import numpy as np
     from graph_hscn.config.config import HSCNConfig, OptimConfig, TrainingConfig
@@ -283,10 +284,13 @@ def test_stage_a_epoch_kernel_is_the_per_visit_loop_bit_for_bit(kind):
         ids = train_clustering(None, graphs, scn, mc, oc, tc, batch_graphs=1, epoch_kernel=epoch_kernel)
         return [p.detach().clone() for p in scn.parameters()], ids
 
-    pa, ia = run(True)
-    pb, ib = run(False)
-    for x, y in zip(pa, pb):
-        assert torch.equal(x, y), float((x - y).abs().max())
-    assert len(ia) == len(ib) == 24
-    for x, y in zip(ia, ib):
-        assert np.array_equal(x, y)
+    pa, ia = run(True)                       # the chain walked by one persistent workgroup (k_scn_epoch)
+    pb, ib = run(False)                      # per-graph Python objects, one launch per visit
+    monkeypatch.setenv("HSCN_PERSISTENT_EPOCH", "0")
+    pc, ic = run(True)                       # the library's loop of per-visit launches
+    for other_p, other_i in ((pb, ib), (pc, ic)):
+        for x, y in zip(pa, other_p):
+            assert torch.equal(x, y), float((x - y).abs().max())
+        assert len(ia) == len(other_i) == 24
+        for x, y in zip(ia, other_i):
+            assert np.array_equal(x, y)

@@ -7,7 +7,8 @@ the issue forms the driver has had:
   one launch + flat   the one-launch step, optim.FlatAdam as a launch of its own
   fused               the optimizer in the step's tail (one launch per visit), structure rebuilt every visit
   fused + cache       ... and the graph's CSRs / out-degrees / A_hat x loaded from HBM (per-graph Python objects)
-  one call            hscn_scn_resident_train_epoch: the same launches issued by the library (what train_clustering does)
+  one call            hscn_scn_resident_train_epoch (what train_clustering does): the chain walked by one persistent
+                      workgroup; HSCN_PERSISTENT_EPOCH=0: the same launches issued by the library
 """
 import json
 import os
