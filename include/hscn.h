@@ -639,10 +639,12 @@ int hscn_scn_resident_train_step(const float* x, const int64_t* edge_index, int6
  * of a dataset laid out as one block-diagonal batch: nptr / eptr [G+1]), each the launch of
  * hscn_scn_resident_train_step(B = 1, opt, cache) on that graph -- walked by ONE persistent workgroup with the weights
  * in LDS and the Adam moments in registers when the model has at most 1024 parameters (slices of 32 768 visits per
- * launch), else issued launch by launch by the library; no host language between two visits either way.  cache: REQUIRED and ready -- the structure of ALL G graphs in the batch layout (one
+ * launch), else issued launch by launch by the library; no host language between two visits either way.
+ * cache: REQUIRED and ready -- the structure of ALL G graphs in the batch layout (one
  * hscn_scn_resident_fwd launch over the dataset with its ex_* outputs builds it); opt: REQUIRED; W_rel .. b_mlp and
  * opt's state are updated in place by every visit; g_mc / g_o: the upstream gradients of the two losses (device
- * scalars; the loop's loss mincut + ortho has both = 1); grads [P], stats [4], losses [3]: the last visit's; ticket:
+ * scalars; the loop's loss mincut + ortho has both = 1, which is what the persistent workgroup assumes); grads [P],
+ * stats [4], losses [3]: the last visit's; ticket:
  * a zeroed device int32.  hscn_scn_resident_train_step_supported says whether the shapes qualify. */
 int hscn_scn_resident_train_epoch(const float* x, const int32_t* nptr, const int32_t* eptr, int64_t N, int64_t G,
                                   int64_t visits, int F, int H, int K, int act, float* W_rel, float* b_rel,
