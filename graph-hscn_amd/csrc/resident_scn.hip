@@ -45,6 +45,7 @@ struct ScnArgs {
   float* ex_xpad;           // [N,FP] or NULL: the features padded to FP columns as LDS holds them (float4 loads in the cached front)
   int pre;                  // one-launch step: the ex_* arrays hold this batch's structure already (loaded, not built)
   long long visits, visit0; // k_scn_epoch: graph visits of the launch, number of the first one
+  int G;                    // k_scn_epoch: graphs of the dataset (B = 1: a visit is a batch of one)
   // forward only: losses [3] = {mean mincut, mean ortho, their sum}; with a ticket counter (zero before
   // the first launch, left at zero) the workgroup that finishes last reduces the per-graph statistics
   float* losses;
@@ -1039,6 +1040,7 @@ __device__ __forceinline__ void scn_bwd_tail(const ScnArgs& A, int n0, int n, fl
 struct ScnEpochState {
   float m, v, step;
   double b1t, b2t;
+  float gmc, go;   // the upstream gradients, read once for the whole chain
 };
 template <int H, typename TS, int NTC>
 __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const float* Sl, const float* yl, float* DL,
@@ -1050,8 +1052,8 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
   const int K = A.K, NT = (K + 15) >> 4;
   const int wave = wave_id(), lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
   const int ntile = (n + 15) >> 4;
-  // (the epoch kernel: loss = mincut + ortho of ONE graph, train_clustering.py:48 -- both upstream gradients are 1)
-  const float gmc = ES ? 1.0f : (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B, go = ES ? 1.0f : (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
+  const float gmc = ES ? ES->gmc : (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B;
+  const float go = ES ? ES->go : (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
   const float c_num = -gmc / den, c_den = gmc * num / (den * den);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 gWm[NTC][TD], gWr[TD], gWo[TD];
@@ -1458,6 +1460,8 @@ __global__ void __launch_bounds__(SRT) k_scn_epoch(const ScnArgs A0) {
     ES.step = KA->adam_step[0];
     ES.b1t = KA->adam_pows[0];
     ES.b2t = KA->adam_pows[1];
+    ES.gmc = A0.g_mc ? A0.g_mc[0] : 0.f;   // (B = 1: no division)
+    ES.go = A0.g_o ? A0.g_o[0] : 0.f;
   }
   float num = 0.f, den = 1.f, nrm = 0.f, o = 0.f;
   bool have_w = false;
@@ -1483,7 +1487,7 @@ __global__ void __launch_bounds__(SRT) k_scn_epoch(const ScnArgs A0) {
     float* ssl = fb + Y.ssl;
     int *rowptr_d = ib + Y.rowptr_d, *col_d = ib + Y.col_d, *rowptr_s = ib + Y.rowptr_s, *col_s = ib + Y.col_s;
     const int wave = wave_id();
-    const int g = (int)(v % A.B);
+    const int g = (int)(v % A.G);
     const int n0 = A.nptr[g], n = A.nptr[g + 1] - n0;
     const int e0 = A.eptr[g], ne = A.eptr[g + 1] - e0;
     if (n > A.max_n || ne > A.max_e || n < 1 || ne < 0) {   // (uniform) skipped: no step for this graph
@@ -1770,7 +1774,7 @@ static int scn_epoch_impl(int f16, const float* x, const int32_t* nptr, const in
   const char* pe = getenv("HSCN_PERSISTENT_EPOCH");
   if (A.P <= SRT && !(pe && pe[0] == '0')) {
     A.nptr = nptr; A.eptr = eptr; A.ex_rowptr_d = cache->rowptr_d; A.ex_rowptr_s = cache->rowptr_s;
-    A.B = (int)G;
+    A.G = (int)G;
     const size_t lds = scn_layout(H, K, max_n, max_e, 2).total * 4;
 #define HSCN_EPOCH(H_, TS_)                                                                                    \
   do {                                                                                                         \

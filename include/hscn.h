@@ -643,8 +643,7 @@ int hscn_scn_resident_train_step(const float* x, const int64_t* edge_index, int6
  * cache: REQUIRED and ready -- the structure of ALL G graphs in the batch layout (one
  * hscn_scn_resident_fwd launch over the dataset with its ex_* outputs builds it); opt: REQUIRED; W_rel .. b_mlp and
  * opt's state are updated in place by every visit; g_mc / g_o: the upstream gradients of the two losses (device
- * scalars; the loop's loss mincut + ortho has both = 1, which is what the persistent workgroup assumes); grads [P],
- * stats [4], losses [3]: the last visit's; ticket:
+ * scalars; the loop's loss mincut + ortho has both = 1); grads [P], stats [4], losses [3]: the last visit's; ticket:
  * a zeroed device int32.  hscn_scn_resident_train_step_supported says whether the shapes qualify. */
 int hscn_scn_resident_train_epoch(const float* x, const int32_t* nptr, const int32_t* eptr, int64_t N, int64_t G,
                                   int64_t visits, int F, int H, int K, int act, float* W_rel, float* b_rel,
