@@ -261,8 +261,10 @@ def test_stage_a_driver_follows_the_reference_trajectory(optim):
     print(f"stage-A trajectory ({optim}): ids equal on all {sure_nodes} nodes with margin > 1e-5; flips on nearer ties: {flips}")
 
 
-@pytest.mark.parametrize("kind", ["adam", "adamW"])
-def test_stage_a_epoch_kernel_is_the_per_visit_loop_bit_for_bit(kind, monkeypatch):
+@pytest.mark.parametrize("kind,name,K,act", [("adam", "peptides_func", 16, "elu"), ("adamW", "peptides_func", 16, "elu"),
+                                             ("adam", "pcqm_contact", 8, "tanh"), ("adamW", "peptides_func", 32, "relu"),
+                                             ("adam", "peptides_struct", 4, "elu")])
+def test_stage_a_epoch_kernel_is_the_per_visit_loop_bit_for_bit(kind, name, K, act, monkeypatch):
     """The reference's stage-A loop from ONE call (hscn_scn_resident_train_epoch: the dataset as one batch in HBM, its
     structure built by one forward launch, the visits walked by one persistent workgroup -- or issued back to back
     by the library, HSCN_PERSISTENT_EPOCH=0 --, the assignment pass one more launch) against the same loop issued
@@ -273,15 +275,16 @@ def test_stage_a_epoch_kernel_is_the_per_visit_loop_bit_for_bit(kind, monkeypatc
     from graph_hscn.loader.synthetic import make_dataset
     from graph_hscn.model.hscn import SCN
     from graph_hscn.train.train_clustering import train_clustering
-    graphs = make_dataset("peptides_func", 24, seed=13)
-    mc = HSCNConfig("relu", num_clusters=16, cluster_epochs=3)
+    graphs = make_dataset(name, 24, seed=13)
+    mc = HSCNConfig("relu", num_clusters=K, cluster_epochs=3)
     oc = OptimConfig(kind, lr=0.01, weight_decay=0.01 if kind == "adamW" else 0.0)
     tc = TrainingConfig("hscn", "cross_entropy", "ap")
 
     def run(epoch_kernel):
         torch.manual_seed(5)
-        scn = SCN([16], "elu", 9, 16).to("cuda")
+        scn = SCN([16], act, graphs[0].x.size(1), K).to("cuda")
         ids = train_clustering(None, graphs, scn, mc, oc, tc, batch_graphs=1, epoch_kernel=epoch_kernel)
+        assert scn.last_engine == "resident"
         return [p.detach().clone() for p in scn.parameters()], ids
 
     pa, ia = run(True)                       # the chain walked by one persistent workgroup (k_scn_epoch)
