@@ -8,7 +8,7 @@ the issue forms the driver has had:
   fused               the optimizer in the step's tail (one launch per visit), structure rebuilt every visit
   fused + cache       ... and the graph's CSRs / out-degrees / A_hat x loaded from HBM (per-graph Python objects)
   one call            hscn_scn_resident_train_epoch (what train_clustering does): the chain walked by one persistent
-                      workgroup; HSCN_PERSISTENT_EPOCH=0: the same launches issued by the library
+                      workgroup; "launch per visit": HSCN_PERSISTENT_EPOCH=0, the per-visit launches issued by the library
 """
 import json
 import os
@@ -90,6 +90,9 @@ def main(G=1024, K=16):
     scn = SCN([16], "elu", 9, K).to(dev)
     r = ScnEpochRunner(scn, big.to(dev), "adam", 0.01, 0.0)
     out["one call"] = timed(lambda: r.run(G), G)
+    os.environ["HSCN_PERSISTENT_EPOCH"] = "0"          # (read by the library at every call)
+    out["one call, launch per visit"] = timed(lambda: r.run(G), G)
+    del os.environ["HSCN_PERSISTENT_EPOCH"]
     # the same pass captured once as a hipGraph of G kernel nodes and replayed (what ScnEpochRunner.run does per epoch)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
