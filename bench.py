@@ -16,6 +16,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with the
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -36,6 +39,11 @@ WORKLOADS = {
     "pcqm_contact": ("pcqm_contact", 256, 16, 1, "l1"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HSCN_BENCH_REHEARSAL=1: let N ranks SHARE fewer GPUs (rank r on device r % count), process group on gloo, gradients
+# through the one-shot all-reduce (RCCL refuses two ranks on one device).  It exists to run the N-rank code path --
+# self-launch, shard seeds, exchange, strong-scaling leg, A/B child -- on a one-GPU box; its line says so and its
+# numbers are NOT a scaling measurement.
+REHEARSAL = os.environ.get("HSCN_BENCH_REHEARSAL") == "1"
 
 
 def parse():
@@ -78,6 +86,16 @@ def parse():
                     help="--stage a: sparse = fused graph-resident launches on the edge list; dense = to_dense_adj + "
                          "dense_mincut_pool on the matrix cores (BASELINE.json configs[3]: PascalVOC-SP, 64 clusters; "
                          "equally sized graphs, n = 479)")
+    ap.add_argument("--allreduce", default=os.environ.get("HSCN_ALLREDUCE", "rccl"), choices=["rccl", "oneshot"],
+                    help="gradient exchange of an N-rank run: rccl = one captured RCCL all-reduce of the flat buffer; oneshot = "
+                         "hscn_allreduce_oneshot (one launch over hipIpc-mapped peer memory, one xGMI hop).  The N-rank "
+                         "line of the default choice carries the other one's time as `allreduce_ab`, measured by a child job")
+    ap.add_argument("--no-allreduce-ab", action="store_true", help="N > 1: skip the child job that times the other all-reduce")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1: skip the strong-scaling reference (rank 0 alone on the whole global batch)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="after the reported timed region (`value` = that FIRST region), time the same --steps steps this many "
+                         "more times and report the spread (`repeats`): a 20-step region is 0.6 ms, one scheduling hiccup moves it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming-spmm", action="store_true")
     ap.add_argument("--no-stage-a", action="store_true")
@@ -487,32 +505,97 @@ def stage_a_main(args):
     print(json.dumps(out))
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, timeout=None):
+    """Start ``bench.py`` as n ranks (one per GPU) with torch.distributed.run as a CHILD job and return
+    (return code, rank 0's JSON line or None, tail of its other output).  Called before this process has touched
+    the GPU, or from a process that keeps running -- never an exec (a process that has initialised the GPU must not
+    be replaced)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+              "TORCHELASTIC_RUN_ID", "HSCN_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    try:
+        pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        return 124, None, f"timed out after {timeout} s: {(e.stdout or b'')[-400:].decode(errors='replace')}"
+    line, rest = None, []
+    for ln in pr.stdout.decode(errors="replace").splitlines():
+        try:
+            doc = json.loads(ln)
+            if isinstance(doc, dict) and "metric" in doc:
+                line = doc
+                continue
+        except ValueError:
+            pass
+        rest.append(ln)
+    return pr.returncode, line, "\n".join(rest[-5:])
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` with no launcher around it: become the launcher.  Nothing here initialises the
+    GPU (``device_count`` does not), the ranks are fresh child processes, and the one line relayed is rank 0's."""
+    have = torch.cuda.device_count()
+    if have < args.gpus and not (REHEARSAL and have >= 1):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s); refusing to report a {args.gpus}-GPU "
+                         f"line from fewer devices")
+    rc, line, rest = launch_ranks(args.gpus, sys.argv[1:])
+    if rest:
+        print(rest, file=sys.stderr)
+    if rc != 0 or line is None:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the {args.gpus}-rank job failed (exit code {rc})")
+    if line.get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the job reported n_gpus = {line.get('n_gpus')}")
+    print(json.dumps(line))
+
+
 def main():
     args = parse()
     if args.stage == "a":
         return stage_a_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # a line whose n_gpus differs from what was asked for is worse than no line
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    force_dist = os.environ.get("HSCN_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with a single rank
+    shared_gpus = REHEARSAL and world > torch.cuda.device_count()
+    if world > torch.cuda.device_count() and not shared_gpus:
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    force_dist = os.environ.get("HSCN_BENCH_FORCE_DIST") == "1"   # exercise the collective path with a single rank
+    cdev = dev                                                     # where the process group's own tensors live
     if world > 1 or force_dist:
         if force_dist and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-        with _StdoutToStderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            dist.all_reduce(torch.zeros(1, device=dev))          # creates the communicator (and prints the banner) now
-            torch.cuda.synchronize()
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        if shared_gpus:
+            if args.allreduce != "oneshot":
+                raise SystemExit("HSCN_BENCH_REHEARSAL with ranks sharing a GPU needs --allreduce oneshot (RCCL refuses)")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            cdev = torch.device("cpu")
+        else:
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.all_reduce(torch.zeros(1, device=dev))      # creates the communicator (and prints the banner) now
+                torch.cuda.synchronize()
     from graph_hscn import _hip
     from graph_hscn.config.config import ACT_DICT
     from graph_hscn.distributed import FlatGradReducer
@@ -530,7 +613,7 @@ def main():
     model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], F, args.hidden, C, args.layers).to(dev)
     model.engine = args.engine
     # every rank owns B graphs: equal weights, RCCL averages with no scaling launch
-    reducer = (FlatGradReducer(model, single_rank_collective=force_dist, equal_weights=True)
+    reducer = (FlatGradReducer(model, single_rank_collective=force_dist, equal_weights=True, algorithm=args.allreduce)
                if (world > 1 or force_dist) else None)
 
     def barrier():
@@ -541,7 +624,7 @@ def main():
     ts = TimedStep(args, model, hb, loss_fn, reducer, B, world)
     dt = time_steps(ts, args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
@@ -549,6 +632,47 @@ def main():
     spg = ts.spg
     if ts.fused is not None:
         ts.fused.check()
+    if reducer is not None:
+        reducer.check()          # a timed-out one-shot exchange would have left gradients unreduced
+
+    # ---- spread: the same timed region again (exactly --steps steps each, max over ranks); `value` stays the first
+    repeats = None
+    if args.repeats > 0:
+        reps = []
+        for _ in range(args.repeats):
+            d = time_steps(ts, args.steps, 0, barrier)
+            if world > 1:
+                t = torch.tensor([d], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            reps.append(1e3 * d / args.steps)
+        allr = [ms] + reps
+        repeats = {"k": args.repeats, "ms_per_step": [round(r, 6) for r in reps],
+                   "median_ms_per_step_incl_first": statistics.median(allr), "min_ms_per_step": min(allr),
+                   "max_ms_per_step": max(allr),
+                   "median_graphs_per_s": B * world / (statistics.median(allr) * 1e-3),
+                   "note": "`value` / `ms_per_step` are the FIRST timed region; these are further regions of the same length"}
+
+    # ---- strong scaling (N > 1): the weak line above runs B graphs per GPU, i.e. a global batch of B * N; the same
+    # global batch on ONE GPU is measured here by rank 0 alone (the other ranks wait at the barrier), so the line can
+    # be read either way: weak (value vs the 1-GPU line's value) or strong (one_gpu_ms_per_step / ms_per_step)
+    strong = None
+    if world > 1 and not args.no_strong:
+        if rank == 0:
+            hbS = build_hetero_batch(shape, B * world, K, args.seed * 1000, dev, args.cluster_ids)[0].to(dev)
+            if args.dtype == "f16":
+                hbS = hbS.with_feature_dtype(torch.float16)
+            tsS = TimedStep(args, model, hbS, loss_fn, None, B * world, 1)
+            local_barrier = torch.cuda.synchronize
+            dS = time_steps(tsS, args.steps, args.warmup, local_barrier, settle_s=0.05)
+            dS = min(dS, time_steps(tsS, args.steps, 0, local_barrier))
+            t1 = 1e3 * dS / args.steps
+            strong = {"global_batch": B * world, "one_gpu_ms_per_step": t1, "one_gpu_graphs_per_s": B * world / (t1 * 1e-3),
+                      "n_gpu_ms_per_step": ms, "n_gpus": world, "speedup_vs_one_gpu_same_global_batch": t1 / ms,
+                      "note": "strong reading of the same run: global batch fixed at graphs_per_gpu * n_gpus; the one-GPU "
+                              "time is rank 0 alone on all of it (its best form for that batch size), measured in this job"}
+            del tsS, hbS
+        barrier()
 
     # ---- the same measurement with ONE step per hipGraph replay (what round 1 reported): the difference is the host's
     # replay overhead per graph launch, not kernel time
@@ -779,13 +903,41 @@ def main():
                                      ("captured in the step's hipGraph" if ts.in_graph_allreduce else "eager, after each replay")),
                        "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "one_step_per_graph": single, "other_cluster_ids": other_ids,
-            "streaming_spmm_scaled": streaming, "stage_a": stage_a,
+            "streaming_spmm_scaled": streaming, "stage_a": stage_a, "repeats": repeats,
         }
+        out["config"]["allreduce_algorithm"] = None if reducer is None else args.allreduce
+        if shared_gpus:
+            out["rehearsal"] = (f"{world} ranks SHARE {torch.cuda.device_count()} GPU(s) (HSCN_BENCH_REHEARSAL=1): this line "
+                                f"exercises the N-rank code path and is NOT a scaling measurement")
+        if strong is not None:
+            out["strong_scaling"] = strong
         if cpu:
             out["vs_cpu_baseline"] = value / cpu["value"]
-        print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # ---- A/B of the exchange (N > 1): the OTHER all-reduce algorithm in a child job of its own, started after this
+        # job's ranks have left the GPUs -- a failure there (it has never met real xGMI before this run) costs its
+        # own entry, not this line
+        if world > 1 and not args.no_allreduce_ab and "HSCN_BENCH_AB_CHILD" not in os.environ:
+            other = "oneshot" if (args.allreduce == "rccl" or shared_gpus) else "rccl"
+            os.environ["HSCN_BENCH_AB_CHILD"] = "1"
+            argv = ["--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup), "--allreduce", other,
+                    "--workload", args.workload, "--hidden", str(args.hidden), "--layers", str(args.layers),
+                    "--cluster-ids", args.cluster_ids, "--dtype", args.dtype, "--structure", args.structure,
+                    "--steps-per-graph", str(args.steps_per_graph), "--seed", str(args.seed),
+                    "--no-cpu-baseline", "--no-streaming-spmm", "--no-stage-a", "--no-other-ids", "--no-strong",
+                    "--no-allreduce-ab"] + (["--batch", str(args.batch)] if args.batch else [])
+            t0 = time.perf_counter()
+            rc, line, rest = launch_ranks(world, argv, timeout=240)
+            ab = {"algorithm": other, "exit_code": rc, "wall_s": round(time.perf_counter() - t0, 1)}
+            if rc == 0 and line is not None:
+                ab.update({"ms_per_step": line["ms_per_step"], "graphs_per_s": line["value"],
+                           "repeats": line.get("repeats"), "vs_this_line": line["value"] / value})
+            else:
+                ab["error"] = rest[-600:]
+            out["allreduce_ab"] = ab
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

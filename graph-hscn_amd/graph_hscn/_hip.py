@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -89,6 +89,15 @@ _SIGNATURES = {
     "hscn_resident_structure": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, P, P, c_int64, c_int, c_int, c_int,
                                         c_int, P, P, P]),
     "hscn_collate_gather_structure": (c_int, [P, P, P, c_int64, P, P, P, P, P, P]),
+    "hscn_comm_alloc": (c_int, [c_size_t, c_int, P]),
+    "hscn_comm_free": (c_int, [P]),
+    "hscn_comm_ipc_export": (c_int, [P, P]),
+    "hscn_comm_ipc_open": (c_int, [P, P]),
+    "hscn_comm_ipc_close": (c_int, [P]),
+    "hscn_allreduce_oneshot_slot_bytes": (c_size_t, [c_int64, c_int]),
+    "hscn_allreduce_oneshot_flag_bytes": (c_size_t, [c_int64, c_int]),
+    "hscn_allreduce_oneshot_chunks": (c_int64, [c_int64]),
+    "hscn_allreduce_oneshot": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, c_float, ctypes.c_uint32, P]),
 }
 # IEEE-half storage twins (include/hscn.h: hscn_resident_*_f16): same argument lists
 for _n in ("hscn_resident_fwd", "hscn_resident_bwd", "hscn_resident_fwd_with_virtual", "hscn_resident_bwd_with_virtual",

@@ -10,6 +10,8 @@ of ONE contiguous buffer instead of one collective per parameter.
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -47,6 +49,121 @@ def shard_list(items: Sequence, sizes: Sequence[int], rank: int, world_size: int
     return list(items[b[rank]: b[rank + 1]])
 
 
+class OneShotAllReduce:
+    """``flat <- scale * sum_r flat_r`` in ONE launch over peer-mapped memory (``hscn_allreduce_oneshot``,
+    csrc/allreduce.hip): every rank stores its buffer into its slot on every rank, raises a per-source epoch flag,
+    waits (bounded) for its own G flags and adds the G slots in rank order -- one xGMI hop instead of a ring's
+    2(G-1), the same summation order on every rank.  The exchange point is between ``loss.backward()`` and
+    ``optimizer.step()`` (reference train/train.py:87-94).
+
+    Construction is collective (every rank of ``group`` must call it with the same ``count``): allocate fine-grained
+    slot / flag memory, exchange hipIpc handles with ``all_gather_object``, map the peers'.  ``__call__`` only
+    launches (capturable into a hipGraph); ``check()`` reads the status words and raises on a timed-out wait."""
+
+    def __init__(self, count: int, device: torch.device, group: Optional[dist.ProcessGroup] = None,
+                 spin_limit: int = 0, rank: Optional[int] = None, world: Optional[int] = None, connect: bool = True):
+        """``connect=False`` stops after the local half (allocation + export): the caller exchanges ``local_info``
+        itself and calls ``connect(infos)`` -- how a test wires two ranks that share one GPU without a NCCL
+        communicator.  Peers that live in THIS process are addressed by pointer (an IPC handle cannot be opened by
+        the process that exported it)."""
+        from . import _hip
+        self._hip = _hip
+        L = _hip.lib()
+        self.count = int(count)
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        self.G = dist.get_world_size(group) if world is None else int(world)
+        if not 1 <= self.G <= 8:
+            raise ValueError("hscn_allreduce_oneshot serves 1..8 ranks (one node)")
+        self.device = device
+        self.group = group
+        self.spin_limit = int(spin_limit)
+        self._mapped: List[int] = []
+        self._slots = self._flags = None
+        sb = L.hscn_allreduce_oneshot_slot_bytes(self.count, self.G)
+        fb = L.hscn_allreduce_oneshot_flag_bytes(self.count, self.G)
+        if sb == 0:
+            raise ValueError("bad count / world size for hscn_allreduce_oneshot")
+        with torch.cuda.device(device):
+            # one allocation (slots first, flags behind them at a 256-byte boundary): one handle to exchange.
+            # Fine-grained memory is what system-scope release/acquire inside a running kernel is specified for;
+            # the other kinds are tried only if the runtime refuses to allocate or export it.
+            self._flag_off = (sb + 255) & ~255
+            total = self._flag_off + fb
+            self._own, handle, self.kind = None, b"", None
+            want = os.environ.get("HSCN_COMM_MEMORY")
+            for kind in ([int(want)] if want is not None else [0, 1, 2]):
+                p = ctypes.c_void_p()
+                if L.hscn_comm_alloc(total, kind, ctypes.byref(p)) != 0:
+                    continue
+                h = ctypes.create_string_buffer(64)
+                if self.G == 1 or L.hscn_comm_ipc_export(p, h) == 0:
+                    self._own, handle, self.kind = p.value, bytes(h.raw), kind
+                    break
+                L.hscn_comm_free(p)
+            if self._own is None:
+                raise RuntimeError("hscn_comm_alloc / hipIpcGetMemHandle failed for every memory kind "
+                                   "(is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)")
+            nch = int(L.hscn_allreduce_oneshot_chunks(self.count))
+            self.epoch = torch.zeros(nch, dtype=torch.int32, device=device)
+            self.status = torch.zeros(2, dtype=torch.int32, device=device)
+        self.local_info = (self.rank, self.kind, handle, os.getpid(), self._own)
+        if connect:
+            infos = [self.local_info]
+            if self.G > 1:
+                infos = [None] * self.G
+                dist.all_gather_object(infos, self.local_info, group=group)
+            self.connect(infos)
+            if self.G > 1:
+                dist.barrier(group=group)          # nobody launches before every rank has mapped every peer
+
+    def connect(self, infos) -> None:
+        L = self._hip.lib()
+        infos = sorted(infos)
+        if [i[0] for i in infos] != list(range(self.G)) or any(i[1] != self.kind for i in infos):
+            raise RuntimeError("ranks disagree on the one-shot all-reduce set-up (rank set or memory kind)")
+        base = []
+        with torch.cuda.device(self.device):
+            for r, _, h, pid, addr in infos:
+                if r == self.rank:
+                    base.append(self._own)
+                elif pid == os.getpid():
+                    base.append(addr)
+                else:
+                    q = ctypes.c_void_p()
+                    self._hip.check(L.hscn_comm_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(q)),
+                                    "hscn_comm_ipc_open")
+                    self._mapped.append(q.value)
+                    base.append(q.value)
+        self._slots = (ctypes.c_void_p * self.G)(*base)
+        self._flags = (ctypes.c_void_p * self.G)(*[b + self._flag_off for b in base])
+
+    def __call__(self, flat: torch.Tensor, scale: float) -> None:
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.numel() != self.count:
+            raise ValueError("OneShotAllReduce: flat must be the contiguous float32 buffer it was built for")
+        if self._slots is None:
+            raise RuntimeError("OneShotAllReduce.connect() has not run")
+        h = self._hip
+        h.call("hscn_allreduce_oneshot", h.ptr(flat), self.count, self._slots, self._flags, h.ptr(self.epoch),
+               h.ptr(self.status), self.rank, self.G, float(scale), self.spin_limit, h.stream())
+
+    def check(self) -> None:
+        st = self.status.cpu()
+        if int(st[0]) != 0:
+            raise RuntimeError(f"hscn_allreduce_oneshot: rank {self.rank} timed out waiting for sources "
+                               f"{[q for q in range(self.G) if (int(st[1]) >> q) & 1]}; the gradients of that step "
+                               "were left unreduced")
+
+    def close(self) -> None:
+        L = self._hip.lib()
+        torch.cuda.synchronize(self.device)
+        for q in self._mapped:
+            L.hscn_comm_ipc_close(ctypes.c_void_p(q))
+        self._mapped = []
+        if self._own is not None:
+            L.hscn_comm_free(ctypes.c_void_p(self._own))
+            self._own = None
+
+
 class FlatGradReducer:
     """All-reduce every gradient of ``module`` as one flat fp32 buffer.
 
@@ -57,8 +174,16 @@ class FlatGradReducer:
     ``criterion`` is a mean over B x C elements (loss.py:9,16)."""
 
     def __init__(self, module: torch.nn.Module, process_group: Optional[dist.ProcessGroup] = None,
-                 single_rank_collective: bool = False, equal_weights: bool = False):
-        """``equal_weights``: the caller promises that EVERY rank passes the same ``local_weight`` in every
+                 single_rank_collective: bool = False, equal_weights: bool = False,
+                 algorithm: Optional[str] = None, oneshot_factory=None):
+        """``algorithm``: "rccl" (``dist.all_reduce``) or "oneshot" (``OneShotAllReduce``: one launch over
+        peer-mapped memory; gradients must tile one flat buffer, which the graph-resident steps guarantee).
+        Default: the environment's ``HSCN_ALLREDUCE`` or "rccl".  The choice is made here, from an argument /
+        environment that identical code sets identically on every rank, and verified collectively at the first
+        reduction.  ``oneshot_factory(count, device, group)`` builds the transport (tests inject a host emulation
+        of the slot protocol to drive this branch over gloo).
+
+        ``equal_weights``: the caller promises that EVERY rank passes the same ``local_weight`` in every
         call (equal shards: bench.py, fit_resident).  Only then may the reduction be RCCL's AVG with no scaling
         launch.  The choice must be the same on all ranks -- one collective issued as AVG by some ranks and
         as SUM by others is undefined behaviour -- so it is a constructor argument that identical code sets
@@ -68,6 +193,11 @@ class FlatGradReducer:
         self.group = process_group
         self.equal_weights = bool(equal_weights)
         self.always = single_rank_collective   # issue the collective even in a world of one (exercises the RCCL path)
+        self.algorithm = (algorithm or os.environ.get("HSCN_ALLREDUCE") or "rccl").lower()
+        if self.algorithm not in ("rccl", "oneshot"):
+            raise ValueError(f"unknown all-reduce algorithm {self.algorithm!r} (rccl | oneshot)")
+        self._oneshot_factory = oneshot_factory
+        self.oneshot = None
         self._flat: Optional[torch.Tensor] = None
         self._mask: Optional[List[bool]] = None
         self._fast = None      # (tuple of gradient data_ptrs, flat view): replayed steps reuse the same buffers
@@ -114,6 +244,21 @@ class FlatGradReducer:
         flat.set_(g0.untyped_storage(), spans[0][0], (end - spans[0][0],))
         return flat
 
+    def _agree_on_algorithm(self, flat: torch.Tensor) -> None:
+        """Every rank must take the one-shot branch with the same element count, or none may: checked once, with
+        the backend's own collective, before any peer memory is touched."""
+        if not (dist.is_initialized() and self.world_size > 1):
+            return
+        t = torch.tensor([flat.numel(), -flat.numel()], dtype=torch.int64, device=flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if int(t[0]) != flat.numel() or int(-t[1]) != flat.numel():
+            raise RuntimeError("ranks disagree on the flat gradient buffer handed to the one-shot all-reduce")
+
+    def check(self) -> None:
+        """Raise if a one-shot exchange timed out (reads two device words: call it once per epoch, not per step)."""
+        if self.oneshot is not None and hasattr(self.oneshot, "check"):
+            self.oneshot.check()
+
     @staticmethod
     def _check_equal(scale: float, ws: int) -> None:
         if abs(scale * ws - 1.0) > 1e-9:
@@ -129,7 +274,9 @@ class FlatGradReducer:
             if (sum(p.grad is not None for p in self.params) == len(key)
                     and all(p.grad is not None and p.grad.data_ptr() == k for p, k in zip(self._fast_params, key))):
                 scale = float(local_weight) / float(total_weight)
-                if self._fast_avg:
+                if self.oneshot is not None:
+                    self.oneshot(flat, scale)
+                elif self._fast_avg:
                     self._check_equal(scale, ws)
                     dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
                 else:
@@ -151,12 +298,31 @@ class FlatGradReducer:
             scale = float(local_weight) / float(w.item())
         flat = self._aliased_flat(grads)
         self.last_path = "aliased" if flat is not None else "packed"
+        if self.algorithm == "oneshot":
+            if flat is None:
+                raise RuntimeError("HSCN_ALLREDUCE=oneshot needs gradients that tile ONE flat buffer (the graph-resident "
+                                   "steps produce them: ResidentTrainStep.bind_grads)")
+            if self.oneshot is None:
+                self._agree_on_algorithm(flat)
+                make = self._oneshot_factory or (lambda n, dev, grp: OneShotAllReduce(n, dev, grp))
+                self.oneshot = make(flat.numel(), flat.device, self.group)
+            self.last_path = "oneshot"
         if flat is not None:
             self._fast_params = [p for p, m in zip(self.params, mask) if m]
             self._fast_avg = self.equal_weights and dist.get_backend(self.group) == "nccl"
             self._fast = (tuple(g.data_ptr() for g in grads), flat, ws)
             # one collective on the gradients where they already live
-            if self._fast_avg:
+            if self.oneshot is not None:
+                # a weighted mean needs no scaling launch either: the kernel multiplies the rank-ordered sum of the
+                # UNSCALED gradients once, which presumes equal weights; unequal shards pre-scale and sum
+                if self.equal_weights:
+                    self._check_equal(scale, ws)
+                    self.oneshot(flat, scale)
+                else:
+                    flat.mul_(scale)
+                    self.oneshot(flat, 1.0)
+                    self._fast = None          # (the fast path above passes `scale` to the kernel: equal weights only)
+            elif self._fast_avg:
                 self._check_equal(scale, ws)
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # equal shards: RCCL averages
             else:

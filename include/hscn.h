@@ -19,7 +19,8 @@
  *     negative HSCN_E_* for bad arguments; never throws;
  *   - node features are row-major fp32 [rows, width]; CSR indices are int32,
  *     COO inputs are int64 [2,E] as torch_geometric stores them;
- *   - stateless and re-entrant; no global handles;
+ *   - stateless and re-entrant; no global handles (the hscn_comm_* set-up helpers of the data-parallel exchange
+ *     are the one documented exception: they allocate / map peer memory, host-synchronously, once per job);
  *   - all reductions are ordered: results are bitwise reproducible run to run
  *     (no floating-point atomics anywhere).
  */
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 13
+#define HSCN_ABI_VERSION 14
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -707,6 +708,43 @@ int hscn_scn_resident_bwd_f16(const hscn_half* x, const int64_t* edge_index, int
 int hscn_adam_step(float* const* params_host, const int32_t* seg_off_host, int nseg, const float* grads,
                    float* exp_avg, float* exp_avg_sq, int64_t P, float* step_dev, double* beta_pows_dev,
                    const double* lr_dev, double beta1, double beta2, double eps, double weight_decay, int decoupled, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Data-parallel exchange: one-shot peer-to-peer all-reduce of the flat gradient buffer.
+ * The reference is single process; the exchange slots in between loss.backward() and
+ * optimizer.step() of the training iteration, reference graph_hscn/train/train.py:87-94.
+ * At 4.6 KB - 640 KB the collective is pure latency and the 8 GPUs of a node are one xGMI hop apart, so instead of
+ * a ring (2(G-1) dependent hops) every rank stores its buffer into slot `rank` of every rank's slot buffer, raises
+ * a per-source epoch flag there (system-scope release), waits for its own G flags (bounded spin), and adds its G
+ * slots in RANK ORDER: flat = scale * (slot_0 + slot_1 + ... + slot_{G-1}), separately rounded adds, the same order
+ * on every rank, so replicas stay bit-identical.  One launch; capturable (the epoch is device state advanced by the
+ * kernel).  Slots are double-buffered by epoch parity (csrc/allreduce.hip explains why two suffice).
+ *
+ * Set-up (host-synchronous, once per job; the only entry points that allocate):
+ *   hscn_comm_alloc      zero-filled device memory that peers may write while a kernel polls it.
+ *                        kind 0 = fine-grained (hipDeviceMallocFinegrained: what the memory model requires for
+ *                        system-scope synchronisation inside a kernel), 1 = uncached, 2 = plain hipMalloc.
+ *   hscn_comm_ipc_export / _open / _close   hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle on a
+ *                        64-byte handle (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0).
+ * Every rank allocates slot_bytes + flag_bytes, exports both, opens its peers', and passes the G mapped addresses
+ * (its own allocation at index `rank`) as HOST arrays; they travel in the kernel arguments.
+ *   epoch  [hscn_allreduce_oneshot_chunks(count)] uint32 local device words, zero before the first call;
+ *   status [2] uint32 local device words, zero: [0] bit 0 = a wait timed out (that chunk of `flat` is then left
+ *          unreduced), [1] = bit mask of the sources whose flag never arrived;
+ *   spin_limit: polls (each followed by a short sleep) before a wait gives up; 0 = default (~1 s).
+ * count <= 2 Mi floats (every workgroup of a launch must be resident at once).
+ * ------------------------------------------------------------------------- */
+int hscn_comm_alloc(size_t bytes, int kind, void** out_ptr_host);
+int hscn_comm_free(void* ptr);
+int hscn_comm_ipc_export(void* ptr, void* handle64_host);
+int hscn_comm_ipc_open(const void* handle64_host, void** out_ptr_host);
+int hscn_comm_ipc_close(void* ptr);
+size_t hscn_allreduce_oneshot_slot_bytes(int64_t count, int G);
+size_t hscn_allreduce_oneshot_flag_bytes(int64_t count, int G);
+int64_t hscn_allreduce_oneshot_chunks(int64_t count);
+int hscn_allreduce_oneshot(float* flat, int64_t count, void* const* peer_slots_host /*[G]*/,
+                           void* const* peer_flags_host /*[G]*/, uint32_t* epoch, uint32_t* status, int rank, int G,
+                           float scale, uint32_t spin_limit, void* stream);
 
 #ifdef __cplusplus
 }
