@@ -824,29 +824,45 @@ def main():
         streaming["peak_GBs"] = HBM_PEAK_GBS
 
     # HBM traffic from PMC passes: separate rocprofv3 runs of this script (the counters cannot be read from inside
-    # the process); the file records the commit it was collected at
+    # the process).  The newest profiles/rNN_pmc_traffic.json is used; it records the fingerprint of the kernel
+    # sources it was collected from, and the line says whether that is still the code that is running
     if rank == 0:
-        for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        import glob
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from fingerprint import csrc_fingerprint
+        now = csrc_fingerprint()
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            fname = os.path.basename(path)
             try:
-                doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                doc = json.load(open(path))
                 pmc = doc["kernels"]
             except (OSError, KeyError, ValueError):
                 continue
             default_shape = (args.workload == "peptides_func" and B == 128 and args.hidden == 16 and args.layers == 3
                              and args.cluster_ids == "scn_untrained")
+            stale = doc.get("_csrc_sha") != now
             if roofline and default_shape and roofline["traffic"] is None:
                 key = roofline["kernel"].split(" ")[0]      # exact kernel name
                 if key and key in pmc:
                     roofline["traffic"] = pmc[key]["traffic_bytes"]
                     roofline["frac_traffic"] = pmc[key]["traffic_bytes"] / (roofline["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    roofline["traffic_commit"] = doc.get("_commit", "unrecorded")
+                    roofline["traffic_csrc_sha"] = doc.get("_csrc_sha", "unrecorded")
+                    roofline["csrc_sha_now"] = now
+                    roofline["stale"] = bool(stale)
                     roofline["traffic_source"] = (f"profiles/{fname}: a SEPARATE rocprofv3 --pmc run of this command "
                                                   f"(FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction), "
-                                                  f"collected at commit {doc.get('_commit', 'unrecorded')}")
-                    roofline["rocprof_kernel_stats"] = ("profiles/r02_step_kernel_stats.csv (rocprofv3 --kernel-trace --stats "
-                                                        "of the default command): the C call timed here = k_hscn_step + "
-                                                        "k_param_reduce")
+                                                  f"collected at commit {doc.get('_commit', 'unrecorded')}"
+                                                  + ("; STALE: the kernel sources have changed since" if stale else
+                                                     "; the kernel sources are unchanged since"))
+                    roofline["rocprof_kernel_stats"] = (f"profiles/{fname.split('_')[0]}_step_kernel_stats.csv (rocprofv3 "
+                                                        "--kernel-trace --stats of the default command): the C call timed "
+                                                        "here = k_hscn_step + k_param_reduce")
             if streaming and "traffic" not in streaming and "k_spmm_scaled_H128" in pmc:
                 streaming["traffic"] = pmc["k_spmm_scaled_H128"]["traffic_bytes"]
+                streaming["traffic_stale"] = bool(stale)
+            if roofline is None or roofline.get("traffic") is not None:
+                break
 
     # ---- stage A (MinCUT coarsening: gcn_norm + SCN fwd + (mc+o) bwd) on the same graphs, fused engine,
     # one hipGraph replay per 128-graph step; reported beside the stage C headline

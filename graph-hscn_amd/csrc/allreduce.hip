@@ -16,9 +16,19 @@
 // epoch e + 2, every peer has raised e + 1, i.e. has finished reading the epoch-e data.  A flag may therefore read e
 // or e + 1 while a rank waits for e: the test is (int32)(flag - e) >= 0.
 //
+// Two forms of the same protocol, chosen by size:
+//   * granules (count <= AR_GRANULE_MAX, the headline's 1 146 floats): a slot element is ONE naturally aligned 8-byte
+//     word {float bits, epoch}, stored and polled with relaxed system-scope 64-bit atomics.  Value and tag travel in
+//     one single-copy-atomic object, so there is no flag, no release and no acquire fence: the reader spins on the
+//     element itself until its tag is the epoch.  One fabric round trip in all.
+//   * slabs + flags (larger buffers): 16-byte stores of plain floats, per-(source, chunk) epoch flags, one
+//     system-scope release on the writer and one acquire on the reader per workgroup (two L2 maintenance operations,
+//     ~1.7 us each: measured +4.7 us per step at one rank against +2.0 for the granule form's target).
+//
 // Memory: slots and flags are fine-grained device allocations (hscn_comm_alloc), the only kind for which the HSA
 // memory model promises system-scope release/acquire between agents inside a running kernel.
 #include "hscn_common.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -26,6 +36,7 @@ namespace {
 constexpr int AR_MAXG = 8;
 constexpr int AR_THREADS = 256;
 constexpr int AR_CHUNK = 2048;   // floats per workgroup (8 KB: two 16-byte pieces per lane and peer)
+constexpr int AR_GRANULE_MAX = 16384;   // counts up to this use the granule form (one element per thread)
 
 struct ArArgs {
   float* slots[AR_MAXG];      // slots[p]: rank p's slot buffer as mapped here: [2 parities][G sources][stride]
@@ -116,8 +127,67 @@ __global__ void __launch_bounds__(AR_THREADS) k_allreduce_oneshot(const ArArgs A
   if (t == 0) A.epoch[c] = e;
 }
 
+// Granule form: thread t of workgroup c owns element i = c * 256 + t.  It stores {value, e} into slot `rank` of every
+// rank, then polls its element in each of its own G slots until the tag reads e (all G loads in flight per round),
+// adds the G values in rank order, scales and writes back.  No LDS, no barrier except the one that keeps the epoch
+// word from being advanced before every thread has read it.
+__global__ void __launch_bounds__(AR_THREADS) k_allreduce_granules(const ArArgs A) {
+  typedef unsigned long long u64;
+  const int c = blockIdx.x, t = threadIdx.x;
+  const uint32_t e = A.epoch[c] + 1u;
+  const int64_t par = (int64_t)(e & 1u) * A.G;
+  const int64_t i = (int64_t)c * AR_THREADS + t;
+  if (i < A.count) {
+    const float mine = A.flat[i];
+    const u64 g = ((u64)e << 32) | (u64)__float_as_uint(mine);
+#pragma unroll
+    for (int p = 0; p < AR_MAXG; ++p)
+      if (p < A.G)
+        __hip_atomic_store(reinterpret_cast<u64*>(A.slots[p]) + (par + A.rank) * A.stride + i, g, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    const u64* base = reinterpret_cast<const u64*>(A.slots[A.rank]) + par * A.stride + i;
+    u64 v[AR_MAXG];
+    unsigned have = 0;
+    const unsigned want = (1u << A.G) - 1u;
+    uint32_t spins = 0;
+    while (true) {
+#pragma unroll
+      for (int q = 0; q < AR_MAXG; ++q)
+        if (q < A.G && !((have >> q) & 1u))
+          v[q] = __hip_atomic_load(base + (int64_t)q * A.stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int q = 0; q < AR_MAXG; ++q)
+        if (q < A.G && (uint32_t)(v[q] >> 32) == e) have |= 1u << q;
+      if (have == want) break;
+      if (++spins > A.spin_limit) {
+        atomicOr(A.status, 1u);
+        atomicOr(A.status + 1, want & ~have);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (have == want) {
+      float s = __uint_as_float((uint32_t)v[0]);
+#pragma unroll
+      for (int q = 1; q < AR_MAXG; ++q)
+        if (q < A.G) s = add_rn(s, __uint_as_float((uint32_t)v[q]));
+      A.flat[i] = mul_rn(s, A.scale);
+    }
+  }
+  __syncthreads();
+  if (t == 0) A.epoch[c] = e;
+}
+
+inline bool ar_granules(int64_t count) {
+  static const int forced = [] { const char* v = getenv("HSCN_ALLREDUCE_FORM"); return v ? (v[0] == 'g' ? 1 : (v[0] == 's' ? 2 : 0)) : 0; }();
+  if (forced == 1) return true;
+  if (forced == 2) return false;
+  return count <= AR_GRANULE_MAX;
+}
 inline int64_t ar_stride(int64_t count) { return (count + 3) & ~int64_t(3); }
-inline int ar_chunks(int64_t count) { return (int)((count + AR_CHUNK - 1) / AR_CHUNK); }
+inline int ar_chunks(int64_t count) {
+  return (int)(ar_granules(count) ? (count + AR_THREADS - 1) / AR_THREADS : (count + AR_CHUNK - 1) / AR_CHUNK);
+}
 
 }  // namespace
 
@@ -165,7 +235,7 @@ int hscn_comm_ipc_close(void* ptr) {
 
 size_t hscn_allreduce_oneshot_slot_bytes(int64_t count, int G) {
   if (count <= 0 || G < 1 || G > AR_MAXG) return 0;
-  return (size_t)2 * G * ar_stride(count) * sizeof(float);
+  return (size_t)2 * G * ar_stride(count) * (ar_granules(count) ? sizeof(uint64_t) : sizeof(float));
 }
 
 size_t hscn_allreduce_oneshot_flag_bytes(int64_t count, int G) {
@@ -192,7 +262,10 @@ int hscn_allreduce_oneshot(float* flat, int64_t count, void* const* peer_slots_h
   A.count = count; A.stride = ar_stride(count);
   A.scale = scale; A.rank = rank; A.G = G; A.nchunks = ar_chunks(count);
   A.spin_limit = spin_limit ? spin_limit : (1u << 21);
-  hipLaunchKernelGGL(k_allreduce_oneshot, dim3(A.nchunks), dim3(AR_THREADS), 0, hscn_stream(stream), A);
+  if (ar_granules(count))
+    hipLaunchKernelGGL(k_allreduce_granules, dim3(A.nchunks), dim3(AR_THREADS), 0, hscn_stream(stream), A);
+  else
+    hipLaunchKernelGGL(k_allreduce_oneshot, dim3(A.nchunks), dim3(AR_THREADS), 0, hscn_stream(stream), A);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -169,6 +169,30 @@ __device__ __forceinline__ float row_ror_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + OFF, 0xF, 0xF, true));
 }
 
+// the value lane K of each 16-lane DPP row holds, in every lane of that row (row_newbcast: gfx90a and later): a vector
+// element crosses lanes in ONE VALU operation -- no LDS round trip, no v_readlane -> SGPR -> VALU hazard slots
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xF, 0xF, true));
+}
+// acc = fmaf(x_k, w[k], acc) for k = 0 .. N-1 in ascending order, x_k = the value of lane k of this lane's DPP row:
+// one row of a small matrix-vector product whose vector lives one element per lane
+template <int N, int K = 0>
+__device__ __forceinline__ float row_dot(float x, const float (&w)[N], float acc) {
+  if constexpr (K < N) {
+    acc = fmaf(row_bcast<K>(x), w[K], acc);
+    return row_dot<N, K + 1>(x, w, acc);
+  } else {
+    return acc;
+  }
+}
+// x_0 + x_1 + ... + x_{N-1} added in that order (the lanes of this lane's DPP row)
+template <int N, int K = 0>
+__device__ __forceinline__ float row_seq_sum(float x, float acc) {
+  if constexpr (K < N) return row_seq_sum<N, K + 1>(x, acc + row_bcast<K>(x));
+  else return acc;
+}
+
 // inclusive scan over the 64 lanes of a fully active wave: Hillis-Steele inside the four DPP rows
 // (row_shr, zeros shifted in), then the three row totals through readlane.  VALU only.
 __device__ __forceinline__ int wave_incl_scan(int v) {
@@ -261,6 +285,78 @@ __device__ void build_csr_lds(const int* ek, const int* eo, int ne, int nrows, i
     col[s + rank] = eo[e];
   }
   lds_barrier();
+}
+
+// ---- BOTH stable CSRs of one edge list (keyed by ek: rowptr_a / col_a = eo; keyed by eo: rowptr_t / col_t = ek)
+// for rows of at most ELL_D edges, in TWO workgroup barriers (the pair of build_csr_lds calls takes four + four side
+// by side).  Phase 1: every edge draws a slot in its row of either table from a returning LDS atomic and leaves its
+// edge number there (the slot order is arbitrary, the final order is not).  Phase 2: a thread owns a row: it reads the
+// row's <= ELL_D edge numbers, ranks them against each other in registers and stores the columns in ascending edge
+// order; the row's offset comes from a prefix sum of the counts for which a wave re-adds the counts in front of its
+// slice (no barrier of its own).  cnt_a, cnt_t: [nrows + 1], ovf: [1], all ZERO on entry; ell_a, ell_t: [nrows * ELL_D].
+// dinv (optional) = in-degree^-1/2 of the rows keyed by ek.  Returns false -- for every thread alike -- when some row
+// holds more than ELL_D edges; nothing usable has been written then and the caller takes the general build.
+constexpr int ELL_D = 6;
+__device__ bool build_csr_pair_ell(const int* ek, const int* eo, int ne, int nrows, int* rowptr_a, int* col_a,
+                                   int* rowptr_t, int* col_t, float* dinv, int* cnt_a, int* ell_a, int* cnt_t,
+                                   int* ell_t, int* ovf, int RTn, int wave, int NWn) {
+  for (int e = threadIdx.x; e < ne; e += RTn) {
+    const int k = ek[e], o = eo[e];
+    if (k >= 0) {
+      const int pa = atomicAdd(&cnt_a[k], 1), pt = atomicAdd(&cnt_t[o], 1);
+      if (pa < ELL_D) ell_a[k * ELL_D + pa] = e; else ovf[0] = 1;
+      if (pt < ELL_D) ell_t[o * ELL_D + pt] = e; else ovf[0] = 1;
+    }
+  }
+  lds_barrier();
+  if (ovf[0] != 0) return false;
+  const int NA = NWn > 1 ? NWn / 2 : 1;
+  auto rows = [&](const int* cnt, const int* ell, const int* other, int* rowptr, int* col, float* dv, int gw, int gnw) {
+    const int lane = threadIdx.x & 63, gt = gw * 64 + lane, gnt = gnw * 64;
+    const int per = (nrows + gnt - 1) / gnt;
+    const int wb = gw * 64 * per;                          // first row of this wave's slice
+    int front = 0;
+    for (int j = lane; j < wb && j < nrows; j += 64) front += cnt[j];
+    front = __builtin_amdgcn_readlane(wave_incl_scan(front), 63);
+    const int b = gt * per;
+    int s = 0;
+    for (int i = 0; i < per; ++i)
+      if (b + i < nrows) s += cnt[b + i];
+    int run = front + wave_incl_scan(s) - s;
+    for (int i = 0; i < per; ++i) {
+      const int r = b + i;
+      if (r >= nrows) break;
+      const int c = cnt[r];
+      int ev[ELL_D];
+#pragma unroll
+      for (int j = 0; j < ELL_D; ++j) ev[j] = j < c ? ell[r * ELL_D + j] : 0x7fffffff;
+      int ov[ELL_D];
+#pragma unroll
+      for (int j = 0; j < ELL_D; ++j) ov[j] = other[j < c ? ev[j] : 0];
+#pragma unroll
+      for (int j = 0; j < ELL_D; ++j) {
+        int rank = 0;
+#pragma unroll
+        for (int m = 0; m < ELL_D; ++m) rank += ev[m] < ev[j] ? 1 : 0;
+        if (j < c) col[run + rank] = ov[j];
+      }
+      rowptr[r] = run;
+      if (dv) dv[r] = c > 0 ? 1.0f / sqrtf((float)c) : 0.f;
+      run += c;
+      if (r == nrows - 1) rowptr[nrows] = run;
+    }
+    if (nrows == 0 && gt == 0) rowptr[0] = 0;
+  };
+  if (NWn == 1) {
+    rows(cnt_a, ell_a, eo, rowptr_a, col_a, dinv, 0, 1);
+    rows(cnt_t, ell_t, ek, rowptr_t, col_t, nullptr, 0, 1);
+  } else if (wave < NA) {
+    rows(cnt_a, ell_a, eo, rowptr_a, col_a, dinv, wave, NA);
+  } else {
+    rows(cnt_t, ell_t, ek, rowptr_t, col_t, nullptr, wave - NA, NWn - NA);
+  }
+  lds_barrier();
+  return true;
 }
 
 // ---- stable CSR, few rows of high degree (local -> virtual: rows are clusters) ----------------

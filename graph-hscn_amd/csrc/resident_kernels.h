@@ -54,6 +54,12 @@ struct LayerP {
   const float *W_ll, *b_ll, *W_vv, *b_vv, *W_src, *W_dst, *att_src, *att_dst, *b_gat;
 };
 
+// capacities of the one-launch step's virtual program in its fixed-layout form (hscn_fwd_body MODE 6): Peptides-sized
+// graphs, up to 32 clusters
+struct StepVCaps {
+  static constexpr int N = 448, V = 32, EVV = V * (V + 1) / 2;
+};
+
 struct FwdArgs {
   const float* x_local;
   const float* x_virtual;
@@ -113,6 +119,15 @@ struct BwdArgs {
   int F, L, C, head_act, max_n, max_ell, P;
   int two;  // 1: two n x H buffers instead of three (one more barrier per layer; for graphs that need the LDS)
 };
+
+// a layer's parameter pointers as a plain object, whatever address space the argument block is read through (the
+// by-value kernel argument, or the constant-address-space view of it that late_args() hands out)
+template <typename AT>
+__device__ __forceinline__ LayerP layer_of(const AT& A, int l) {
+  LayerP P;
+  __builtin_memcpy(&P, &A.layer[l], sizeof(LayerP));
+  return P;
+}
 
 // ---- layer weights: global -> registers (prefetch) -> LDS (transposed Wt[k][o], rows k>=fin zero) ----
 // The 4 matrices of a layer ([H][fin] each, nn.Linear layout: W_ll, W_src, W_dst, W_vv) and 5
@@ -310,14 +325,27 @@ __device__ void lin_mfma(const float* X, const float* Wt, float* Y, int n, const
 // Wt comes off the matrix cores, bias + ReLU ride in the epilogue.  The n x H intermediate X Wt and the
 // workgroup barrier between "transform" and "gather-reduce" do not exist: a layer is one barrier.
 // (A_hat X) Wt instead of the reference's A_hat (X Wt): same value, rounded in another order.
+// pool_part (optional, [H] words of this wave): the column sums of the rows this wave produced -- the wave's share of
+// global_mean_pool, taken from the accumulators (rows of a tile in row order, tiles in tile order, then the four row
+// groups of the lanes): the pooling pass over the finished layer and its barrier do not exist.
 template <int H, typename TS>
 __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, const float* X, const float* Wt,
-                          const float* bias, float* Y, TS* __restrict__ gout, int n, const Grp& G) {
+                          const float* bias, float* Y, TS* __restrict__ gout, int n, const Grp& G,
+                          float* pool_part = nullptr) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int TD = H / 16, KS = H / 4;
   const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
   const int ntile = (n + 15) >> 4;
-  if (G.w >= ntile) return;
+  if (G.w >= ntile) {
+    if (pool_part && lj == 0) {
+#pragma unroll
+      for (int ct = 0; ct < TD; ++ct) pool_part[ct * 16 + li] = 0.f;
+    }
+    return;
+  }
+  float ps[TD];
+#pragma unroll
+  for (int ct = 0; ct < TD; ++ct) ps[ct] = 0.f;
   float b[TD][KS], bia[TD];
 #pragma unroll
   for (int ct = 0; ct < TD; ++ct) {
@@ -348,6 +376,7 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
           const float v = rnd<TS>(fmaxf(acc[ct][r] + bia[ct], 0.f));   // the activation as its storage type holds it
           Y[idx] = v;
           if (gout) stf(gout, (size_t)idx, v);
+          ps[ct] += v;
         }
       }
   };
@@ -382,6 +411,15 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
       }
     }
     finish(rt, z);
+  }
+  if (pool_part) {
+#pragma unroll
+    for (int ct = 0; ct < TD; ++ct) {
+      float t = ps[ct];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (lj == 0) pool_part[ct * 16 + li] = t;
+    }
   }
 }
 
@@ -509,9 +547,15 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
 // as their own specialisations, so each fetches only the code of its own path (the generic body is 75 KB of ISA
 // against a 64 KB instruction cache shared by two CUs, and a workgroup runs its program once per launch).
 // TS: storage type of features / activations in HBM (float or half_t; the argument block carries them as float*).
-template <int H, int RT, int MODE = 0, typename TS = float>
-__device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
+template <int H, int RT, int MODE = 0, typename TS = float, typename AT = FwdArgs>
+__device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // MODE 5 = the virtual branch of the one-launch training step (resident_step.h): what the launch fixes is a
+  // compile-time constant here, so its code paths and the scalar registers that steer them do not exist
+  constexpr bool STEPV = MODE == 5 || MODE == 6;
+  const int a_exp = STEPV ? 0 : A.exp, a_exp_dinv = STEPV ? 0 : A.exp_dinv, a_spec = STEPV ? 1 : A.spec;
+  const int l_begin = STEPV ? 0 : A.l_begin, l_end = STEPV ? A.L : A.l_end;
+  const int a_acq = STEPV ? (RT <= 256 ? 1 : 0) : A.acq;
   const TS* const xl_g = reinterpret_cast<const TS*>(A.x_local);
   const TS* const xv_g = reinterpret_cast<const TS*>(A.x_virtual);
   TS* const acts_g = reinterpret_cast<TS*>(A.acts);
@@ -522,25 +566,32 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   constexpr int WSZ = 4 * H * H + 5 * H;
   const int n0 = A.lptr[g], n = A.lptr[g + 1] - n0;
   const int v0 = A.vptr[g], nv = A.vptr[g + 1] - v0;
-  const bool vonly = MODE == 2 || MODE == 4 || (MODE == 0 && A.compute_virtual == 2);  // virtual branch only: the local activations come from `acts`
+  const bool vonly = MODE == 2 || MODE == 4 || MODE == 5 || MODE == 6 || (MODE == 0 && A.compute_virtual == 2);  // virtual branch only: the local activations come from `acts`
   // (a virtual-only workgroup touches the ll edges only when it builds the source-keyed CSR for the backward)
-  const int e0 = A.eptr_ll[g], ne = (vonly && !A.exp) ? 0 : A.eptr_ll[g + 1] - e0;
+  const int e0 = A.eptr_ll[g], ne = (vonly && !a_exp) ? 0 : A.eptr_ll[g + 1] - e0;
   const int ev0 = A.eptr_vv[g], nev = A.eptr_vv[g + 1] - ev0;
   const int el0 = A.eptr_lv[g], nel = A.eptr_lv[g + 1] - el0;
   if ((n > A.max_n) | (nv > A.max_v) | (ne > A.max_ell) | (nev > A.max_evv) | (nel > A.max_n) | (n < 0) | (nv < 0)) {
     if (threadIdx.x == 0 && A.flag) atomicOr(A.flag, 4);
     // the launches that consume this workgroup's exports walk them without knowing about the error: leave
     // empty structure (all-zero row pointers) behind, never stale memory
-    if (A.exp && A.csr_rowptr_t && n >= 0)
+    if (a_exp && A.csr_rowptr_t && n >= 0)
       for (int i = threadIdx.x; i <= n; i += RT) A.csr_rowptr_t[(size_t)n0 + g + i] = 0;
-    if (vonly && A.l_begin == 0 && A.l_end < A.L && A.vs_rowptr_lv && nv >= 0)
+    if (vonly && l_begin == 0 && l_end < A.L && A.vs_rowptr_lv && nv >= 0)
       for (int i = threadIdx.x; i <= nv; i += RT) {
         A.vs_rowptr_lv[(size_t)v0 + g + i] = 0;
         A.vs_rowptr_vv[(size_t)v0 + g + i] = 0;
       }
     return;
   }
-  const FwdLayout Y = fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.db, A.exp);
+  // MODE 6: the capacities that size the LDS layout are compile-time constants (StepVCaps; the host takes this form
+  // when the batch's maxima fit them), so every LDS address below is an immediate, not a scalar register that lives
+  // -- or is spilled -- through the whole program
+  constexpr bool FIXL = MODE == 6;
+  const int cap_v = FIXL ? StepVCaps::V : A.max_v;
+  const int a_db = FIXL ? 1 : A.db;
+  const FwdLayout Y = FIXL ? fwd_layout(H, 1, StepVCaps::N, StepVCaps::V, 0, StepVCaps::EVV, 1, 0)
+                           : fwd_layout(H, A.C, A.max_n, A.max_v, A.max_ell, A.max_evv, A.db, a_exp);
   float* fb = reinterpret_cast<float*>(smem);
   int* ib = reinterpret_cast<int*>(smem);
   float *xa = fb + Y.xa, *bh = fb + Y.bh, *xva = fb + Y.xva, *xvb = fb + Y.xvb, *zs = fb + Y.zs;
@@ -589,8 +640,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   // ---- prologue: request every global input of this graph, then consume -----------------------
   STAMP(0);
   WStage<H, RT> ws;
-  const bool resume = MODE == 4 || (MODE == 0 && vonly && A.l_begin > 0);
-  const bool prestruct = vonly && A.pre_rp_lv != nullptr && A.l_begin == 0;
+  const bool resume = MODE == 4 || (MODE == 0 && vonly && l_begin > 0);
+  const bool prestruct = vonly && A.pre_rp_lv != nullptr && l_begin == 0;
   if (!resume && !prestruct) {
   constexpr int EPT = 2;   // edges per thread held in registers (covers RT*EPT edges per relation)
   constexpr int XPT = 8;   // feature words per thread held in registers
@@ -615,7 +666,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     if (cv && eb < nel) { rvd[i] = pvd[o2 ? el0 + e : 0]; rvs[i] = pvs[o2 ? el0 + e : 0]; }
     if (cv && eb < nev) { rwd[i] = pwd[o3 ? ev0 + e : 0]; rws[i] = pws[o3 ? ev0 + e : 0]; }
   }
-  ws.fetch(A.layer[0], !vonly, cv, F);   // after the edges: they are consumed first
+  ws.fetch(layer_of(A, 0), !vonly, cv, F);   // after the edges: they are consumed first
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int idx = threadIdx.x + i * RT;
@@ -710,7 +761,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   // the CSR builds count in these (they hand them back zeroed)
   for (int i = threadIdx.x; i <= n; i += RT) {
     (ib + Y.cursorA)[i] = 0;
-    if (A.exp) (ib + Y.cursorT)[i] = 0;
+    if (a_exp) (ib + Y.cursorT)[i] = 0;
   }
   if (cv)
     for (int i = threadIdx.x; i <= nv; i += RT) (ib + Y.cursorV)[i] = 0;
@@ -722,8 +773,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   // five barriers)
   {
     int *rowptr_t = ib + Y.rowptr_t, *col_t = ib + Y.col_t;
-    const int w_t = !A.exp ? 0 : (cv ? (NW * 3) / 8 : NW - NW / 2);          // 6 of 16 waves (1 of 4)
-    const int w_ll = vonly ? 0 : (cv ? (A.exp ? (NW * 3) / 8 : NW / 2) : NW - w_t);
+    const int w_t = !a_exp ? 0 : (cv ? (NW * 3) / 8 : NW - NW / 2);          // 6 of 16 waves (1 of 4)
+    const int w_ll = vonly ? 0 : (cv ? (a_exp ? (NW * 3) / 8 : NW / 2) : NW - w_t);
     const int w_vv = cv ? (NW - w_ll - w_t) / 2 : 0;
     const int w_lv = cv ? NW - w_ll - w_t - w_vv : 0;
     const int wa = wave < w_ll ? 0 : (wave < w_ll + w_t ? 1 : (wave < w_ll + w_t + w_vv ? 2 : 3));
@@ -789,18 +840,18 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     STAMP(2);
     lds_barrier();
     // export the source-keyed CSR and the degree norm for the backward launch
-    if (A.exp) {
+    if (a_exp) {
       for (int i = threadIdx.x; i <= n; i += RT) A.csr_rowptr_t[(size_t)n0 + g + i] = rowptr_t[i];
       const int cnt_t = rowptr_t[n];
       for (int p = threadIdx.x; p < cnt_t; p += RT) A.csr_col_t[(size_t)e0 + p] = col_t[p];
     }
-    if (A.exp_dinv)
+    if (a_exp_dinv)
       for (int i = threadIdx.x; i < n; i += RT) A.dinv_out[(size_t)n0 + i] = dinv[i];
   }
   } else if (prestruct) {
     // ---- virtual branch on dataset-resident structure: nothing is staged or built, the CSRs of the two virtual
     // relations and the degree norm are loaded (graph-local ids, exactly what the builds below would produce)
-    ws.fetch(A.layer[0], false, true, F);
+    ws.fetch(layer_of(A, 0), false, true, F);
     for (int idx = threadIdx.x; idx < n * H; idx += RT) {
       const int r = idx / H, k = idx - r * H;
       xa[idx] = k < F ? ldf(xl_g, (size_t)(n0 + r) * F + k) : 0.f;
@@ -823,8 +874,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
   } else {
     // ---- resumed virtual branch: the structure and the virtual features come from the state the
     // first part of this step exported, the local rows from the previous layer's activations
-    ws.fetch(A.layer[A.l_begin], false, true, H);
-    const TS* src = acts_g + ((size_t)(A.l_begin - 1) * A.N + n0) * H;
+    ws.fetch(layer_of(A, l_begin), false, true, H);
+    const TS* src = acts_g + ((size_t)(l_begin - 1) * A.N + n0) * H;
     for (int i = threadIdx.x; i < n * (H / 4); i += RT) reinterpret_cast<float4*>(xa)[i] = ldf4(src, i);
     for (int i = threadIdx.x; i < nv * H; i += RT) xva[i] = ldf(vsxv_g, (size_t)v0 * H + i);
     for (int i = threadIdx.x; i <= nv; i += RT) {
@@ -834,15 +885,15 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     for (int i = threadIdx.x; i < nel; i += RT) col_lv[i] = A.vs_col_lv[(size_t)el0 + i];
     for (int i = threadIdx.x; i < nev; i += RT) col_vv[i] = A.vs_col_vv[(size_t)ev0 + i];
     for (int i = threadIdx.x; i < nv; i += RT) dinv_v[i] = A.vs_dinv_v[(size_t)v0 + i];
-    ws.store(wt + (A.db ? (A.l_begin & 1) * WSZ : 0));
+    ws.store(wt + (a_db ? (l_begin & 1) * WSZ : 0));
     lds_barrier();
     if (wave == 0) build_chunk_table();
     lds_barrier();
   }
   STAMP(3);
 
-  for (int l = A.l_begin; l < A.l_end; ++l) {
-    const bool DB = A.db != 0;                 // two weight buffers: the next layer's land under this layer's math
+  for (int l = l_begin; l < l_end; ++l) {
+    const bool DB = a_db != 0;                 // two weight buffers: the next layer's land under this layer's math
     float* W = wt + (DB ? (l & 1) * WSZ : 0);
     float* Wn = wt + (DB ? ((l + 1) & 1) * WSZ : 0);
     const float* b_ll = W + 4 * H * H;
@@ -850,9 +901,9 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     const float* b_gat = b_ll + 2 * H;
     const float* att_s = b_ll + 3 * H;
     const float* att_d = b_ll + 4 * H;
-    const bool more = l + 1 < A.l_end;
+    const bool more = l + 1 < l_end;
     // fetch the next layer's weights now, park them in LDS under this layer's math
-    if (more && DB) ws.fetch(A.layer[l + 1], !vonly, cv, H);
+    if (more && DB) ws.fetch(layer_of(A, l + 1), !vonly, cv, H);
     STAMP(4 + 4 * l);
     auto transforms_ll = [&](const Grp& G_) {
       if (H <= 32) lin_mfma<H, false>(xa, W, bh, n, nullptr, G_);
@@ -873,7 +924,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     // applies the two H x H matrices to the two aggregated rows.  Same values as transform-then-aggregate,
     // another rounding order.
     auto transforms_virtual = [&](const Grp& G_) {
-      if (G_.t == 0) ck_arrive[A.max_v] = 0;   // this layer's chunk counter (the phase barrier orders it before the reduce)
+      if (G_.t == 0) ck_arrive[cap_v] = 0;   // this layer's chunk counter (the phase barrier orders it before the reduce)
       att_logits<H>(xa, W + H * H, att_s, a_s, n, G_);
       att_logits<H>(xva, W + 2 * H * H, att_d, a_d, nv, G_);
     };
@@ -900,7 +951,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       // wave is free takes the next one -- in a virtual-only workgroup the loading waves join in once their rows are
       // parked, so 16 clusters of a graph take one round on 16 waves instead of two on 12.  A chunk's arithmetic does
       // not depend on who runs it, a cluster is finished by its last arriver in chunk order: same bits as before.
-      int* ck_next = ck_arrive + A.max_v;
+      int* ck_next = ck_arrive + cap_v;
       (void)G_;
       for (;;) {
         int ck = 0;
@@ -1059,7 +1110,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     // (the two wave groups may only run side by side while the local layer leaves xa alone until the layer ends:
     // group B gathers input rows from it in phase 2.  The unfused H = 64 local path rewrites xa in its second
     // phase, so there the branches take turns)
-    if (cv && A.spec && (FUSE || vonly)) {
+    if (cv && a_spec && (FUSE || vonly)) {
       // two barriers per layer: the ll path (group A) and the virtual branch (group B) side by side
       // (virtual-only launch: group A streams the next layer's local rows into the idle transform
       // buffer while group B works, the two buffers swap roles at the end of the layer)
@@ -1102,8 +1153,8 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
         lds_barrier();
         STAMP(5 + 4 * l);
         float4* ndst = reinterpret_cast<float4*>(bh);
-        const bool sc1l = hand && !A.acq;
-        if (hand && A.acq) {
+        const bool sc1l = hand && !a_acq;
+        if (hand && a_acq) {
           wait_published<true>(A.ready + g, A.epoch[0] * 8u + (uint32_t)(l + 1), A.flag);
 #pragma unroll
           for (int u = 0; u < PF; ++u) {
@@ -1164,7 +1215,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
       }
     }
     if (more && !DB) {  // single weight buffer: everybody is done with it now
-      ws.fetch(A.layer[l + 1], !vonly, cv, H);
+      ws.fetch(layer_of(A, l + 1), !vonly, cv, H);
       ws.store(Wn);
       lds_barrier();
     }
@@ -1174,7 +1225,7 @@ __device__ __forceinline__ void hscn_fwd_body(const FwdArgs& A, const int g) {
     }
   }
 
-  if (vonly && A.l_end < A.L) {
+  if (vonly && l_end < A.L) {
     // first part of a split virtual branch: hand the state to the part that resumes at l_end
     for (int idx = threadIdx.x; idx < nv * H; idx += RT) stf(vsxv_g, (size_t)v0 * H + idx, xva[idx]);
     for (int i = threadIdx.x; i <= nv; i += RT) {

@@ -57,6 +57,7 @@ struct StepArgs {
 struct StepLayout {
   size_t A, dinv, wt, headw, part, vec, red, rowptr, col, rowptr_t, col_t, wsum, total;
   size_t ek, eo, cursorA, tmpA, cursorT, tmpT;
+  size_t cntA, cntT, ellA, ellT, ovf;   // the two-barrier build for low-degree rows (build_csr_pair_ell)
   int NB;
   size_t bufw;  // words per n x H buffer
 };
@@ -71,8 +72,10 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   size_t bufw = (size_t)((max_n + 15) / 16 * 16) * H;   // whole 16-row tiles (A[0] doubles as per-wave tile scratch)
   const size_t stage = 2 * up4(max_ell);
   const size_t scratch = 2 * up4((size_t)max_n + 1) + 2 * up4(max_ell);
+  const size_t scratch_ell = 2 * up4((size_t)max_n + 1) + 2 * up4((size_t)max_n * ELL_D) + 4;
   if (stage > bufw) bufw = stage;
   if (scratch > bufw) bufw = scratch;
+  if (scratch_ell > bufw) bufw = scratch_ell;
   Y.bufw = bufw;
   Y.A = take(bufw * Y.NB);
   Y.ek = Y.A + bufw;
@@ -81,6 +84,11 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   Y.tmpA = Y.cursorA + up4((size_t)max_n + 1);
   Y.cursorT = Y.tmpA + up4(max_ell);
   Y.tmpT = Y.cursorT + up4((size_t)max_n + 1);
+  Y.cntA = Y.A + 2 * bufw;                                  // (the same words as the general build's scratch)
+  Y.cntT = Y.cntA + up4((size_t)max_n + 1);
+  Y.ellA = Y.cntT + up4((size_t)max_n + 1);
+  Y.ellT = Y.ellA + up4((size_t)max_n * ELL_D);
+  Y.ovf = Y.ellT + up4((size_t)max_n * ELL_D);
   Y.dinv = take(max_n);
   Y.wt = take((size_t)L * (H * H + H));                            // per layer: Wt[k][o] (rows k >= fin zero) | b[H]
   Y.headw = take((size_t)H * H + H + (size_t)C * H + 4 * (size_t)C);  // W1 | b1 | W2 | b2 | target row | g_pred row | loss terms
@@ -167,6 +175,9 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   const Grp ALL{(int)threadIdx.x, RT, wave, NW};
   constexpr int WL = H * H + H;   // words per layer in wt
 
+#ifndef HSCN_CSR_ELL
+#define HSCN_CSR_ELL 1
+#endif
   // ---- prologue: every global input of the graph is requested before anything is consumed ----------------
   STAMP(0);
   constexpr int EPT = 2, XPT = 8;
@@ -282,8 +293,12 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     }
     if (bad && A.flag) atomicOr(A.flag, 2);
   }
+#if HSCN_CSR_ELL
+  for (int i = threadIdx.x; i <= n; i += RT) { (ib + Y.cntA)[i] = 0; (ib + Y.cntT)[i] = 0; }
+#else
   for (int i = threadIdx.x; i <= n; i += RT) { (ib + Y.cursorA)[i] = 0; (ib + Y.cursorT)[i] = 0; }
-  if (threadIdx.x == 0) { (ib + Y.wsum)[0] = 0; (ib + Y.wsum)[1] = 0; }   // fold sign-offs (H = 16 backward), export sign-offs
+#endif
+  if (threadIdx.x == 0) { (ib + Y.wsum)[0] = 0; (ib + Y.wsum)[1] = 0; (ib + Y.ovf)[0] = 0; }   // fold sign-offs (H = 16 backward), export sign-offs
   {
     float* x0 = buf(0);
 #pragma unroll
@@ -313,6 +328,30 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   lds_barrier();
   STAMP(1);
   // ---- structure: the two CSRs of the local->local relation side by side (four barriers each) -------------
+  // Molecule-like graphs (every row of at most ELL_D edges) take the two-barrier build of both CSRs; a graph with a
+  // denser row takes the general one (four barriers after re-zeroing its counters).  Same arrays either way.
+#if HSCN_CSR_ELL
+  if (!pre) {
+    const bool low = build_csr_pair_ell(ib + Y.ek, ib + Y.eo, ne, n, rowptr, col, rowptr_t, col_t, dinv, ib + Y.cntA,
+                                        ib + Y.ellA, ib + Y.cntT, ib + Y.ellT, ib + Y.ovf, RT, wave, NW);
+    if (!low) {
+      const int NA = NW / 2 > 0 ? NW / 2 : 1;
+      const bool inB = wave >= NA && NW > 1;
+      if (NW == 1) {
+        build_csr_lds(ib + Y.ek, ib + Y.eo, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, ALL, true);
+        build_csr_lds(ib + Y.eo, ib + Y.ek, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, ALL, true);
+        dinv_from_rowptr(rowptr, n, dinv, ALL);
+      } else if (!inB) {
+        const Grp GA{(int)threadIdx.x, NA * 64, wave, NA};
+        build_csr_lds(ib + Y.ek, ib + Y.eo, ne, n, rowptr, col, ib + Y.cursorA, ib + Y.tmpA, GA, true);
+        dinv_from_rowptr(rowptr, n, dinv, GA);
+      } else {
+        const Grp GB{(int)threadIdx.x - NA * 64, (NW - NA) * 64, wave - NA, NW - NA};
+        build_csr_lds(ib + Y.eo, ib + Y.ek, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, GB, true);
+      }
+    }
+  }
+#else
   if (!pre) {
     const int NA = NW / 2 > 0 ? NW / 2 : 1;
     const bool inB = wave >= NA && NW > 1;
@@ -329,6 +368,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       build_csr_lds(ib + Y.eo, ib + Y.ek, ne, n, rowptr_t, col_t, ib + Y.cursorT, ib + Y.tmpT, GB, false);
     }
   }
+#endif
   lds_barrier();
   STAMP(3);
   // ---- forward layers: A[l] -> A[l + 1], one barrier each ----------------------------------------------------
@@ -391,9 +431,12 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   };
   for (int l = 0; l < L; ++l) {
     STAMP(4 + l);
+    // the last layer leaves each wave's share of global_mean_pool behind (column sums out of its accumulators)
+    float* pool_w = l == L - 1 ? partp + wave * H : nullptr;
     if (wave < NC) {
-      gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC);
+      gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w);
     } else if (hand) {
+      if (pool_w && lane < H) pool_w[lane] = 0.f;
       if (l >= 2) raise(l - 1);
       if (l >= 1) export_rows(buf(l), acts_g + ((size_t)(l - 1) * A.N + n0) * H);
     }
@@ -404,32 +447,14 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     raise(L - 1);
   }
   STAMP(12);
-  // ---- global_mean_pool + head + this graph's row of the loss tail --------------------------------------------
+  // ---- head + this graph's row of the loss tail (wave 0) ---------------------------------------------------
   float* aL = buf(L);
-  {
-    constexpr int LPR = H / 4;
-    constexpr int S = 64 / LPR;
-    const int slot = lane / LPR, f = (lane % LPR) * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = wave * S + slot; i < n; i += NW * S) {
-      const float4 v = *reinterpret_cast<const float4*>(aL + i * H + f);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-#pragma unroll
-    for (int off = 32; off >= LPR; off >>= 1) {
-      acc.x += __shfl_xor(acc.x, off, 64);
-      acc.y += __shfl_xor(acc.y, off, 64);
-      acc.z += __shfl_xor(acc.z, off, 64);
-      acc.w += __shfl_xor(acc.w, off, 64);
-    }
-    if (slot == 0) *reinterpret_cast<float4*>(partp + wave * H + f) = acc;
-  }
-  lds_barrier();
   if (hand && wave >= NC && NW > 1) raise(L - 1);       // the last hand-off signs off beside the head (wave 0's chain)
   float* pol = vec;          // pooled
   float* zz = vec + 64;      // z = act(lin_1(pooled))
   float* gz = vec + 128;     // dL/d(lin_1 output, pre-activation)
   float* gpool = vec + 192;
+  float* gpn = vec + 256;    // gpool / n: the gradient of every unmasked element of the last layer's output
   const float* W1l = headw;
   const float* b1l = headw + H * H;
   const float* W2l = b1l + H;
@@ -437,8 +462,53 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   const float* tgl = b2l + C;
   float* gpl = headw + HT + C;       // g_pred row
   float* ltl = gpl + C;              // loss terms
+  // H = 16, C <= 16: the head's five small products run out of REGISTERS -- every LDS word the chain needs (the
+  // waves' pool partials, a row and a column of W1 and of W2 per lane, biases, the target row) is requested in one
+  // batch, and a vector element crosses lanes through a DPP row broadcast (one VALU operation), not through an LDS
+  // round trip with a wavefront fence on either side.  Same fmaf chains in the same order as the general path below.
+  const bool fast_head = H == 16 && C <= 16;
   if (threadIdx.x < 64) {
     const float cnt = (float)(n > 0 ? n : 1);
+    if (fast_head) {
+      constexpr int HH = H <= 16 ? H : 16;
+      const bool lh = lane < HH, lc = lane < C;
+      const int lk = lh ? lane : 0, lcc = lc ? lane : 0;
+      float pw[NW], w1r[HH], w1c[HH], w2r[HH], w2c[16];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) pw[w] = partp[w * H + lk];
+#pragma unroll
+      for (int k4 = 0; k4 < HH / 4; ++k4) {
+        const float4 a = *reinterpret_cast<const float4*>(W1l + lk * H + 4 * k4);
+        w1r[4 * k4] = a.x; w1r[4 * k4 + 1] = a.y; w1r[4 * k4 + 2] = a.z; w1r[4 * k4 + 3] = a.w;
+        const float4 b = *reinterpret_cast<const float4*>(W2l + lcc * H + 4 * k4);
+        w2r[4 * k4] = b.x; w2r[4 * k4 + 1] = b.y; w2r[4 * k4 + 2] = b.z; w2r[4 * k4 + 3] = b.w;
+      }
+#pragma unroll
+      for (int o = 0; o < HH; ++o) w1c[o] = W1l[o * H + lk];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) w2c[c] = c < C ? W2l[c * H + lk] : 0.f;
+      const float bb1 = b1l[lk], bb2 = b2l[lcc], tgt = tgl[lcc];
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += pw[w];
+      const float polv = s / cnt;                                    // lane k: pooled[k]
+      const float zv = apply_act(row_dot<HH>(polv, w1r, 0.f) + bb1, A.head_act);   // lane o: z[o]
+      const float pc = row_dot<HH>(zv, w2r, 0.f) + bb2;               // lane c: pred[c]
+      float lt, sg, gg;
+      criterion_elem(A.loss_kind, pc, tgt, A.inv_count, lt, sg, gg);   // same element code as k_criterion
+      if (lc) {
+        A.pred[(size_t)g * C + lane] = pc;
+        if (A.score) A.score[(size_t)g * C + lane] = sg;             // (= 1 / (1 + exp(-pred)), criterion_elem's)
+      }
+      lt = lc ? lt : 0.f;                                             // (lanes past C: exact zeros in the sums below)
+      gg = lc ? gg : 0.f;
+      const float sl = row_seq_sum<16>(lt, 0.f);                      // loss terms in class order
+      const float gzv = row_dot<16>(gg, w2c, 0.f) * act_grad_from_output(zv, A.head_act);   // lane o
+      const float gpa = row_dot<HH>(gzv, w1c, 0.f);                   // lane k: d loss / d pooled[k]
+      if (lh) { pol[lane] = polv; zz[lane] = zv; gz[lane] = gzv; gpool[lane] = gpa; gpn[lane] = gpa / cnt; }
+      if (lc) gpl[lane] = gg;
+      if (lane == 0) part[A.Pn] = sl;
+    } else {
     if (lane < H) {
       float s = 0.f;
 #pragma unroll
@@ -482,7 +552,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       gpl[c] = gg;
       ltl[c] = lt;
       A.pred[(size_t)g * C + c] = pc;
-      if (A.score) A.score[(size_t)g * C + c] = 1.0f / (1.0f + expf(-pc));
+      if (A.score) A.score[(size_t)g * C + c] = sg;
     }
     // ---- head backward, first half (same wave: no barrier needed up to gz) ----
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -497,6 +567,8 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
 #pragma unroll
       for (int o = 0; o < H; ++o) acc = fmaf(gz[o], W1l[o * H + lane], acc);
       gpool[lane] = acc;
+      gpn[lane] = acc / cnt;
+    }
     }
   }
   lds_barrier();
@@ -512,7 +584,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     part[oW2 + idx] = gpl[c] * zz[k];
   }
   for (int c = threadIdx.x; c < C; c += RT) part[ob2 + c] = gpl[c];
-  if (threadIdx.x == RT - 64) {   // the graph's loss terms, summed in class order
+  if (!fast_head && threadIdx.x == RT - 64) {   // the graph's loss terms, summed in class order
     float sl = 0.f;
     for (int c = 0; c < C; ++c) sl += ltl[c];
     part[A.Pn] = sl;
@@ -566,11 +638,8 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     int pend_ob = 0;
     // The gradient of the last layer's output is never materialised: G_L[j][k] = a_L[j][k] > 0 ? gpool[k] / n : 0 is
     // applied where the first backward layer reads it (the same values as the masking pass of the launch pair).
-    const float ncnt = (float)(n > 0 ? n : 1);
-    const float4 gq4 = make_float4(gpool[4 * lj + 0] / ncnt, gpool[4 * lj + 1] / ncnt, gpool[4 * lj + 2] / ncnt,
-                                   gpool[4 * lj + 3] / ncnt);       // this lane's feature quarter (tile gather)
-    const float4 gb4 = make_float4(gpool[4 * (lane & 3) + 0] / ncnt, gpool[4 * (lane & 3) + 1] / ncnt,
-                                   gpool[4 * (lane & 3) + 2] / ncnt, gpool[4 * (lane & 3) + 3] / ncnt);   // (bias sums)
+    const float4 gq4 = *reinterpret_cast<const float4*>(gpn + 4 * lj);            // this lane's feature quarter (tile gather)
+    const float4 gb4 = *reinterpret_cast<const float4*>(gpn + 4 * (lane & 3));    // (bias sums)
     auto gl4 = [](const float4 a, const float4 q) {
       return make_float4(a.x > 0.f ? q.x : 0.f, a.y > 0.f ? q.y : 0.f, a.z > 0.f ? q.z : 0.f, a.w > 0.f ? q.w : 0.f);
     };
@@ -579,7 +648,8 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       off -= H * fin + H;
       const int oW = off, ob = off + H * fin;
       float* bredw = bred + (it & 1) * NW * H;
-      lds_barrier();  // G complete; the previous layer's partial tiles and bias partials are in LDS
+      if (it > 0) lds_barrier();  // G complete; the previous layer's partial tiles and bias partials are in LDS
+                                   // (it = 0: nothing was written to LDS since the barrier behind the head)
       if (pend_oW >= 0) {
         // (the folding threads are the workgroup's LAST ones: with 23 row tiles on 16 waves the first seven waves own
         // two tiles, the last ones one)
@@ -838,10 +908,11 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
 }
 
 // grid = B (no virtual branch) or 2B: blocks [0, B) run the local program, blocks [B, 2B) the virtual branch
-template <int H, int RT, typename TS>
+// VMODE: 5 = the virtual program sizes its LDS layout from the arguments, 6 = from StepVCaps (compile time)
+template <int H, int RT, typename TS, int VMODE = 5>
 __global__ void __launch_bounds__(RT) k_hscn_step(const StepArgs S, const FwdArgs V) {
   if ((int)blockIdx.x < S.B) hscn_step_local<H, RT, TS>(S, blockIdx.x);
-  else hscn_fwd_body<H, RT, 2, TS>(V, (int)blockIdx.x - S.B);
+  else hscn_fwd_body<H, RT, VMODE, TS>(V, (int)blockIdx.x - S.B);
 }
 template <int H, int RT, typename TS>
 __global__ void __launch_bounds__(RT) k_hscn_step_local(const StepArgs S) {
@@ -852,12 +923,12 @@ inline size_t step_lds_bytes(int H, int L, int C, int max_n, int max_ell) {
   return step_layout(H, L, C, max_n, max_ell).total * 4;
 }
 
-template <int H, int RT, typename TS>
+template <int H, int RT, typename TS, int VMODE = 5>
 int launch_step_rt(const StepArgs& S, const FwdArgs* V, size_t lds, hipStream_t st) {
   if (V) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_hscn_step<H, RT, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_hscn_step<H, RT, TS><<<(unsigned)(2 * S.B), RT, lds, st>>>(S, *V);
+      (void)hipFuncSetAttribute((const void*)k_hscn_step<H, RT, TS, VMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_hscn_step<H, RT, TS, VMODE><<<(unsigned)(2 * S.B), RT, lds, st>>>(S, *V);
   } else {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_hscn_step_local<H, RT, TS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -872,10 +943,20 @@ template <int H, typename TS>
 int launch_step(StepArgs& S, FwdArgs* V, hipStream_t st) {
   size_t lds = step_lds_bytes(H, S.L, S.C, S.max_n, S.max_ell);
   if (lds > 160 * 1024) return HSCN_E_UNSUPPORTED;
+  bool fixed_layout = false;
   if (V) {
     V->spec = 1; V->exp = 0; V->exp_dinv = 0;
-    const size_t lv = pick_fwd_lds(*V, H);
+    size_t lv = pick_fwd_lds(*V, H);
     if (lv > 160 * 1024) return HSCN_E_UNSUPPORTED;
+    // 16-wave workgroups on graphs within StepVCaps: the virtual program with its LDS layout fixed at compile time
+    // (hscn_fwd_body MODE 6: the layout's ~40 offsets are immediates instead of scalar registers -- 90 SGPR spills
+    // become 9); HSCN_STEP_FIXED_LAYOUT=0 keeps the run-time layout (A/B, and what larger graphs / more clusters take)
+    static const bool allow_fixed = !(getenv("HSCN_STEP_FIXED_LAYOUT") && atoi(getenv("HSCN_STEP_FIXED_LAYOUT")) == 0);
+    if (allow_fixed && S.max_n > 64 && V->max_n <= StepVCaps::N && V->max_v <= StepVCaps::V && V->max_evv <= StepVCaps::EVV &&
+        V->l_begin == 0 && V->l_end == V->L) {
+      const size_t lf = fwd_layout(H, 1, StepVCaps::N, StepVCaps::V, 0, StepVCaps::EVV, 1, 0).total * 4;
+      if (lf <= 160 * 1024) { fixed_layout = true; lv = lf; V->db = 1; }
+    }
     if (lv > lds) lds = lv;
     if (S.max_n > 64) {
       // 16-wave workgroups: one per CU (the acquire-free consumer form is measured for exactly that): ask for more
@@ -886,5 +967,6 @@ int launch_step(StepArgs& S, FwdArgs* V, hipStream_t st) {
     }
   }
   if (S.max_n <= 64) return launch_step_rt<H, 256, TS>(S, V, lds, st);
+  if (fixed_layout) return launch_step_rt<H, 1024, TS, 6>(S, V, lds, st);
   return launch_step_rt<H, 1024, TS>(S, V, lds, st);
 }

@@ -718,7 +718,9 @@ int hscn_adam_step(float* const* params_host, const int32_t* seg_off_host, int n
  * a per-source epoch flag there (system-scope release), waits for its own G flags (bounded spin), and adds its G
  * slots in RANK ORDER: flat = scale * (slot_0 + slot_1 + ... + slot_{G-1}), separately rounded adds, the same order
  * on every rank, so replicas stay bit-identical.  One launch; capturable (the epoch is device state advanced by the
- * kernel).  Slots are double-buffered by epoch parity (csrc/allreduce.hip explains why two suffice).
+ * kernel).  Slots are double-buffered by epoch parity (csrc/allreduce.hip explains why two suffice).  Buffers of up
+ * to 16 384 floats travel as 8-byte {value, epoch} granules (64-bit relaxed system-scope atomics: no flag, no fence,
+ * one fabric round trip); larger ones as 16-byte slabs with per-chunk flags and one release / acquire per workgroup.
  *
  * Set-up (host-synchronous, once per job; the only entry points that allocate):
  *   hscn_comm_alloc      zero-filled device memory that peers may write while a kernel polls it.

@@ -67,3 +67,19 @@ def grads_close(a, b, rel=2e-6):
     if d > lim:
         print("max abs diff", d, "limit", lim)
     return d <= lim
+
+
+def pool_order_close(a, b, rel=1e-5):
+    """Outputs of the one-launch step's head against the launch pair's: the same head applied to a mean pool whose
+    partial sums are grouped differently -- per wave out of the last layer's accumulators (rows of a tile, tiles of a
+    wave, waves) instead of a strided pass over the finished layer.  n <= 444 non-negative (post-ReLU) terms: either
+    grouping is within (n - 1) 2^-24 <= 2.7e-5 of the exact sum in the worst case and ~sqrt(n) 2^-24 ~ 1e-6 typically;
+    the bar applied is north_star's 1e-5, relative to the tensor's magnitude.  Returns the verdict; prints the distance
+    when it fails."""
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    d = float((a - b).abs().max()) if a.numel() else 0.0
+    lim = rel * max(1.0, float(b.abs().max()) if b.numel() else 0.0)
+    if d > lim:
+        print("pool-order distance", d, "limit", lim)
+    return d <= lim

@@ -8,6 +8,8 @@ out exactly as the kernel lays out a rank's allocation:
 and a call walks the kernel's steps chunk by chunk: epoch e = last + 1, parity e & 1, store into slot `rank` of
 every rank, raise flag `rank` there with e, wait (bounded) until the own flags read e or e + 1
 ((int32)(flag - e) >= 0), add the own G slots in rank order with float32 roundings, scale, advance the epoch.
+(The kernel's granule form for small buffers differs only in carrying the epoch inside each 8-byte element instead
+of in a flag word; the parity / epoch reasoning checked here is common to both.)
 It pins the index arithmetic and the two-parity reuse argument under real concurrency on a CPU box; the memory
 ordering of the device code is what the -m gpu tests (two processes sharing one GPU) are for."""
 import time

@@ -36,7 +36,8 @@ def test_single_rank_is_a_scaling_and_replays_from_a_hipgraph(count):
     want = (x.cpu().numpy() * np.float32(0.25)).astype(np.float32)
     ar(x, 0.25)
     assert np.array_equal(x.cpu().numpy(), want)
-    nch = (count + 2047) // 2048
+    nch = ar.epoch.numel()                     # granule form: 256 elements per workgroup; slab form: 2048
+    assert nch == (count + 255) // 256
     assert ar.epoch.cpu().tolist() == [1] * nch
     ar.check()
     # captured: the epoch is device state advanced by the kernel, nothing is frozen into the graph
@@ -93,10 +94,11 @@ def test_missing_peer_times_out_flags_it_and_leaves_the_buffer():
     a1.close()
 
 
-@pytest.mark.parametrize("count", [1146, 159381])
+@pytest.mark.parametrize("count", [1146, 16384, 159381])
 def test_two_ranks_in_one_process_on_two_streams(count):
-    """Both ranks' kernels run concurrently on one GPU (two streams) and really wait for each other's flags;
-    159 381 floats = the largest model of SURVEY 8(a9) (78 workgroups per rank)."""
+    """Both ranks' kernels run concurrently on one GPU (two streams) and really wait for each other: 1 146 floats =
+    the headline model (granule form, 5 workgroups), 16 384 = the largest granule buffer (64 workgroups per rank),
+    159 381 = the largest model of SURVEY 8(a9) (slab + flag form, 78 workgroups per rank)."""
     from graph_hscn.distributed import OneShotAllReduce
     dev = torch.device(DEV)
     ars = [OneShotAllReduce(count, dev, rank=r, world=2, connect=False) for r in range(2)]
@@ -130,10 +132,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _ipc_worker(rank, world, port, count, iters, q):
+def _ipc_worker(rank, world, port, count, iters, form, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "graph-hscn_amd")]
+    if form:
+        os.environ["HSCN_ALLREDUCE_FORM"] = form     # (read once per process, before the first call)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -166,16 +170,17 @@ def _ipc_worker(rank, world, port, count, iters, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
-def test_processes_sharing_the_gpu_through_hipipc(world):
+@pytest.mark.parametrize("world,form", [(2, ""), (3, ""), (2, "slabs")])
+def test_processes_sharing_the_gpu_through_hipipc(world, form):
     """The multi-GPU set-up path end to end -- fine-grained allocation, hipIpcGetMemHandle, all_gather_object,
     hipIpcOpenMemHandle -- and the protocol between kernels of DIFFERENT processes (separate queues, no common
-    stream order), 200 exchanges with uneven arrival."""
+    stream order), 200 exchanges with uneven arrival.  form "" = what the size selects (1 146 floats: granules),
+    "slabs" forces the slab + flag form onto the same buffer."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     count, iters = 1146, 200
-    procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, count, iters, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, count, iters, form, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]

@@ -67,10 +67,13 @@ def test_direct_step_is_the_autograd_step_bit_for_bit(overlap, compute_virtual, 
     rs.run()                      # idempotent: buffers are rewritten, not accumulated into
     torch.cuda.synchronize()
     rs.check()
-    assert torch.equal(rs.pred, pred.detach())
-    assert torch.equal(rs.score, score)
-    assert torch.equal(rs.loss, loss.detach())
-    from tests.helpers import grads_close
+    from tests.helpers import grads_close, pool_order_close
+    # the launch pair IS the autograd path's launches: bit for bit; the one-launch step pools out of the last layer's
+    # accumulators (another grouping of the same row sums): float rounding
+    same = pool_order_close if one_launch else torch.equal
+    assert same(rs.pred, pred.detach())
+    assert same(rs.score, score)
+    assert same(rs.loss, loss.detach())
     got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert got.keys() == grads.keys()
     for n in grads:
@@ -285,10 +288,10 @@ def test_scn_one_launch_step_against_the_launch_pair(name, B, K, H, act, dtype):
 def test_one_launch_step_against_the_launch_pair_at_full_occupancy(name, B, K, H, L, C, dtype):
     """The one-launch step with every CU busy (up to 2B = 256 workgroups: B local programs, B virtual-branch
     programs that recompute the local chain they read) and graphs of very different sizes, eager and replayed,
-    40 times: prediction, score, loss and the final virtual features equal the launch pair's bit for bit every
-    time; the gradients equal them to float rounding (H = 16 groups the weight gradient's partial sums by row
-    tile) and are bitwise identical from run to run."""
-    from tests.helpers import grads_close
+    40 times: the final virtual features equal the launch pair's bit for bit every time; prediction, score and the
+    gradients equal them to float rounding (the one-launch step pools out of the last layer's accumulators and, at
+    H = 16, groups the weight gradient's partial sums by row tile) and are bitwise identical from run to run."""
+    from tests.helpers import grads_close, pool_order_close
     from graph_hscn.config.config import ACT_DICT
     from graph_hscn.data import HeteroBatch
     from graph_hscn.loader.hetero_data import hetero_from_clusters
@@ -326,10 +329,11 @@ def test_one_launch_step_against_the_launch_pair_at_full_occupancy(name, B, K, H
             one.run()
         torch.cuda.synchronize()
         assert torch.equal(one.virtual, pair.virtual), it
-        assert torch.equal(one.pred, pair.pred) and torch.equal(one.score, pair.score), it
         if it == 0:
-            first = one.grads.clone()
-            assert grads_close(one.grads[:-1], pair.grads[:-1]) and torch.equal(one.grads[-1], pair.grads[-1])
+            first, first_pred, first_score = one.grads.clone(), one.pred.clone(), one.score.clone()
+            assert pool_order_close(one.pred, pair.pred) and pool_order_close(one.score, pair.score)
+            assert grads_close(one.grads[:-1], pair.grads[:-1], rel=1e-5) and pool_order_close(one.grads[-1], pair.grads[-1])
+        assert torch.equal(one.pred, first_pred) and torch.equal(one.score, first_score), it
         assert torch.equal(one.grads, first), it          # bitwise reproducible
     one.check()
 

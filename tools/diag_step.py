@@ -51,13 +51,13 @@ def main():
     rs.run()
     torch.cuda.synchronize()
     st = buf.cpu().numpy()
-    names = {0: "start", 1: "prologue + stage", 3: "two CSRs side by side"}
+    names = {0: "start", 1: "prologue + stage", 3: "two CSRs (two-barrier build)"}
     keys = [0, 1, 3]
     for l in range(Lyr):
         names[4 + l] = f"fwd L{l - 1} (+ publish)" if l else "(-)"
         keys.append(4 + l)
     names[12] = f"fwd L{Lyr - 1}"
-    names[13] = "pool + head + loss row"
+    names[13] = "head + loss row (wave 0)"
     names[14] = "head bwd + mask"
     keys += [12, 13, 14]
     for l in range(Lyr - 1, -1, -1):          # H = 16: one phase per backward layer
