@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming-spmm", action="store_true")
     ap.add_argument("--no-stage-a", action="store_true")
+    ap.add_argument("--no-stage-a-dense", action="store_true",
+                    help="skip the secondary line `stage_a_dense` (BASELINE.json configs[3]: PascalVOC-SP-shaped graphs, "
+                         "B = 128, K = 64, MinCUT coarsening step on the dense MFMA route, with its MFMA roofline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -372,6 +375,10 @@ def time_steps(ts, steps, warmup, barrier, settle_s=0.0):
 
 
 def stage_a_main(args):
+    print(json.dumps(stage_a_line(args)))
+
+
+def stage_a_line(args):
     """--stage a: one MinCUT coarsening step (reference train/train_clustering.py:37-49 for a batch of graphs) as
     the reported line.  --route dense is BASELINE.json configs[3]: to_dense_adj + dense_mincut_pool with A S,
     S^T(A S), S^T S, S^T X on the matrix cores; the roofline is the MFMA one of the A S launch
@@ -388,8 +395,8 @@ def stage_a_main(args):
     shape, B0, K, C, loss_fn = WORKLOADS[args.workload]
     B = args.batch or B0
     rng = np.random.default_rng(args.seed)
-    fixed_n = int(round(SHAPES[shape].n_mean)) if args.route == "dense" else None
-    graphs = [make_graph(rng, SHAPES[shape], n=fixed_n) for _ in range(B)]
+    fixed_n = None      # (round 2 gave every graph n = 479 on the dense route; graphs of any sizes share a batch now)
+    graphs = [make_graph(rng, SHAPES[shape]) for _ in range(B)]
     F = graphs[0].x.size(1)
     torch.manual_seed(1)
     scn = SCN([16], "elu", F, K, mincut_route=args.route).to(dev)
@@ -414,9 +421,15 @@ def stage_a_main(args):
         step = eager_step
         issue = ("eager (layered operators + csrc/dense.hip through autograd)" if args.route == "dense" else
                  "eager (layered operators through autograd: the graphs do not fit the fused stage-A launch at this K)")
-        # (not replayed from a hipGraph: the layered gcn_norm selects its self loops with a boolean mask -- a
-        # data-dependent shape -- which a stream capture refuses; the line is host-bound, the roofline below times the
-        # dominant C call by itself)
+        if args.route == "dense" and args.mode == "graph":
+            # every launch of the dense route has a host-known shape (gcn_norm_static, A + I straight from the raw
+            # edges, ragged contractions): the whole step -- forward, losses, backward -- replays from one hipGraph
+            try:
+                gd = capture(eager_step)
+                step = gd.replay
+                issue = "hipGraph replay of the layered operators + csrc/dense.hip (autograd captured once)"
+            except RuntimeError as e:      # pragma: no cover
+                issue += f" [capture refused: {str(e)[:80]}]"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -457,14 +470,15 @@ def stage_a_main(args):
         cached = {"structure_build": "cached after the first visit (hscn_scn_structure)", "ms_per_step": 1e3 * dt2 / args.steps,
                   "graphs_per_s": B * args.steps / dt2}
     if args.route == "dense":
-        # the dominant launch: A S (a [n,n] x [n,K] product per graph) inside hscn_mincut_dense_fwd -- time the C call
-        n = fixed_n
-        timer = KernelTimer(["hscn_mincut_dense_fwd", "hscn_mincut_dense_bwd"])
+        # the dominant launch: A S (a [n,n] x [n,K] product per graph) inside hscn_mincut_dense_ragged_fwd -- time the C call
+        sizes = np.array([int(g.num_nodes) for g in graphs], dtype=np.float64)
+        timer = KernelTimer(["hscn_mincut_dense_fwd", "hscn_mincut_dense_bwd", "hscn_mincut_dense_ragged_fwd",
+                             "hscn_mincut_dense_ragged_bwd"])
         orig = _hip.call
         Fh.call = lambda name, *a: timer.wrap(name, lambda *b: orig(name, *b), *a)
         for _ in range(5):
             torch.cuda._sleep(400000)
-            step()
+            eager_step()
         torch.cuda.synchronize()
         Fh.call = orig
 
@@ -480,17 +494,21 @@ def stage_a_main(args):
             e_.record()
             torch.cuda.synchronize()
             return s_.elapsed_time(e_) * 1e-3 / 20
-        t_f, t_b = avg("hscn_mincut_dense_fwd"), avg("hscn_mincut_dense_bwd")
-        fl_sas = B * (2.0 * K * n * n + 2.0 * n * K * K)               # S^T A S
-        fl_f = B * (2.0 * n * n * K + 2.0 * K * n * K + 2.0 * K * n * K + 2.0 * K * n * 16)   # + S^T S + S^T X
+        rag = any(ev[0].startswith("hscn_mincut_dense_ragged") for ev in timer.events)
+        t_f = avg("hscn_mincut_dense_ragged_fwd" if rag else "hscn_mincut_dense_fwd")
+        t_b = avg("hscn_mincut_dense_ragged_bwd" if rag else "hscn_mincut_dense_bwd")
+        # S^T A S = 2 K n^2 + 2 n K^2 flops per graph, summed over the batch's actual sizes
+        fl_sas = float(np.sum(2.0 * K * sizes * sizes + 2.0 * sizes * K * K))
+        fl_f = float(np.sum(2.0 * sizes * sizes * K + 2.0 * K * sizes * K + 2.0 * K * sizes * K + 2.0 * K * sizes * 16))   # + S^T S + S^T X
         PEAK = 157.3
         roofline = {"bound": "mfma", "kernel": "hscn_mincut_dense_fwd (softmax, k_bgemm A S, merged S^T(AS) | S^T S | S^T X, "
                     "statistics: v_mfma_f32_16x16x4_f32)", "achieved": fl_sas / t_f / 1e12, "peak": PEAK, "unit": "TFLOP/s",
                     "frac": fl_sas / t_f / 1e12 / PEAK, "traffic": None,
                     "flops_per_launch_SAS": fl_sas, "flops_per_launch_all_contractions": fl_f,
                     "frac_all_contractions": fl_f / t_f / 1e12 / PEAK, "avg_launch_us": t_f * 1e6,
-                    "bwd_launch_us": t_b * 1e6, "adjacency_bytes": B * n * n * 4,
-                    "adjacency_GBs_fwd": B * n * n * 4 / t_f / 1e9,
+                    "bwd_launch_us": t_b * 1e6, "adjacency_bytes": float(np.sum(sizes * sizes) * 4),
+                    "adjacency_GBs_fwd": float(np.sum(sizes * sizes) * 4) / t_f / 1e9,
+                    "nodes_per_graph_min_max": [int(sizes.min()), int(sizes.max())],
                     "note": "the C call spans several launches (softmax, A S, the merged cluster-space contractions, "
                             "statistics); MFMA-busy of the A S launch alone: profiles/*pmc_mfma_dense*.json"}
     out = {"metric": f"graphs/sec (fwd+bwd) on {args.workload} stage A (MinCUT coarsening)", "value": B * args.steps / dt,
@@ -502,7 +520,7 @@ def stage_a_main(args):
            "roofline": roofline, "cpu_baseline": None}
     if cached is not None:
         out["structure_cached"] = cached
-    print(json.dumps(out))
+    return out
 
 
 def _free_port():
@@ -892,6 +910,21 @@ def main():
                        "ms_per_step": ta * 1e3, "graphs_per_s": B / ta,
                        "combined_A_plus_C_graphs_per_s": B / (ta + dt / args.steps)}
 
+    # ---- secondary line: BASELINE.json configs[3] -- the MinCUT coarsening step on PascalVOC-SP-shaped graphs (real
+    # size spread, n in [395, 500]), 64 clusters, dense S^T A S route on the matrix cores, replayed from a hipGraph
+    stage_a_dense = None
+    if rank == 0 and world == 1 and not args.no_stage_a_dense and args.dtype == "f32":
+        import copy
+        a2 = copy.copy(args)
+        a2.workload, a2.route, a2.stage, a2.batch, a2.mode = "pascalvoc_sp", "dense", "a", None, "graph"
+        a2.steps, a2.warmup = max(20, min(args.steps, 100)), 10
+        try:
+            ln = stage_a_line(a2)
+            stage_a_dense = {"metric": ln["metric"], "value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"],
+                             "steps": a2.steps, "dtype": "f32", "config": ln["config"], "roofline": ln["roofline"]}
+        except RuntimeError as e:      # pragma: no cover
+            stage_a_dense = {"error": str(e)[:300]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(hb_host, args, C, loss_fn, args.cpu_seconds)
@@ -919,7 +952,7 @@ def main():
                                      ("captured in the step's hipGraph" if ts.in_graph_allreduce else "eager, after each replay")),
                        "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "one_step_per_graph": single, "other_cluster_ids": other_ids,
-            "streaming_spmm_scaled": streaming, "stage_a": stage_a, "repeats": repeats,
+            "streaming_spmm_scaled": streaming, "stage_a": stage_a, "stage_a_dense": stage_a_dense, "repeats": repeats,
         }
         out["config"]["allreduce_algorithm"] = None if reducer is None else args.allreduce
         if shared_gpus:

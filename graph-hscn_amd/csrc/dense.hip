@@ -42,6 +42,15 @@ struct BRhs {
   float* C;
   int N;
   int64_t ldb, ldc, sB, sC;
+  int ragB, ragC;   // ragged batch: the operand of batch b starts at row nptr[b] of ONE flat [N_total, ld] array
+};
+// A batch of graphs of DIFFERENT sizes (PascalVOC-SP: n in [395, 500]): node-indexed operands are flat
+// [N_total, width] arrays -- graph b owns rows [nptr[b], nptr[b + 1]) -- while per-graph matrices (the adjacency
+// [B, nmax, nmax], zero beyond n_b; the K x K cluster-space results) keep a uniform batch stride.
+// a: A is node-indexed;  m / k: M / Kd is this graph's node count n_b instead of the uniform argument.
+struct Rag {
+  const int32_t* nptr;
+  int a, m, k;
 };
 struct BRhs3 {
   BRhs r[3];
@@ -49,11 +58,18 @@ struct BRhs3 {
 template <int TA, int NT, int RS>
 __global__ void __launch_bounds__(256)
 k_bgemm(const float* __restrict__ A, const BRhs3 R, int M, int Kd, int64_t lda, int64_t sA,
-        float* __restrict__ rsum) {
+        float* __restrict__ rsum, const Rag G) {
   const float* __restrict__ Bm = R.r[blockIdx.z].B;
   float* __restrict__ C = R.r[blockIdx.z].C;
   const int N = R.r[blockIdx.z].N;
   const int64_t ldb = R.r[blockIdx.z].ldb, ldc = R.r[blockIdx.z].ldc, sB = R.r[blockIdx.z].sB, sC = R.r[blockIdx.z].sC;
+  const int row0 = G.nptr ? G.nptr[blockIdx.y] : 0;
+  if (G.nptr) {
+    const int nb = G.nptr[blockIdx.y + 1] - row0;
+    if (G.m) M = nb;
+    if (G.k) Kd = nb;
+    if ((int)blockIdx.x * GM >= M) return;      // (the grid is sized for the largest graph; the whole workgroup leaves)
+  }
   constexpr int AST = GK + 4;                           // padded row stride of the [m][k] image (bank spread, 16-B aligned)
   constexpr int ASZ = TA ? GK * GM : GM * AST;
   __shared__ __align__(16) float As[2][ASZ];          // TA=0: [m][k];  TA=1: [k][m] (stride GM)
@@ -62,9 +78,9 @@ k_bgemm(const float* __restrict__ A, const BRhs3 R, int M, int Kd, int64_t lda, 
   __shared__ __align__(16) float Bs[2][GK * BST];
   const int b = blockIdx.y;
   const int m0 = blockIdx.x * GM;
-  A += (size_t)b * sA;
-  Bm += (size_t)b * sB;
-  C += (size_t)b * sC;
+  A += (G.nptr && G.a) ? (size_t)row0 * lda : (size_t)b * sA;
+  Bm += (G.nptr && R.r[blockIdx.z].ragB) ? (size_t)row0 * ldb : (size_t)b * sB;
+  C += (G.nptr && R.r[blockIdx.z].ragC) ? (size_t)row0 * ldc : (size_t)b * sC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   f32x4 acc[NT];
@@ -169,7 +185,7 @@ k_bgemm(const float* __restrict__ A, const BRhs3 R, int M, int Kd, int64_t lda, 
   }
   if (RS && TA == 0 && (threadIdx.x & 3) == 0) {
     const int row = m0 + (threadIdx.x >> 2);
-    if (row < M) rsum[(size_t)b * M + row] = rs;
+    if (row < M) rsum[(G.nptr ? (size_t)row0 : (size_t)b * M) + row] = rs;
   }
   // C/D layout: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -226,7 +242,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // padded by one word (the row sums walk a row per thread).
 __global__ void __launch_bounds__(256)
 k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, const float* __restrict__ ss,
-                 float* __restrict__ oa, float* __restrict__ stats, int n, int K) {
+                 float* __restrict__ oa, float* __restrict__ stats, int n, int K, const int32_t* __restrict__ nptr) {
   extern __shared__ float lds[];
   const int KS = K + 1, KK = K * K;
   float* oal = lds;                  // [K][KS]
@@ -234,8 +250,10 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
   float* dn = ssl + K * KS;          // [K]
   float* red = dn + K;               // [4]
   const int g = blockIdx.x;
-  const float* Sg = S + (size_t)g * n * K;
-  const float* dg = deg + (size_t)g * n;
+  const size_t r0 = nptr ? (size_t)nptr[g] : (size_t)g * n;
+  if (nptr) n = nptr[g + 1] - nptr[g];
+  const float* Sg = S + r0 * K;
+  const float* dg = deg + r0;
   const float* ssg = ss + (size_t)g * KK;
   float* oag = oa + (size_t)g * KK;
   for (int idx = threadIdx.x; idx < KK; idx += 256) {
@@ -368,12 +386,13 @@ k_dense_gss(const float* __restrict__ stats, const float* __restrict__ ss, const
 __global__ void __launch_bounds__(256)
 k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const float* __restrict__ AtS,
             const float* __restrict__ SG, const float* __restrict__ deg, const float* __restrict__ stats,
-            const float* __restrict__ g_losses, float* __restrict__ g_logits, int n, int K, int G, int LPRp) {
-  const int64_t rows = (int64_t)G * n;
+            const float* __restrict__ g_losses, float* __restrict__ g_logits, int n, int K, int G, int LPRp,
+            const int32_t* __restrict__ gid, int64_t rows_total) {
+  const int64_t rows = gid ? rows_total : (int64_t)G * n;
   const int RPB = 256 / LPRp;
   const int rl = threadIdx.x / LPRp, fl = threadIdx.x % LPRp;
   for (int64_t r = (int64_t)blockIdx.x * RPB + rl; r < rows; r += (int64_t)gridDim.x * RPB) {
-    const int g = (int)(r / n);
+    const int g = gid ? gid[r] : (int)(r / n);
     const float num = stats[g * 4 + 0], den = stats[g * 4 + 1];
     const float gmc = g_losses[0] / (float)G;
     const float c_num = -gmc / den, c_den = gmc * num / (den * den);
@@ -402,7 +421,7 @@ k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const flo
 
 // nr products op(A) * B_z (z < nr <= 3) in one launch; NT covers the widest right-hand side
 int bgemm_multi(const float* A, const BRhs3& R, int nr, int64_t batch, int M, int Kd, int64_t lda, int64_t sA,
-                int transA, hipStream_t st, float* rsum = nullptr) {
+                int transA, hipStream_t st, float* rsum = nullptr, Rag G = Rag{nullptr, 0, 0, 0}) {
   int nmax = 0;
   for (int z = 0; z < nr; ++z) {
     if (R.r[z].N < 1 || R.r[z].N > GNMAX) return HSCN_E_UNSUPPORTED;
@@ -411,7 +430,7 @@ int bgemm_multi(const float* A, const BRhs3& R, int nr, int64_t batch, int M, in
   const int NT = (nmax + 15) / 16;
   dim3 grid((M + GM - 1) / GM, (unsigned)batch, (unsigned)nr);
   if (rsum && !transA && nr == 1) {   // A . B and the row sums of A in one pass
-#define HSCN_BGEMM_RS(NT_) k_bgemm<0, NT_, 1><<<grid, 256, 0, st>>>(A, R, M, Kd, lda, sA, rsum)
+#define HSCN_BGEMM_RS(NT_) k_bgemm<0, NT_, 1><<<grid, 256, 0, st>>>(A, R, M, Kd, lda, sA, rsum, G)
     switch (NT) {
       case 1: HSCN_BGEMM_RS(1); break;
       case 2: HSCN_BGEMM_RS(2); break;
@@ -422,7 +441,7 @@ int bgemm_multi(const float* A, const BRhs3& R, int nr, int64_t batch, int M, in
     HSCN_RETURN_IF_LAUNCH_FAILED();
     return 0;
   }
-#define HSCN_BGEMM(TA_, NT_) k_bgemm<TA_, NT_, 0><<<grid, 256, 0, st>>>(A, R, M, Kd, lda, sA, nullptr)
+#define HSCN_BGEMM(TA_, NT_) k_bgemm<TA_, NT_, 0><<<grid, 256, 0, st>>>(A, R, M, Kd, lda, sA, nullptr, G)
   if (transA) {
     switch (NT) {
       case 1: HSCN_BGEMM(1, 1); break;
@@ -444,10 +463,71 @@ int bgemm_multi(const float* A, const BRhs3& R, int nr, int64_t batch, int M, in
 }
 
 int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N, int Kd, int64_t lda, int64_t ldb,
-          int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int transA, hipStream_t st, float* rsum = nullptr) {
+          int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int transA, hipStream_t st, float* rsum = nullptr,
+          Rag G = Rag{nullptr, 0, 0, 0}, int ragB = 0, int ragC = 0) {
   BRhs3 R{};
-  R.r[0] = BRhs{Bm, C, N, ldb, ldc, sB, sC};
-  return bgemm_multi(A, R, 1, batch, M, Kd, lda, sA, transA, st, rsum);
+  R.r[0] = BRhs{Bm, C, N, ldb, ldc, sB, sC, ragB, ragC};
+  return bgemm_multi(A, R, 1, batch, M, Kd, lda, sA, transA, st, rsum, G);
+}
+
+// forward / backward of dense_mincut_pool for a batch of B graphs: n = the common node count (nptr == NULL: operands
+// [B, n, .]) or the LARGEST one (ragged: node-indexed operands flat [N, .], adjacency [B, n, n] zero beyond n_b)
+int mincut_dense_fwd_impl(const float* x, const float* adj, const float* logits, const int32_t* nptr, int64_t N,
+                          int64_t B, int n, int K, int F, float* S, float* AS, float* deg, float* stats, float* ss,
+                          float* pooled_x, float* pooled_adj, float* losses, hipStream_t st) {
+  const int64_t rows = nptr ? N : B * n;
+  {
+    int KP = 1;
+    while (KP < K) KP <<= 1;
+    unsigned nb = hscn_blocks(rows, 256 / KP);
+    if (nb > 16384) nb = 16384;
+    k_softmax_rows_d<<<nb, 256, 0, st>>>(logits, S, rows, K, KP);
+  }
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  int rc;
+  const int rg = nptr ? 1 : 0;
+  // A S, and deg = A . 1 from the same pass over the adjacency (0/1 entries: the sums are exact in any order)
+  if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st, deg,
+                  Rag{nptr, 0, 1, 1}, rg, rg)))
+    return rc;
+  // S^T (A S)  -> pooled_adj (raw), S^T S -> ss, S^T X -> pooled_x
+  {
+    BRhs3 R{};
+    R.r[0] = BRhs{AS, pooled_adj, K, K, K, (int64_t)n * K, (int64_t)K * K, rg, 0};
+    R.r[1] = BRhs{S, ss, K, K, K, (int64_t)n * K, (int64_t)K * K, rg, 0};
+    int nr = 2;
+    if (x && pooled_x && F > 0) R.r[nr++] = BRhs{x, pooled_x, F, F, F, (int64_t)n * F, (int64_t)K * F, rg, 0};
+    if ((rc = bgemm_multi(S, R, nr, B, K, n, K, (int64_t)n * K, 1, st, nullptr, Rag{nptr, 1, 0, 1}))) return rc;
+  }
+  k_dense_finalize<<<(unsigned)B, 256, (size_t)(2 * K * (K + 1) + K + 4) * 4, st>>>(S, deg, ss, pooled_adj, stats, n, K, nptr);
+  k_losses_d<<<1, 64, 0, st>>>(stats, losses, (int)B);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int mincut_dense_bwd_impl(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
+                          const float* ss, const float* g_losses, const int32_t* nptr, const int32_t* gid, int64_t N,
+                          int64_t B, int n, int K, float* AtS, float* sg_ws, float* gss_ws, float* g_logits,
+                          hipStream_t st) {
+  int rc;
+  const int rg = nptr ? 1 : 0;
+  if ((rc = bgemm(adj, S, AtS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 1, st, nullptr,
+                  Rag{nptr, 0, 1, 1}, rg, rg)))
+    return rc;
+  // Gss' (scaled) -> gss_ws [B,K,K];  SG = S Gss' -> sg_ws
+  k_dense_gss<<<(unsigned)B, 256, 0, st>>>(stats, ss, g_losses, gss_ws, K, (int)B);
+  if ((rc = bgemm(S, gss_ws, sg_ws, B, n, K, K, K, K, K, (int64_t)n * K, (int64_t)K * K, (int64_t)n * K, 0, st, nullptr,
+                  Rag{nptr, 1, 1, 0}, 0, rg)))
+    return rc;
+  int LPRp = 1;
+  while (LPRp * 4 < K) LPRp <<= 1;
+  const int64_t rows = nptr ? N : B * n;
+  int64_t nb = (rows + 256 / LPRp - 1) / (256 / LPRp);
+  if (nb > 8192) nb = 8192;
+  k_dense_bwd<<<(unsigned)nb, 256, 0, st>>>(S, AS, AtS, sg_ws, deg, stats, g_losses, g_logits, n, K, (int)B, LPRp,
+                                            nptr ? gid : nullptr, rows);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
 }
 
 }  // namespace
@@ -468,32 +548,8 @@ int hscn_mincut_dense_fwd(const float* x, const float* adj, const float* logits,
                           float* pooled_adj, float* losses, void* stream_) {
   if (B < 1 || n < 1 || K < 1 || K > GNMAX || F < 0 || F > GNMAX) return HSCN_E_BADARG;
   if (!adj || !logits || !S || !AS || !deg || !stats || !ss || !pooled_adj || !losses) return HSCN_E_BADARG;
-  hipStream_t st = hscn_stream(stream_);
-  const int64_t rows = B * n;
-  {
-    int KP = 1;
-    while (KP < K) KP <<= 1;
-    unsigned nb = hscn_blocks(rows, 256 / KP);
-    if (nb > 16384) nb = 16384;
-    k_softmax_rows_d<<<nb, 256, 0, st>>>(logits, S, rows, K, KP);
-  }
-  HSCN_RETURN_IF_LAUNCH_FAILED();
-  int rc;
-  // A S, and deg = A . 1 from the same pass over the adjacency (0/1 entries: the sums are exact in any order)
-  if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st, deg))) return rc;
-  // S^T (A S)  -> pooled_adj (raw), S^T S -> ss, S^T X -> pooled_x
-  {
-    BRhs3 R{};
-    R.r[0] = BRhs{AS, pooled_adj, K, K, K, (int64_t)n * K, (int64_t)K * K};
-    R.r[1] = BRhs{S, ss, K, K, K, (int64_t)n * K, (int64_t)K * K};
-    int nr = 2;
-    if (x && pooled_x && F > 0) R.r[nr++] = BRhs{x, pooled_x, F, F, F, (int64_t)n * F, (int64_t)K * F};
-    if ((rc = bgemm_multi(S, R, nr, B, K, n, K, (int64_t)n * K, 1, st))) return rc;
-  }
-  k_dense_finalize<<<(unsigned)B, 256, (size_t)(2 * K * (K + 1) + K + 4) * 4, st>>>(S, deg, ss, pooled_adj, stats, n, K);
-  k_losses_d<<<1, 64, 0, st>>>(stats, losses, (int)B);
-  HSCN_RETURN_IF_LAUNCH_FAILED();
-  return 0;
+  return mincut_dense_fwd_impl(x, adj, logits, nullptr, 0, B, n, K, F, S, AS, deg, stats, ss, pooled_x, pooled_adj,
+                               losses, hscn_stream(stream_));
 }
 
 int hscn_mincut_dense_bwd(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
@@ -502,20 +558,28 @@ int hscn_mincut_dense_bwd(const float* adj, const float* S, const float* AS, con
   if (B < 1 || n < 1 || K < 1 || K > GNMAX) return HSCN_E_BADARG;
   if (!adj || !S || !AS || !deg || !stats || !ss || !g_losses || !AtS || !sg_ws || !gss_ws || !g_logits)
     return HSCN_E_BADARG;
-  hipStream_t st = hscn_stream(stream_);
-  int rc;
-  if ((rc = bgemm(adj, S, AtS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 1, st))) return rc;
-  // Gss' (scaled) -> gss_ws [B,K,K];  SG = S Gss' -> g_logits (used as scratch, then overwritten row by row)
-  k_dense_gss<<<(unsigned)B, 256, 0, st>>>(stats, ss, g_losses, gss_ws, K, (int)B);
-  if ((rc = bgemm(S, gss_ws, sg_ws, B, n, K, K, K, K, K, (int64_t)n * K, (int64_t)K * K, (int64_t)n * K, 0, st))) return rc;
-  int LPRp = 1;
-  while (LPRp * 4 < K) LPRp <<= 1;
-  const int64_t rows = B * n;
-  int64_t nb = (rows + 256 / LPRp - 1) / (256 / LPRp);
-  if (nb > 8192) nb = 8192;
-  k_dense_bwd<<<(unsigned)nb, 256, 0, st>>>(S, AS, AtS, sg_ws, deg, stats, g_losses, g_logits, n, K, (int)B, LPRp);
-  HSCN_RETURN_IF_LAUNCH_FAILED();
-  return 0;
+  return mincut_dense_bwd_impl(adj, S, AS, deg, stats, ss, g_losses, nullptr, nullptr, 0, B, n, K, AtS, sg_ws, gss_ws,
+                               g_logits, hscn_stream(stream_));
+}
+
+int hscn_mincut_dense_ragged_fwd(const float* x, const float* adj, const float* logits, const int32_t* nptr, int64_t N,
+                                 int64_t B, int nmax, int K, int F, float* S, float* AS, float* deg, float* stats,
+                                 float* ss, float* pooled_x, float* pooled_adj, float* losses, void* stream_) {
+  if (B < 1 || N < 1 || nmax < 1 || K < 1 || K > GNMAX || F < 0 || F > GNMAX) return HSCN_E_BADARG;
+  if (!adj || !logits || !nptr || !S || !AS || !deg || !stats || !ss || !pooled_adj || !losses) return HSCN_E_BADARG;
+  return mincut_dense_fwd_impl(x, adj, logits, nptr, N, B, nmax, K, F, S, AS, deg, stats, ss, pooled_x, pooled_adj,
+                               losses, hscn_stream(stream_));
+}
+
+int hscn_mincut_dense_ragged_bwd(const float* adj, const float* S, const float* AS, const float* deg,
+                                 const float* stats, const float* ss, const float* g_losses, const int32_t* nptr,
+                                 const int32_t* gid, int64_t N, int64_t B, int nmax, int K, float* AtS, float* sg_ws,
+                                 float* gss_ws, float* g_logits, void* stream_) {
+  if (B < 1 || N < 1 || nmax < 1 || K < 1 || K > GNMAX) return HSCN_E_BADARG;
+  if (!adj || !S || !AS || !deg || !stats || !ss || !g_losses || !nptr || !gid || !AtS || !sg_ws || !gss_ws || !g_logits)
+    return HSCN_E_BADARG;
+  return mincut_dense_bwd_impl(adj, S, AS, deg, stats, ss, g_losses, nptr, gid, N, B, nmax, K, AtS, sg_ws, gss_ws,
+                               g_logits, hscn_stream(stream_));
 }
 
 }  // extern "C"

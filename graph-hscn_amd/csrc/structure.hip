@@ -225,6 +225,60 @@ __global__ void k_dense_adj_batched(const int64_t* __restrict__ row, const int64
   atomicAdd(&adj[(b * n + (r - b * n)) * n + (c - b * n)], 1.0f);
 }
 
+// block-diagonal batch of graphs of DIFFERENT sizes -> [B, nmax, nmax] (zero beyond a graph's n_b).  gid[i] = graph of
+// node i, nptr[b] = first node of graph b.  mode 0: adj[b, r, c] += 1 for every edge (to_dense_adj on the list as
+// given); mode 1: self loops of the list are skipped and the identity is added -- the adjacency
+// add_remaining_self_loops + to_dense_adj produce from RAW edges (every node ends with exactly one loop).
+// Threads [0, E) take the edges, threads [E, E + N) the diagonal.
+__global__ void k_dense_adj_ragged(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t E,
+                                   const int32_t* __restrict__ nptr, const int32_t* __restrict__ gid, int64_t N,
+                                   int64_t nmax, int mode, float* __restrict__ adj) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < E) {
+    const int64_t r = row[t], c = col[t];
+    if (r < 0 || r >= N || c < 0 || c >= N) return;
+    if (mode == 1 && r == c) return;
+    const int b = gid[r];
+    if (gid[c] != b) return;
+    const int64_t r0 = nptr[b];
+    atomicAdd(&adj[((int64_t)b * nmax + (r - r0)) * nmax + (c - r0)], 1.0f);
+  } else if (mode == 1 && t < E + N) {
+    const int64_t i = t - E;
+    const int b = gid[i];
+    const int64_t li = i - nptr[b];
+    atomicAdd(&adj[((int64_t)b * nmax + li) * nmax + li], 1.0f);
+  }
+}
+
+// gcn_norm's self-loop bookkeeping (PyG add_remaining_self_loops) with a STATIC output shape, so that
+// it can sit inside a captured stream: out = the E input edges IN PLACE followed by one loop per node.  An input edge
+// that is a self loop keeps its slot with weight 0 (PyG removes it from the front part: a zero-weight term adds
+// nothing to a degree and +0 to an aggregation, at the position the removed edge had), its weight moves to the
+// node's loop in the tail (several loops on one node: one of them wins, as with torch's index_put_); nodes without
+// one get `fill`.  Launch 1 (tail = false) writes the edge part and initialises the tail, launch 2 (tail = true) moves
+// the existing loops' weights.
+__global__ void k_gcn_norm_self_loops(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                      const float* __restrict__ w, int64_t E, int64_t N, float fill,
+                                      int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
+                                      float* __restrict__ w_out, bool tail) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!tail) {
+    if (t < E) {
+      const int64_t r = row[t], c = col[t];
+      row_out[t] = r;
+      col_out[t] = c;
+      w_out[t] = r == c ? 0.f : (w ? w[t] : 1.f);
+    } else if (t < E + N) {
+      row_out[t] = t - E;
+      col_out[t] = t - E;
+      w_out[t] = fill;
+    }
+  } else if (t < E) {
+    const int64_t r = row[t];
+    if (r == col[t] && r >= 0 && r < N) w_out[E + r] = w ? w[t] : 1.f;
+  }
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -342,6 +396,29 @@ int hscn_to_dense_adj_batched(const int64_t* row, const int64_t* col, int64_t E,
   if (E < 0 || n < 0 || B < 0 || (E > 0 && (!row || !col || !adj))) return HSCN_E_BADARG;
   if (E == 0 || B == 0) return 0;
   k_dense_adj_batched<<<hscn_blocks(E, 256), 256, 0, hscn_stream(stream_)>>>(row, col, E, B, n, adj);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_to_dense_adj_ragged(const int64_t* row, const int64_t* col, int64_t E, const int32_t* nptr, const int32_t* gid,
+                             int64_t N, int64_t B, int64_t nmax, int mode, float* adj, void* stream_) {
+  if (E < 0 || N < 0 || B < 0 || nmax < 0 || (mode != 0 && mode != 1)) return HSCN_E_BADARG;
+  if ((E > 0 && (!row || !col)) || !nptr || !gid || !adj) return HSCN_E_BADARG;
+  const int64_t work = E + (mode == 1 ? N : 0);
+  if (work == 0 || B == 0) return 0;
+  k_dense_adj_ragged<<<hscn_blocks(work, 256), 256, 0, hscn_stream(stream_)>>>(row, col, E, nptr, gid, N, nmax, mode, adj);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_gcn_norm_self_loops(const int64_t* row, const int64_t* col, const float* w, int64_t E, int64_t N, float fill,
+                             int64_t* row_out, int64_t* col_out, float* w_out, void* stream_) {
+  if (E < 0 || N < 0 || (E > 0 && (!row || !col)) || !row_out || !col_out || !w_out) return HSCN_E_BADARG;
+  if (E + N == 0) return 0;
+  hipStream_t st = hscn_stream(stream_);
+  k_gcn_norm_self_loops<<<hscn_blocks(E + N, 256), 256, 0, st>>>(row, col, w, E, N, fill, row_out, col_out, w_out, false);
+  if (E > 0)
+    k_gcn_norm_self_loops<<<hscn_blocks(E, 256), 256, 0, st>>>(row, col, w, E, N, fill, row_out, col_out, w_out, true);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -26,7 +26,8 @@ from torch import Tensor
 from ..config.config import ACT_DICT, CONV_DICT, HSCNConfig
 from ..nn import GATConv, GCNConv, GraphConv, HeteroConv, Linear
 from ..nn import functional as Fh
-from ..nn.pool import global_mean_pool, mincut_pool_sparse, to_dense_adj, to_dense_adj_batched
+from ..nn.pool import (global_mean_pool, mincut_pool_sparse, to_dense_adj, to_dense_adj_batched,
+                       to_dense_adj_ragged)
 from ..structure import Relation, relation_of
 from .. import engine as _engine
 
@@ -126,21 +127,49 @@ class SCN(nn.Module):
                                                           lin.weight, lin.bias)
             self.last_engine = "resident"
             return (S, mc, o, total) if with_total else (S, mc, o)
-        from ..nn.pool import gcn_norm
+        from ..nn.pool import gcn_norm, gcn_norm_static
         self.last_engine = "layered"
         if data.x.dtype == torch.float16:
             raise RuntimeError("half-precision feature storage runs on the fused stage-A launch only (mp_units=[H], "
                                "mlp_units=[], graphs that fit one CU's LDS)")
-        ei, ew = gcn_norm(data.edge_index.to(dev), None, int(data.num_nodes), add_self_loops=True)
-        node_ptr = data.ptr.to(dev).to(torch.int32) if "ptr" in data and data.ptr is not None else None
-        S, mc, o, _ = self.forward(data.x.to(dev).float(), ei, ew, node_ptr=node_ptr,
-                                   nodes_per_graph=getattr(data, "max_nodes", None) if node_ptr is not None else None)
+        raw_ei = data.edge_index if data.edge_index.is_cuda else data.edge_index.to(dev)
+        N = int(data.num_nodes)
+        batched = "ptr" in data and data.ptr is not None
+        if not self._dense():
+            ei, ew = gcn_norm(raw_ei, None, N, add_self_loops=True)
+            node_ptr = data.ptr.to(dev).to(torch.int32) if batched else None
+            S, mc, o, _ = self.forward(data.x.to(dev).float(), ei, ew, node_ptr=node_ptr)
+            return (S, mc, o, mc + o) if with_total else (S, mc, o)
+        # dense route: gcn_norm(add_self_loops=True) in its static-shape form and A + I straight from the raw edges --
+        # every launch has a shape known on the host, so the whole step (forward, losses, backward) can be captured
+        # and replayed as one hipGraph; graphs of any sizes share a batch
+        ei, ew = gcn_norm_static(raw_ei, None, N)
+        cached = getattr(data, "_dense_seg", None)
+        if cached is None or cached[0].device != dev:
+            if batched:
+                cached = (data.ptr.to(dev).to(torch.int32).contiguous(), data.batch.to(dev).to(torch.int32).contiguous(),
+                          int(data.max_nodes))
+            else:
+                cached = (torch.tensor([0, N], dtype=torch.int32, device=dev),
+                          torch.zeros(N, dtype=torch.int32, device=dev), N)
+            try:
+                data._dense_seg = cached
+            except AttributeError:
+                pass
+        node_ptr, gid, nmax = cached
+        S, mc, o, _ = self.forward(data.x.to(dev).float(), ei, ew, node_ptr=node_ptr, nodes_per_graph=nmax,
+                                   node_graph=gid, raw_edge_index=raw_ei)
         return (S, mc, o, mc + o) if with_total else (S, mc, o)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
-                node_ptr: Optional[Tensor] = None, nodes_per_graph: Optional[int] = None):
-        """``nodes_per_graph`` (dense route on a batch): the common node count of the batch's graphs -- a dense
-        [B,n,n] adjacency needs equally sized graphs (the reference's own call is one graph at a time)."""
+                node_ptr: Optional[Tensor] = None, nodes_per_graph: Optional[int] = None,
+                node_graph: Optional[Tensor] = None, raw_edge_index: Optional[Tensor] = None):
+        """Batched calls of the dense route (extensions; the reference's own call is one graph at a time):
+        ``nodes_per_graph`` = the LARGEST node count of the batch's graphs (the common one when they are equal),
+        ``node_graph`` int32 [N] = graph of every node -- needed when the graphs differ in size: the adjacency is then
+        [B, nmax, nmax] with zeros beyond each graph, node-indexed tensors stay flat, and every graph's loss terms
+        equal the single-graph call's.  ``raw_edge_index``: the edge list BEFORE gcn_norm added self loops, when
+        ``edge_index`` came from ``gcn_norm_static`` (whose zero-weight placeholders must not be counted)."""
         n = x.size(0)
         rel = relation_of(edge_index, n, n)
         x = self.mp(x.float(), rel, edge_weight)
@@ -157,9 +186,20 @@ class SCN(nn.Module):
             else:
                 Bg = int(node_ptr.numel()) - 1
                 ng = int(nodes_per_graph) if nodes_per_graph else 0
-                if ng <= 0 or Bg * ng != n:
-                    raise ValueError("the dense MinCUT route takes one graph, or a batch of equally sized graphs with "
-                                     "nodes_per_graph given (a dense [B,n,n] adjacency has one n)")
+                if ng <= 0:
+                    raise ValueError("the dense MinCUT route on a batch needs nodes_per_graph (the largest graph's node "
+                                     "count: it sizes the [B,n,n] adjacency)")
+            if node_ptr is not None and (Bg * ng != n or raw_edge_index is not None):
+                if node_graph is None:
+                    raise ValueError("graphs of different sizes on the dense MinCUT route need node_graph (int32 [N])")
+                # ragged batch: A + I of every graph in its own [nmax, nmax] block, node-indexed tensors flat
+                if raw_edge_index is not None:
+                    adj = to_dense_adj_ragged(raw_edge_index, node_ptr, node_graph, Bg, ng, raw=True)
+                else:
+                    adj = to_dense_adj_ragged(edge_index, node_ptr, node_graph, Bg, ng)
+                S, mc_loss, o_loss, _, _ = Fh.MinCutDenseRaggedFn.apply(s, x, adj, node_ptr, node_graph)
+                self.last_route = "dense-ragged"
+                return S, mc_loss, o_loss, None
             adj = to_dense_adj_batched(edge_index, Bg, ng)
             S, mc_loss, o_loss, _, _ = Fh.MinCutDenseFn.apply(s.view(Bg, ng, -1), x.view(Bg, ng, -1), adj)
             self.last_route = "dense"

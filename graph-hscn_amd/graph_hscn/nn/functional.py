@@ -377,6 +377,50 @@ def _pack_loss_grads(g_mc: Optional[Tensor], g_o: Optional[Tensor], dev) -> Tens
 # --------------------------------------------------------------------------- #
 # MinCUT pooling, dense route (matrix cores)
 # --------------------------------------------------------------------------- #
+class MinCutDenseRaggedFn(Function):
+    """``MinCutDenseFn`` for a batch of graphs of DIFFERENT sizes: (logits [N,K], x [N,F] | None, adj [B,nmax,nmax]
+    zero beyond each graph, nptr int32 [B+1], gid int32 [N]) -> (S [N,K], mincut, ortho, pooled_x, pooled_adj);
+    losses = mean over graphs, every graph's terms equal to the single-graph call's (hscn_mincut_dense_ragged_*)."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, x: Optional[Tensor], adj: Tensor, nptr: Tensor, gid: Tensor):
+        logits, x, adj = _c(logits), _c(x), _c(adj)
+        N, K = logits.shape
+        B, nmax = adj.shape[0], adj.shape[1]
+        dev = logits.device
+        Fx = x.shape[1] if x is not None else 0
+        S = torch.empty_like(logits)
+        AS = torch.empty_like(logits)
+        deg = torch.empty(N, dtype=torch.float32, device=dev)
+        stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        ss = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+        px = torch.empty(B, K, Fx, dtype=torch.float32, device=dev) if x is not None else None
+        padj = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        call("hscn_mincut_dense_ragged_fwd", ptr(x), ptr(adj), ptr(logits), ptr(nptr), N, B, nmax, K, Fx, ptr(S), ptr(AS),
+             ptr(deg), ptr(stats), ptr(ss), ptr(px), ptr(padj), ptr(losses), stream())
+        ctx.save_for_backward(adj, S, AS, deg, stats, ss, nptr, gid)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(S, padj)
+        if px is not None:
+            ctx.mark_non_differentiable(px)
+        return S, losses[0], losses[1], px, padj
+
+    @staticmethod
+    def backward(ctx, gS, g_mc, g_o, g_px, g_padj):
+        adj, S, AS, deg, stats, ss, nptr, gid = ctx.saved_tensors
+        N, K = S.shape
+        B, nmax = adj.shape[0], adj.shape[1]
+        gl = _pack_loss_grads(g_mc, g_o, S.device)
+        AtS = torch.empty_like(S)
+        SG = torch.empty_like(S)
+        Gss = torch.empty_like(ss)
+        g_logits = torch.empty_like(S)
+        call("hscn_mincut_dense_ragged_bwd", ptr(adj), ptr(S), ptr(AS), ptr(deg), ptr(stats), ptr(ss), ptr(gl), ptr(nptr),
+             ptr(gid), N, B, nmax, K, ptr(AtS), ptr(SG), ptr(Gss), ptr(g_logits), stream())
+        return g_logits, None, None, None, None
+
+
 class MinCutDenseFn(Function):
     """(logits [B,n,K], x [B,n,F] | None, adj [B,n,n]) -> (S, mincut, ortho, pooled_x, pooled_adj).
     Gradients flow from the two losses to ``logits``."""

@@ -45,6 +45,44 @@ def to_dense_adj_batched(edge_index: Tensor, num_graphs: int, nodes_per_graph: i
     return adj
 
 
+def to_dense_adj_ragged(edge_index: Tensor, nptr: Tensor, gid: Tensor, num_graphs: int, max_nodes: int,
+                        raw: bool = False) -> Tensor:
+    """``to_dense_adj(edge_index, batch)`` for a block-diagonal batch of graphs of different sizes: ``[B, nmax, nmax]``,
+    zero beyond a graph's own nodes.  ``raw=True``: ``edge_index`` is the RAW edge list and the result is what
+    ``gcn_norm(add_self_loops=True)`` followed by ``to_dense_adj`` gives -- off-diagonal counts plus the identity
+    (train/train_clustering.py:37-42, model/hscn.py:61) -- without building the self-looped list first."""
+    B, n = int(num_graphs), int(max_nodes)
+    adj = torch.zeros(B, n, n, dtype=torch.float32, device=edge_index.device)
+    call("hscn_to_dense_adj_ragged", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()),
+         edge_index.size(1), ptr(nptr), ptr(gid), int(gid.numel()), B, n, 1 if raw else 0, ptr(adj), stream())
+    return adj
+
+
+def gcn_norm_static(edge_index: Tensor, edge_weight: Optional[Tensor] = None, num_nodes: Optional[int] = None,
+                    improved: bool = False) -> Tuple[Tensor, Tensor]:
+    """``gcn_norm(add_self_loops=True)`` with a STATIC output shape ``[2, E + N]`` (no boolean-mask indexing, no
+    data-dependent size: the whole of it can sit inside a hipGraph capture).  The E input edges keep their slots -- an
+    input self loop stays in place with weight 0 and hands its weight to the node's loop -- then one loop per node.
+    Degrees, normalised weights and every aggregation over this list equal PyG's over its (shorter) list: a
+    zero-weight edge adds nothing to a degree and +0 to a sum, at the position the removed edge had.  What differs
+    is the list's LENGTH when the input has self loops: ``gcn_norm`` (above) stays the drop-in for callers that look
+    at the returned ``edge_index``; stage A's layered route uses this one."""
+    if num_nodes is None:
+        raise ValueError("gcn_norm_static needs num_nodes (reading edge_index.max() would synchronise)")
+    N, E = int(num_nodes), int(edge_index.size(1))
+    dev = edge_index.device
+    ei = torch.empty(2, E + N, dtype=torch.int64, device=dev)
+    w_in = torch.empty(E + N, dtype=torch.float32, device=dev)
+    call("hscn_gcn_norm_self_loops", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()),
+         ptr(edge_weight.contiguous()) if edge_weight is not None else None, E, N, 2.0 if improved else 1.0,
+         ptr(ei[0]), ptr(ei[1]), ptr(w_in), stream())
+    csr = build_csr(ei[1], ei[0], N, N)
+    dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+    w = torch.empty(max(E + N, 1), dtype=torch.float32, device=dev)
+    call("hscn_gcn_norm_weights", ptr(csr.rowptr), ptr(csr.col), ptr(csr.eid), ptr(w_in), N, ptr(dinv), ptr(w), stream())
+    return ei, w[: E + N]
+
+
 def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor] = None, num_nodes: Optional[int] = None,
              improved: bool = False, add_self_loops: bool = True,
              dtype: torch.dtype = torch.float32) -> Tuple[Tensor, Tensor]:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 14
+#define HSCN_ABI_VERSION 15
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -213,6 +213,21 @@ int hscn_mincut_sparse_bwd(const float* S, const float* stats, const float* ss,
                            const float* g_losses /*[2] device*/, float* g_logits,
                            int64_t num_nodes, int64_t num_graphs, int K, void* stream);
 
+/* The same for a batch of graphs of DIFFERENT sizes (BASELINE.json configs[3]: PascalVOC-SP, n in [395, 500]; the
+ * reference's own call is one graph at a time, model/hscn.py:61-63, so any n per call must work): node-indexed
+ * operands (logits, x, S, AS, deg, AtS, sg_ws, g_logits) are flat [N, width] arrays -- graph b owns rows
+ * [nptr[b], nptr[b + 1]) -- the adjacency is [B, nmax, nmax] with zeros beyond a graph's n_b (nmax = the largest n_b),
+ * the per-graph results (stats [B,4], ss / pooled_adj [B,K,K], pooled_x [B,K,F]) keep their shapes.  gid [N] int32 = graph
+ * of every node.  Values per graph identical to the uniform entry points on that graph alone; losses = mean over graphs. */
+int hscn_mincut_dense_ragged_fwd(const float* x /*[N,F] or NULL*/, const float* adj /*[B,nmax,nmax]*/,
+                                 const float* logits /*[N,K]*/, const int32_t* nptr /*[B+1]*/, int64_t N, int64_t B,
+                                 int nmax, int K, int F, float* S, float* AS, float* deg /*[N]*/, float* stats,
+                                 float* ss, float* pooled_x, float* pooled_adj, float* losses /*[2]*/, void* stream);
+int hscn_mincut_dense_ragged_bwd(const float* adj, const float* S, const float* AS, const float* deg,
+                                 const float* stats, const float* ss, const float* g_losses /*[2]*/,
+                                 const int32_t* nptr, const int32_t* gid /*[N]*/, int64_t N, int64_t B, int nmax, int K,
+                                 float* AtS, float* sg_ws, float* gss_ws /*[B,K,K]*/, float* g_logits, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * a6  dense_mincut_pool, dense route on the matrix cores (reference model/hscn.py:61-63
  * with the dense [B,n,n] adjacency PyG's to_dense_adj builds; BASELINE config 4).
@@ -271,6 +286,20 @@ int hscn_to_dense_adj(const int64_t* row, const int64_t* col, int64_t num_edges,
  * to_dense_adj(edge_index, batch) gives for equally sized graphs -- the input of the dense MinCUT route */
 int hscn_to_dense_adj_batched(const int64_t* row, const int64_t* col, int64_t E, int64_t B, int64_t n, float* adj,
                               void* stream);
+/* to_dense_adj(edge_index, batch) for graphs of different sizes: adj [B, nmax, nmax], ZERO on entry.  mode 0: every
+ * edge of the list counts (to_dense_adj on the list as given, reference model/hscn.py:61); mode 1: the list's self
+ * loops are skipped and the identity added -- what gcn_norm's add_remaining_self_loops followed by to_dense_adj
+ * (train/train_clustering.py:37-42 then model/hscn.py:61) yields from RAW edges. */
+int hscn_to_dense_adj_ragged(const int64_t* row, const int64_t* col, int64_t E, const int32_t* nptr /*[B+1]*/,
+                             const int32_t* gid /*[N]*/, int64_t N, int64_t B, int64_t nmax, int mode, float* adj,
+                             void* stream);
+/* gcn_norm's self-loop bookkeeping (PyG add_remaining_self_loops; train/train_clustering.py:37-42) with a STATIC output
+ * shape [E + N] -- capturable, no data-dependent size: the E input edges keep their slots (an input self loop stays
+ * in place with weight 0, its weight moves to the node's loop), then one loop per node (weight = the moved one or
+ * `fill`).  Degrees and aggregations over this list equal PyG's over its shorter one. */
+int hscn_gcn_norm_self_loops(const int64_t* row, const int64_t* col, const float* w /*[E] or NULL = ones*/, int64_t E,
+                             int64_t N, float fill, int64_t* row_out /*[E+N]*/, int64_t* col_out, float* w_out,
+                             void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Collate on the device (reference: the PyG DataLoader collates HeteroData on the host for every step,

@@ -16,7 +16,7 @@ def main():
     rounds = int(sys.argv[1])
     names = sys.argv[2:]
     extra = os.environ.get("AB_ARGS", "").split()
-    res = {n: ([], []) for n in names}
+    res = {n: ([], [], []) for n in names}
     for r in range(rounds):
         for n in names:
             base, *envs = n.split(":")                      # "ship:HSCN_STEP_FIXED_LAYOUT=0": the same build under an env
@@ -26,7 +26,7 @@ def main():
                 k, v = kv.split("=", 1)
                 env[k] = v
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "400", "--warmup", "40", "--no-cpu-baseline",
-                                  "--no-streaming-spmm", "--no-stage-a", "--repeats", "4"] + extra, env=env, stdout=subprocess.PIPE,
+                                  "--no-streaming-spmm", "--no-stage-a-dense", "--repeats", "4"] + extra, env=env, stdout=subprocess.PIPE,
                                  stderr=subprocess.DEVNULL, timeout=300)
             if out.returncode != 0:
                 print(f"{n}: bench failed rc={out.returncode}", flush=True)
@@ -35,12 +35,15 @@ def main():
             res[n][0].append(d["repeats"]["median_ms_per_step_incl_first"])
             if d.get("other_cluster_ids"):
                 res[n][1].append(d["other_cluster_ids"]["ms_per_step"])
-            print(f"round {r} {n:36s} {1e3 * res[n][0][-1]:7.2f} us   uniform ids {1e3 * (res[n][1][-1] if res[n][1] else float('nan')):7.2f} us", flush=True)
+            if d.get("stage_a"):
+                res[n][2].append(d["stage_a"]["ms_per_step"])
+            print(f"round {r} {n:36s} {1e3 * res[n][0][-1]:7.2f} us   uniform ids {1e3 * (res[n][1][-1] if res[n][1] else float('nan')):7.2f} us   stage A {1e3 * (res[n][2][-1] if res[n][2] else float('nan')):7.2f} us", flush=True)
     print("---- summary (us per step: median over rounds, min)")
     for n in names:
-        a, b = res[n]
+        a, b, c = res[n]
         if a:
-            print(f"{n:36s} default {1e3 * statistics.median(a):7.2f} ({1e3 * min(a):7.2f})   uniform {1e3 * statistics.median(b):7.2f} ({1e3 * min(b):7.2f})")
+            print(f"{n:36s} default {1e3 * statistics.median(a):7.2f} ({1e3 * min(a):7.2f})   uniform {1e3 * statistics.median(b):7.2f} ({1e3 * min(b):7.2f})"
+                  + (f"   stage A {1e3 * statistics.median(c):7.2f} ({1e3 * min(c):7.2f})" if c else ""))
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ import sys
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "-n"], input="\n".join(names), capture_output=True, text=True).stdout
         return out.splitlines()
     except OSError:
         return names
