@@ -10,6 +10,7 @@
 // MFMA-bound only at PascalVOC-SP sizes (n ~ 480, K = 64: 33 MFLOP per graph); at Peptides
 // sizes the sparse route (mincut.hip) does 8x less work.
 #include "hscn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -197,6 +198,441 @@ k_bgemm(const float* __restrict__ A, const BRhs3 R, int M, int Kd, int64_t lda, 
       if (row < M && col < N) C[(size_t)row * ldc + col] = acc[t][r];
     }
   }
+}
+
+// ---- the adjacency products A S (and A^T S for the backward) on v_mfma_f32_32x32x2_f32 -----------------------------
+// C[b] (n_b x K) = op(A[b]) (n_b x n_b) * S[b] (n_b x K), K <= 64: by far the largest contraction of the dense route
+// (2 K n^2 of the 2 K n^2 + 2 n K^2 flops SURVEY.md 8(d) counts; 33 MFLOP per PascalVOC-SP graph).
+// A workgroup (4 waves) owns 128 rows of one graph; a wave owns 32 of them across all K columns -- NT accumulators of
+// 32 x 32 -- and walks the reduction in slabs of 32: 16 x NT back-to-back MFMAs per slab, 64 cycles each (the f32 MFMA
+// peak: 64 FLOP / clk / SIMD).  Both operands are staged through LDS, two stages, the next slab travelling
+// HBM -> registers under the current slab's MFMAs (one barrier per slab):
+//   A image  [k][m] (k-major, row stride 132 words): an MFMA operand read is 32 consecutive words per half wave;
+//            the transpose of a row-major adjacency tile happens in the staging stores (TA = 0), A^T needs none (TA = 1);
+//   S image  [k][n] row-major.
+// AT = float: the adjacency as dense_mincut_pool's caller hands it over ([B, nmax, nmax] floats: 4 n^2 bytes per graph
+// and pass -- 111 MB for a PascalVOC-SP batch, which makes the product HBM-bound);
+// AT = uint8_t: the counts as bytes ([B, nmax, lda8], lda8 = nmax rounded up to 32, zero filled; what the model's own
+// batched route builds): 4x less traffic, converted exactly on the way into LDS (v_cvt_f32_ubyte*).
+// RS (TA = 0): also the row sums of A (degrees), from the LDS image.
+template <typename AT, int TA, int NT, bool RS>
+__global__ void __launch_bounds__(256)
+k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
+        const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  constexpr int BM = 128, BK = 32, AS_ST = BM + 4, BS_ST = 64;
+  __shared__ __align__(16) float As[2][BK * AS_ST];
+  __shared__ __align__(16) float Bs[2][BK * BS_ST];
+  __shared__ float rs_red[256];
+  const int b = blockIdx.y, m0 = blockIdx.x * BM;
+  const int row0 = nptr ? nptr[b] : b * n_uniform;
+  const int n = nptr ? nptr[b + 1] - row0 : n_uniform;
+  if (m0 >= n) return;
+  const AT* Ab = adj + (size_t)b * nmax * lda;
+  const float* Sb = S + (size_t)row0 * K;
+  float* Cb = C + (size_t)row0 * K;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  // staging registers: the A slab is 128 x 32 (TA = 0) or 32 x 128 (TA = 1) elements, 16 per thread; the S slab 32 x 64
+  float ra[16];
+  float4 rb[2];
+  auto fetch = [&](int k0) {
+    if constexpr (sizeof(AT) == 1) {
+      // 16 consecutive bytes per thread (rows are padded to 32 and zero filled: no column guard)
+      const int r = TA ? (t >> 3) : (t >> 1), c16 = TA ? (t & 7) * 16 : (t & 1) * 16;
+      const int gr = TA ? k0 + r : m0 + r, gc = TA ? m0 + c16 : k0 + c16;
+      uint4 w = make_uint4(0u, 0u, 0u, 0u);
+      if (gr < n && gc < lda) w = *reinterpret_cast<const uint4*>(Ab + (size_t)gr * lda + gc);
+      const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ra[4 * j + 0] = (float)(ww[j] & 0xffu);
+        ra[4 * j + 1] = (float)((ww[j] >> 8) & 0xffu);
+        ra[4 * j + 2] = (float)((ww[j] >> 16) & 0xffu);
+        ra[4 * j + 3] = (float)(ww[j] >> 24);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // TA = 0: rows m0 + (t>>3) + 32u, four columns k0 + 4 (t&7);  TA = 1: rows k0 + (t>>5) + 8u, columns m0 + 4 (t&31)
+        const int gr = TA ? k0 + (t >> 5) + 8 * u : m0 + (t >> 3) + 32 * u;
+        const int gc = TA ? m0 + (t & 31) * 4 : k0 + (t & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < n) {
+          const float* p = reinterpret_cast<const float*>(Ab) + (size_t)gr * lda + gc;
+          if (gc + 3 < n) v = ld4u(p);
+          else {
+            if (gc < n) v.x = p[0];
+            if (gc + 1 < n) v.y = p[1];
+            if (gc + 2 < n) v.z = p[2];
+          }
+        }
+        ra[4 * u + 0] = v.x; ra[4 * u + 1] = v.y; ra[4 * u + 2] = v.z; ra[4 * u + 3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int gr = k0 + (t >> 4) + 16 * u, c4 = (t & 15) * 4;
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < n && c4 < K) {
+        const float* p = Sb + (size_t)gr * K + c4;
+        if (c4 + 3 < K) rb[u] = ld4u(p);
+        else {
+          rb[u].x = p[0];
+          if (c4 + 1 < K) rb[u].y = p[1];
+          if (c4 + 2 < K) rb[u].z = p[2];
+        }
+      }
+    }
+  };
+  auto park = [&](int buf) {
+    float* as = As[buf];
+    if constexpr (sizeof(AT) == 1) {
+      if (TA) {      // 16 consecutive m of row k
+        const int k = t >> 3, c16 = (t & 7) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(&as[k * AS_ST + c16 + 4 * j]) = make_float4(ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]);
+      } else {       // 16 consecutive k of row m: transposed on the way in
+        const int m = t >> 1, c16 = (t & 1) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) as[(c16 + j) * AS_ST + m] = ra[j];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (TA) {
+          const int k = (t >> 5) + 8 * u, m4 = (t & 31) * 4;
+          *reinterpret_cast<float4*>(&as[k * AS_ST + m4]) = make_float4(ra[4 * u], ra[4 * u + 1], ra[4 * u + 2], ra[4 * u + 3]);
+        } else {
+          const int m = (t >> 3) + 32 * u, k4 = (t & 7) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) as[(k4 + j) * AS_ST + m] = ra[4 * u + j];
+        }
+      }
+    }
+    float* bs = Bs[buf];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&bs[((t >> 4) + 16 * u) * BS_ST + (t & 15) * 4]) = rb[u];
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  float rs = 0.f;
+  for (int k0 = 0; k0 < n; k0 += BK) {
+    const bool more = k0 + BK < n;
+    if (more) fetch(k0 + BK);
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
+    if (RS && !TA) {      // thread (m = t & 127, half = t >> 7) adds 16 of the slab's 32 entries of row m
+      const float* p = as + (t >> 7) * 16 * AS_ST + (t & 127);
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) q += p[j * AS_ST];
+      rs += q;
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = as[(kk + lh) * AS_ST + wave * 32 + li];
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const float bv = bs[(kk + lh) * BS_ST + q * 32 + li];
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[q], 0, 0, 0);
+      }
+    }
+    if (more) park(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (RS && !TA) {
+    rs_red[t] = rs;
+    __syncthreads();
+    if (t < 128 && m0 + t < n) rsum[(size_t)row0 + m0 + t] = rs_red[t] + rs_red[t + 128];
+  }
+  // C/D layout of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int col = q * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < n && col < K) Cb[(size_t)row * K + col] = acc[q][r];
+    }
+  }
+}
+
+// ---- A S with the adjacency read STRAIGHT INTO THE MATRIX-CORE OPERAND REGISTERS (TA = 0) ------------------------
+// v_mfma_f32_32x32x2_f32 takes A[i = lane & 31][k = lane >> 5]: which two values of k a step multiplies is free as long
+// as both operands agree.  Step j of a 32-deep slab uses k = 16 h + j for lane half h, so lane (i, h) needs exactly
+// the 16 consecutive entries A[row i][k0 + 16 h .. + 15]: ONE 16-byte load of byte counts (four of floats), no LDS
+// image of the adjacency, no transposing stores, nothing of A behind the slab barrier.  The loads run two slabs ahead
+// (4 registers per slab for bytes); only the S slab (L2-resident, shared by the graph's workgroups) goes through LDS,
+// read as rows 16 h + j.  The row sums (degrees) are the sums of the operands a lane feeds, its two halves folded by
+// one cross-half shuffle.
+template <typename AT, int NT, bool RS>
+__global__ void __launch_bounds__(256)
+k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
+               const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  constexpr int BM = 128, BK = 32, BS_ST = 64;
+  constexpr bool U8 = sizeof(AT) == 1;
+  constexpr int AR = U8 ? 4 : 16;           // registers of one slab's A entries
+  __shared__ __align__(16) float Bs[2][BK * BS_ST];
+  const int b = blockIdx.y, m0 = blockIdx.x * BM;
+  const int row0 = nptr ? nptr[b] : b * n_uniform;
+  const int n = nptr ? nptr[b + 1] - row0 : n_uniform;
+  if (m0 >= n) return;
+  // blockIdx.z: which slice of 32 NT columns of S (and C) this workgroup multiplies -- with byte adjacency re-reading A
+  // per slice is cheap, and twice the waves hide each other's slab barriers and operand latencies
+  const int c0 = blockIdx.z * 32 * NT;
+  const AT* Ab = adj + (size_t)b * nmax * lda;
+  const float* Sb = S + (size_t)row0 * K + c0;
+  float* Cb = C + (size_t)row0 * K + c0;
+  const int Kc = K - c0;      // columns left from c0 on
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int row = m0 + wave * 32 + li;
+  const AT* arow = Ab + (size_t)(row < n ? row : 0) * lda + 16 * lh;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  auto fetchA = [&](int k0, unsigned (&ra)[AR]) {
+#pragma unroll
+    for (int u = 0; u < AR; ++u) ra[u] = 0u;
+    if (row < n && k0 < n) {
+      if constexpr (U8) {            // (rows are padded to 32 and zero filled: no column guard)
+        const uint4 w = *reinterpret_cast<const uint4*>(arow + k0);
+        ra[0] = w.x; ra[1] = w.y; ra[2] = w.z; ra[3] = w.w;
+      } else {
+        const float* p = reinterpret_cast<const float*>(arow) + k0;
+        const int c = k0 + 16 * lh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int cc = c + 4 * u;
+          if (cc + 3 < n) v = ld4u(p + 4 * u);
+          else {
+            if (cc < n) v.x = p[4 * u];
+            if (cc + 1 < n) v.y = p[4 * u + 1];
+            if (cc + 2 < n) v.z = p[4 * u + 2];
+          }
+          ra[4 * u] = __float_as_uint(v.x); ra[4 * u + 1] = __float_as_uint(v.y);
+          ra[4 * u + 2] = __float_as_uint(v.z); ra[4 * u + 3] = __float_as_uint(v.w);
+        }
+      }
+    }
+  };
+  auto a_of = [&](const unsigned (&ra)[AR], int j) -> float {
+    if constexpr (U8) return (float)((ra[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    else return __uint_as_float(ra[j]);
+  };
+  float4 rb[2];
+  auto fetchB = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int gr = k0 + (t >> 4) + 16 * u, c4 = (t & 15) * 4;
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < n && c4 < Kc && c4 < 32 * NT) {
+        const float* p = Sb + (size_t)gr * K + c4;
+        if (c4 + 3 < Kc) rb[u] = ld4u(p);
+        else {
+          rb[u].x = p[0];
+          if (c4 + 1 < Kc) rb[u].y = p[1];
+          if (c4 + 2 < Kc) rb[u].z = p[2];
+        }
+      }
+    }
+  };
+  auto parkB = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Bs[buf][((t >> 4) + 16 * u) * BS_ST + (t & 15) * 4]) = rb[u];
+  };
+  unsigned a0[AR], a1[AR], a2[AR];
+  fetchA(0, a0);
+  fetchA(BK, a1);
+  fetchB(0);
+  parkB(0);
+  __syncthreads();
+  int buf = 0;
+  float rs = 0.f;
+  for (int k0 = 0; k0 < n; k0 += BK) {
+    const bool more = k0 + BK < n;
+    fetchA(k0 + 2 * BK, a2);                  // two slabs ahead (past the end: zeros, no request)
+    if (more) fetchB(k0 + BK);
+    const float* bs = Bs[buf] + lh * 16 * BS_ST + li;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float a = a_of(a0, j);
+      if (RS) rs += a;
+#pragma unroll
+      for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[j * BS_ST + q * 32], acc[q], 0, 0, 0);
+    }
+    if (more) parkB(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+#pragma unroll
+    for (int u = 0; u < AR; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; }
+  }
+  if (RS) {
+    rs += __shfl_xor(rs, 32, 64);
+    if (lh == 0 && row < n && blockIdx.z == 0) rsum[(size_t)row0 + row] = rs;
+  }
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int col = q * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int orow = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (orow < n && col < Kc) Cb[(size_t)orow * K + col] = acc[q][r];
+    }
+  }
+}
+
+// ---- A S with BOTH operands in registers: no LDS, no workgroup barrier (TA = 0, byte or float adjacency) ----------
+// A wave owns a 32 x 32 tile of C: 32 rows of A times 32 columns of S.  Per 32-deep slab lane (i, h) loads its 16
+// adjacency entries A[row i][k0 + 16 h ..] (one 16-byte load of bytes, two slabs ahead) and the 16 entries
+// S[k0 + 16 h + j][c0 + (lane & 31)], j = 0 .. 15, of ITS column (16 dword loads, a half wave reads 128 contiguous
+// bytes per load; S is L2-resident and shared by the graph's waves; one slab ahead), then issues 16 MFMAs on one
+// accumulator.  Waves never wait for each other: what one wave's loads cost, the other waves of its SIMD cover.
+template <typename AT, bool RS>
+__global__ void __launch_bounds__(256)
+k_adj_s_reg(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
+            const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  constexpr int BK = 32;
+  constexpr bool U8 = sizeof(AT) == 1;
+  constexpr int AR = U8 ? 4 : 16;
+  const int b = blockIdx.y;
+  const int row0 = nptr ? nptr[b] : b * n_uniform;
+  const int n = nptr ? nptr[b + 1] - row0 : n_uniform;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int m0 = (blockIdx.x * 4 + wave) * 32;       // this wave's row tile
+  if (m0 >= n) return;                                // (no barrier below: a wave may leave alone)
+  const int c0 = blockIdx.z * 32;
+  const AT* Ab = adj + (size_t)b * nmax * lda;
+  const float* Sb = S + (size_t)row0 * K;
+  float* Cb = C + (size_t)row0 * K;
+  const int row = m0 + li, colg = c0 + li;
+  const bool colok = colg < K;
+  const AT* arow = Ab + (size_t)(row < n ? row : 0) * lda + 16 * lh;
+  const float* scol = Sb + (colok ? colg : 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto fetchA = [&](int k0, unsigned (&ra)[AR]) {
+#pragma unroll
+    for (int u = 0; u < AR; ++u) ra[u] = 0u;
+    if (row < n && k0 < n) {
+      if constexpr (U8) {
+        const uint4 w = *reinterpret_cast<const uint4*>(arow + k0);
+        ra[0] = w.x; ra[1] = w.y; ra[2] = w.z; ra[3] = w.w;
+      } else {
+        const float* p = reinterpret_cast<const float*>(arow) + k0;
+        const int c = k0 + 16 * lh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int cc = c + 4 * u;
+          if (cc + 3 < n) v = ld4u(p + 4 * u);
+          else {
+            if (cc < n) v.x = p[4 * u];
+            if (cc + 1 < n) v.y = p[4 * u + 1];
+            if (cc + 2 < n) v.z = p[4 * u + 2];
+          }
+          ra[4 * u] = __float_as_uint(v.x); ra[4 * u + 1] = __float_as_uint(v.y);
+          ra[4 * u + 2] = __float_as_uint(v.z); ra[4 * u + 3] = __float_as_uint(v.w);
+        }
+      }
+    }
+  };
+  auto a_of = [&](const unsigned (&ra)[AR], int j) -> float {
+    if constexpr (U8) return (float)((ra[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    else return __uint_as_float(ra[j]);
+  };
+  auto fetchB = [&](int k0, float (&rbv)[16]) {
+    const int kb = k0 + 16 * lh;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const bool ok = colok && kb + j < n;
+      const float v = scol[(size_t)(ok ? kb + j : 0) * K];
+      rbv[j] = ok ? v : 0.f;
+    }
+  };
+  unsigned a0[AR], a1[AR], a2[AR];
+  float b0[16], b1[16];
+  fetchA(0, a0);
+  fetchA(BK, a1);
+  fetchB(0, b0);
+  float rs = 0.f;
+  for (int k0 = 0; k0 < n; k0 += BK) {
+    fetchA(k0 + 2 * BK, a2);
+    if (k0 + BK < n) fetchB(k0 + BK, b1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float a = a_of(a0, j);
+      if (RS) rs += a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < AR; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b0[j] = b1[j];
+  }
+  if (RS) {
+    rs += __shfl_xor(rs, 32, 64);
+    if (lh == 0 && row < n && blockIdx.z == 0) rsum[(size_t)row0 + row] = rs;
+  }
+  if (colok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (orow < n) Cb[(size_t)orow * K + colg] = acc[r];
+    }
+  }
+}
+
+template <typename AT>
+int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int32_t* nptr, int64_t B, int n, int nmax,
+                 int64_t lda, int K, int transA, hipStream_t st) {
+  dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)B);
+  const int NT = K > 32 ? 2 : 1;
+  static const bool via_lds = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 32;   // A/B: A staged through LDS
+  // measured on a PascalVOC-SP batch (B = 128, K = 64, byte adjacency; profiles/r03_dense_*): S through LDS 51-52 us
+  // (49-57 % MFMA-busy), both operands in registers 65.6 us (HSCN_DENSE_AS=34), A through LDS as well 59 us (=32), the
+  // 16x16x4 kernel on a float adjacency 49 us (=16)
+  static const bool via_reg = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 34;
+  if (!transA && !via_lds && via_reg) {
+    dim3 gr((unsigned)((nmax + 127) / 128), (unsigned)B, (unsigned)((K + 31) / 32));
+    if (rsum) k_adj_s_reg<AT, true><<<gr, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
+    else k_adj_s_reg<AT, false><<<gr, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
+  if (!transA && !via_lds) {
+    // K > 32 with byte adjacency: two workgroups per row tile, 32 columns each (HSCN_DENSE_SPLIT=0: one, 64 columns)
+    static const bool split_env = !(getenv("HSCN_DENSE_SPLIT") && atoi(getenv("HSCN_DENSE_SPLIT")) == 0);
+    const bool split = NT == 2 && sizeof(AT) == 1 && split_env;
+    dim3 gd(grid.x, grid.y, split ? 2 : 1);
+#define HSCN_ADJ_D(NT_, RS_) k_adj_s_direct<AT, NT_, RS_><<<gd, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K)
+    if (rsum) { if (NT == 2 && !split) HSCN_ADJ_D(2, true); else HSCN_ADJ_D(1, true); }
+    else { if (NT == 2 && !split) HSCN_ADJ_D(2, false); else HSCN_ADJ_D(1, false); }
+#undef HSCN_ADJ_D
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
+#define HSCN_ADJ_S(TA_, NT_, RS_) k_adj_s<AT, TA_, NT_, RS_><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K)
+  if (transA) { if (NT == 2) HSCN_ADJ_S(1, 2, false); else HSCN_ADJ_S(1, 1, false); }
+  else if (rsum) { if (NT == 2) HSCN_ADJ_S(0, 2, true); else HSCN_ADJ_S(0, 1, true); }
+  else { if (NT == 2) HSCN_ADJ_S(0, 2, false); else HSCN_ADJ_S(0, 1, false); }
+#undef HSCN_ADJ_S
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
 }
 
 // row softmax, KP = pow2 >= K lanes per row (K <= 64): consecutive lanes on consecutive addresses
@@ -472,9 +908,10 @@ int bgemm(const float* A, const float* Bm, float* C, int64_t batch, int M, int N
 
 // forward / backward of dense_mincut_pool for a batch of B graphs: n = the common node count (nptr == NULL: operands
 // [B, n, .]) or the LARGEST one (ragged: node-indexed operands flat [N, .], adjacency [B, n, n] zero beyond n_b)
+// adj8 != 0: `adj` points at uint8 counts, rows padded to lda8 = round_up(n, 32) (hscn_to_dense_adj_ragged_u8)
 int mincut_dense_fwd_impl(const float* x, const float* adj, const float* logits, const int32_t* nptr, int64_t N,
                           int64_t B, int n, int K, int F, float* S, float* AS, float* deg, float* stats, float* ss,
-                          float* pooled_x, float* pooled_adj, float* losses, hipStream_t st) {
+                          float* pooled_x, float* pooled_adj, float* losses, hipStream_t st, int adj8 = 0) {
   const int64_t rows = nptr ? N : B * n;
   {
     int KP = 1;
@@ -487,8 +924,13 @@ int mincut_dense_fwd_impl(const float* x, const float* adj, const float* logits,
   int rc;
   const int rg = nptr ? 1 : 0;
   // A S, and deg = A . 1 from the same pass over the adjacency (0/1 entries: the sums are exact in any order)
-  if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st, deg,
-                  Rag{nptr, 0, 1, 1}, rg, rg)))
+  static const bool old_as = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 16;   // A/B: the 16x16x4 kernel
+  if (adj8) {
+    if ((rc = launch_adj_s<uint8_t>(reinterpret_cast<const uint8_t*>(adj), S, AS, deg, nptr, B, n, n, (n + 31) & ~31, K, 0, st))) return rc;
+  } else if (!old_as) {
+    if ((rc = launch_adj_s<float>(adj, S, AS, deg, nptr, B, n, n, n, K, 0, st))) return rc;
+  } else if ((rc = bgemm(adj, S, AS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 0, st, deg,
+                         Rag{nptr, 0, 1, 1}, rg, rg)))
     return rc;
   // S^T (A S)  -> pooled_adj (raw), S^T S -> ss, S^T X -> pooled_x
   {
@@ -508,11 +950,16 @@ int mincut_dense_fwd_impl(const float* x, const float* adj, const float* logits,
 int mincut_dense_bwd_impl(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
                           const float* ss, const float* g_losses, const int32_t* nptr, const int32_t* gid, int64_t N,
                           int64_t B, int n, int K, float* AtS, float* sg_ws, float* gss_ws, float* g_logits,
-                          hipStream_t st) {
+                          hipStream_t st, int adj8 = 0) {
   int rc;
   const int rg = nptr ? 1 : 0;
-  if ((rc = bgemm(adj, S, AtS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 1, st, nullptr,
-                  Rag{nptr, 0, 1, 1}, rg, rg)))
+  static const bool old_as = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 16;
+  if (adj8) {
+    if ((rc = launch_adj_s<uint8_t>(reinterpret_cast<const uint8_t*>(adj), S, AtS, nullptr, nptr, B, n, n, (n + 31) & ~31, K, 1, st))) return rc;
+  } else if (!old_as) {
+    if ((rc = launch_adj_s<float>(adj, S, AtS, nullptr, nptr, B, n, n, n, K, 1, st))) return rc;
+  } else if ((rc = bgemm(adj, S, AtS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 1, st, nullptr,
+                         Rag{nptr, 0, 1, 1}, rg, rg)))
     return rc;
   // Gss' (scaled) -> gss_ws [B,K,K];  SG = S Gss' -> sg_ws
   k_dense_gss<<<(unsigned)B, 256, 0, st>>>(stats, ss, g_losses, gss_ws, K, (int)B);
@@ -562,24 +1009,27 @@ int hscn_mincut_dense_bwd(const float* adj, const float* S, const float* AS, con
                                g_logits, hscn_stream(stream_));
 }
 
-int hscn_mincut_dense_ragged_fwd(const float* x, const float* adj, const float* logits, const int32_t* nptr, int64_t N,
-                                 int64_t B, int nmax, int K, int F, float* S, float* AS, float* deg, float* stats,
-                                 float* ss, float* pooled_x, float* pooled_adj, float* losses, void* stream_) {
+int hscn_mincut_dense_ragged_fwd(const float* x, const void* adj, int adj_elem_bytes, const float* logits,
+                                 const int32_t* nptr, int64_t N, int64_t B, int nmax, int K, int F, float* S, float* AS,
+                                 float* deg, float* stats, float* ss, float* pooled_x, float* pooled_adj, float* losses,
+                                 void* stream_) {
   if (B < 1 || N < 1 || nmax < 1 || K < 1 || K > GNMAX || F < 0 || F > GNMAX) return HSCN_E_BADARG;
+  if (adj_elem_bytes != 4 && adj_elem_bytes != 1) return HSCN_E_BADARG;
   if (!adj || !logits || !nptr || !S || !AS || !deg || !stats || !ss || !pooled_adj || !losses) return HSCN_E_BADARG;
-  return mincut_dense_fwd_impl(x, adj, logits, nptr, N, B, nmax, K, F, S, AS, deg, stats, ss, pooled_x, pooled_adj,
-                               losses, hscn_stream(stream_));
+  return mincut_dense_fwd_impl(x, static_cast<const float*>(adj), logits, nptr, N, B, nmax, K, F, S, AS, deg, stats, ss,
+                               pooled_x, pooled_adj, losses, hscn_stream(stream_), adj_elem_bytes == 1);
 }
 
-int hscn_mincut_dense_ragged_bwd(const float* adj, const float* S, const float* AS, const float* deg,
+int hscn_mincut_dense_ragged_bwd(const void* adj, int adj_elem_bytes, const float* S, const float* AS, const float* deg,
                                  const float* stats, const float* ss, const float* g_losses, const int32_t* nptr,
                                  const int32_t* gid, int64_t N, int64_t B, int nmax, int K, float* AtS, float* sg_ws,
                                  float* gss_ws, float* g_logits, void* stream_) {
   if (B < 1 || N < 1 || nmax < 1 || K < 1 || K > GNMAX) return HSCN_E_BADARG;
+  if (adj_elem_bytes != 4 && adj_elem_bytes != 1) return HSCN_E_BADARG;
   if (!adj || !S || !AS || !deg || !stats || !ss || !g_losses || !nptr || !gid || !AtS || !sg_ws || !gss_ws || !g_logits)
     return HSCN_E_BADARG;
-  return mincut_dense_bwd_impl(adj, S, AS, deg, stats, ss, g_losses, nptr, gid, N, B, nmax, K, AtS, sg_ws, gss_ws,
-                               g_logits, hscn_stream(stream_));
+  return mincut_dense_bwd_impl(static_cast<const float*>(adj), S, AS, deg, stats, ss, g_losses, nptr, gid, N, B, nmax, K,
+                               AtS, sg_ws, gss_ws, g_logits, hscn_stream(stream_), adj_elem_bytes == 1);
 }
 
 }  // extern "C"

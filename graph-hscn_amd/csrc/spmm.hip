@@ -103,6 +103,101 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, cons
   }
 }
 
+// The same gather-reduce with the INDEX CHAIN TAKEN OFF THE CRITICAL PATH (VEC = 4).  k_spmm walks a row through
+// three dependent loads -- rowptr -> col -> h -- so a lane group has data in flight for a third of the time.  Here
+// a lane group carries its current row's first four column indices in registers and, while that row's (up to four)
+// neighbour rows are in flight, fetches the NEXT row's rowptr pair and then its first four columns: per row one
+// exposed latency instead of three.  Loads of absent edges are predicated off, not clamped (a row has ~2 edges: clamped
+// slots would double the gather traffic).  Rows longer than four edges finish in the plain loop.  Accumulation is in
+// CSR slot order with separately rounded multiply and add, exactly as k_spmm: bit-identical results.
+template <int MODE, int NV>
+__global__ void __launch_bounds__(SP_THREADS)
+k_spmm_pipe(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+            const float* __restrict__ dinv_r, const float* __restrict__ dinv_c, const float* __restrict__ wts,
+            const float* __restrict__ h, const float* __restrict__ bias, float* __restrict__ out,
+            int64_t num_rows, int width, int LPR, int RPB, int accumulate, int act, int nt_store) {
+  using V = Vec<4>;
+  constexpr int D = 4;
+  const int rl = threadIdx.x / LPR;
+  const int f = (threadIdx.x - rl * LPR) * 4 * NV;
+  if (rl >= RPB) return;
+  int64_t r = (int64_t)blockIdx.x * RPB + rl;
+  const int64_t step = (int64_t)gridDim.x * RPB;
+  if (r >= num_rows) return;
+  int s = rowptr[r], t = rowptr[r + 1];
+  int jc[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) { jc[u] = 0; if (s + u < t) jc[u] = col[s + u]; }
+  float4 bq[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) bq[q] = bias ? V::load(bias + f + q * 4) : V::zero();
+  for (;;) {
+    const int64_t rn = r + step;
+    const bool more = rn < num_rows;
+    int sn = 0, tn = 0;
+    if (more) { sn = rowptr[rn]; tn = rowptr[rn + 1]; }
+    float dr = 0.f;
+    if (MODE == 0) dr = dinv_r[r];
+    float w[D];
+    float4 x[D][NV];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      w[u] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) x[u][q] = V::zero();
+      if (s + u < t) {
+        const int j = jc[u];
+        if (MODE == 0) w[u] = dinv_c[j];
+        else w[u] = wts ? wts[eid ? eid[s + u] : s + u] : 1.0f;
+        const float* hj = h + (size_t)j * width + f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) x[u][q] = V::load(hj + q * 4);
+      }
+    }
+    int jn[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) { jn[u] = 0; if (more && sn + u < tn) jn[u] = col[sn + u]; }
+    float4 acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = V::zero();
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      if (s + u < t) {
+        const float ww = MODE == 0 ? mul_rn(w[u], dr) : w[u];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) acc[q] = V::axpy(ww, x[u][q], acc[q]);
+      }
+    }
+    for (int p = s + D; p < t; ++p) {      // (rows of more than four edges)
+      const int j = col[p];
+      float ww;
+      if (MODE == 0) ww = mul_rn(dinv_c[j], dr);
+      else ww = wts ? wts[eid ? eid[p] : p] : 1.0f;
+      const float* hj = h + (size_t)j * width + f;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) acc[q] = V::axpy(ww, V::load(hj + q * 4), acc[q]);
+    }
+    float* o = out + (size_t)r * width + f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      float4 a = acc[q];
+      if (bias) a = V::add(a, bq[q]);
+      if (accumulate) a = V::add(a, V::load(o + q * 4));
+      a = V::act(a, act);
+      if (nt_store) {
+        __builtin_nontemporal_store(a.x, o + q * 4 + 0); __builtin_nontemporal_store(a.y, o + q * 4 + 1);
+        __builtin_nontemporal_store(a.z, o + q * 4 + 2); __builtin_nontemporal_store(a.w, o + q * 4 + 3);
+      } else {
+        V::store(o + q * 4, a);
+      }
+    }
+    if (!more) break;
+    r = rn; s = sn; t = tn;
+#pragma unroll
+    for (int u = 0; u < D; ++u) jc[u] = jn[u];
+  }
+}
+
 template <int MODE>
 int launch_spmm(const int32_t* rowptr, const int32_t* col, const int32_t* eid, const float* dinv_r,
                 const float* dinv_c, const float* wts, const float* h, const float* bias, float* out,
@@ -119,6 +214,24 @@ int launch_spmm(const int32_t* rowptr, const int32_t* col, const int32_t* eid, c
   const int LPR = width / (VEC * NV);
   if (LPR > SP_THREADS) return HSCN_E_UNSUPPORTED;
   const int RPB = SP_THREADS / LPR;
+  static const int pipe = getenv("HSCN_SPMM_PIPE") ? atoi(getenv("HSCN_SPMM_PIPE")) : 1;
+  static const int nt = getenv("HSCN_SPMM_NT") ? atoi(getenv("HSCN_SPMM_NT")) : 0;
+  static const int nbmax = getenv("HSCN_SPMM_BLOCKS") ? atoi(getenv("HSCN_SPMM_BLOCKS")) : 8192;
+  // measured (tools/ab_spmm.sh, 658 k rows): the pipelined form wins where a row is a few lanes -- H = 16: 3.55 -> 4.17
+  // TB/s -- and loses where a lane group already keeps 1 KB in flight and registers decide the occupancy -- H = 128:
+  // 4.42 -> 2.95 TB/s (4.05 with one piece per lane); HSCN_SPMM_PIPE=2 forces it at every width
+  if ((pipe == 2 || (pipe == 1 && width <= 32)) && VEC == 4 && NV <= 2 && passes == 0) {
+    int64_t nbp = (num_rows + RPB - 1) / RPB;
+    if (nbp > nbmax) nbp = nbmax;
+    if (NV == 2)
+      k_spmm_pipe<MODE, 2><<<(unsigned)nbp, SP_THREADS, 0, st>>>(rowptr, col, eid, dinv_r, dinv_c, wts, h, bias, out, num_rows,
+                                                               width, LPR, RPB, accumulate, act, nt);
+    else
+      k_spmm_pipe<MODE, 1><<<(unsigned)nbp, SP_THREADS, 0, st>>>(rowptr, col, eid, dinv_r, dinv_c, wts, h, bias, out, num_rows,
+                                                               width, LPR, RPB, accumulate, act, nt);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
   int64_t nb, rpb = 0;
   if (passes > 0) {
     nb = (num_rows + (int64_t)RPB * passes - 1) / ((int64_t)RPB * passes);

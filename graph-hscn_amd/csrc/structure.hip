@@ -250,6 +250,37 @@ __global__ void k_dense_adj_ragged(const int64_t* __restrict__ row, const int64_
   }
 }
 
+// the same counts as BYTES: adj8 [B, nmax, lda8], lda8 = nmax rounded up to 32 (16-byte loads of a row never leave
+// it), zero on entry -- a quarter of the float adjacency's bytes for the matrix-core products that stream it
+// (csrc/dense.hip k_adj_s).  A byte is bumped through an atomic add on its aligned word; a count that would pass
+// 255 (more than 255 parallel edges) raises flag bit 16 instead of carrying into the neighbour.
+__global__ void k_dense_adj_ragged_u8(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t E,
+                                      const int32_t* __restrict__ nptr, const int32_t* __restrict__ gid, int64_t N,
+                                      int64_t nmax, int64_t lda8, int mode, unsigned int* __restrict__ adjw,
+                                      int32_t* __restrict__ flag) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t o;
+  if (t < E) {
+    const int64_t r = row[t], c = col[t];
+    if (r < 0 || r >= N || c < 0 || c >= N) return;
+    if (mode == 1 && r == c) return;
+    const int b = gid[r];
+    if (gid[c] != b) return;
+    const int64_t r0 = nptr[b];
+    o = ((int64_t)b * nmax + (r - r0)) * lda8 + (c - r0);
+  } else if (mode == 1 && t < E + N) {
+    const int64_t i = t - E;
+    const int b = gid[i];
+    const int64_t li = i - nptr[b];
+    o = ((int64_t)b * nmax + li) * lda8 + li;
+  } else {
+    return;
+  }
+  const unsigned sh = (unsigned)(o & 3) * 8u;
+  const unsigned old = atomicAdd(&adjw[o >> 2], 1u << sh);
+  if (((old >> sh) & 0xffu) == 0xffu && flag) atomicOr(flag, 16);
+}
+
 // gcn_norm's self-loop bookkeeping (PyG add_remaining_self_loops) with a STATIC output shape, so that
 // it can sit inside a captured stream: out = the E input edges IN PLACE followed by one loop per node.  An input edge
 // that is a self loop keeps its slot with weight 0 (PyG removes it from the front part: a zero-weight term adds
@@ -328,7 +359,9 @@ int hscn_csr_build(const int64_t* key, const int64_t* other, int64_t E, int64_t 
     HSCN_RETURN_IF_LAUNCH_FAILED();
   }
   int64_t n1 = num_rows + 1;
-  if (n1 <= 64 * 1024) {
+  // (one block walks 4096 entries per trip, ~2.5 us each: beyond two trips the three-launch scan is faster --
+  // 60 k rows of a PascalVOC-SP batch took 38 us in the single block)
+  if (n1 <= 8 * 1024) {
     k_scan_single<<<1, 1024, 0, st>>>(rowptr, n1);
   } else {
     int nblk = (int)((n1 + SCAN_TILE - 1) / SCAN_TILE);
@@ -407,6 +440,19 @@ int hscn_to_dense_adj_ragged(const int64_t* row, const int64_t* col, int64_t E, 
   const int64_t work = E + (mode == 1 ? N : 0);
   if (work == 0 || B == 0) return 0;
   k_dense_adj_ragged<<<hscn_blocks(work, 256), 256, 0, hscn_stream(stream_)>>>(row, col, E, nptr, gid, N, nmax, mode, adj);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_to_dense_adj_ragged_u8(const int64_t* row, const int64_t* col, int64_t E, const int32_t* nptr,
+                                const int32_t* gid, int64_t N, int64_t B, int64_t nmax, int mode, uint8_t* adj8,
+                                int32_t* flag, void* stream_) {
+  if (E < 0 || N < 0 || B < 0 || nmax < 0 || (mode != 0 && mode != 1)) return HSCN_E_BADARG;
+  if ((E > 0 && (!row || !col)) || !nptr || !gid || !adj8) return HSCN_E_BADARG;
+  const int64_t work = E + (mode == 1 ? N : 0);
+  if (work == 0 || B == 0) return 0;
+  k_dense_adj_ragged_u8<<<hscn_blocks(work, 256), 256, 0, hscn_stream(stream_)>>>(
+      row, col, E, nptr, gid, N, nmax, (nmax + 31) & ~(int64_t)31, mode, reinterpret_cast<unsigned int*>(adj8), flag);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -193,10 +193,13 @@ class SCN(nn.Module):
                 if node_graph is None:
                     raise ValueError("graphs of different sizes on the dense MinCUT route need node_graph (int32 [N])")
                 # ragged batch: A + I of every graph in its own [nmax, nmax] block, node-indexed tensors flat
+                # (the adjacency as bytes: nobody outside this call sees it -- batched calls return None in its slot --
+                # and the products that stream it move a quarter of the bytes; HSCN_DENSE_ADJ=f32 keeps floats)
+                as_bytes = os.environ.get("HSCN_DENSE_ADJ", "u8") != "f32"
                 if raw_edge_index is not None:
-                    adj = to_dense_adj_ragged(raw_edge_index, node_ptr, node_graph, Bg, ng, raw=True)
+                    adj = to_dense_adj_ragged(raw_edge_index, node_ptr, node_graph, Bg, ng, raw=True, as_bytes=as_bytes)
                 else:
-                    adj = to_dense_adj_ragged(edge_index, node_ptr, node_graph, Bg, ng)
+                    adj = to_dense_adj_ragged(edge_index, node_ptr, node_graph, Bg, ng, as_bytes=as_bytes)
                 S, mc_loss, o_loss, _, _ = Fh.MinCutDenseRaggedFn.apply(s, x, adj, node_ptr, node_graph)
                 self.last_route = "dense-ragged"
                 return S, mc_loss, o_loss, None

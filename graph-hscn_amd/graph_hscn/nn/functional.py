@@ -379,12 +379,14 @@ def _pack_loss_grads(g_mc: Optional[Tensor], g_o: Optional[Tensor], dev) -> Tens
 # --------------------------------------------------------------------------- #
 class MinCutDenseRaggedFn(Function):
     """``MinCutDenseFn`` for a batch of graphs of DIFFERENT sizes: (logits [N,K], x [N,F] | None, adj [B,nmax,nmax]
-    zero beyond each graph, nptr int32 [B+1], gid int32 [N]) -> (S [N,K], mincut, ortho, pooled_x, pooled_adj);
+    float32 -- or uint8 [B,nmax,round_up(nmax,32)] -- zero beyond each graph, nptr int32 [B+1], gid int32 [N]) -> (S [N,K], mincut, ortho, pooled_x, pooled_adj);
     losses = mean over graphs, every graph's terms equal to the single-graph call's (hscn_mincut_dense_ragged_*)."""
 
     @staticmethod
     def forward(ctx, logits: Tensor, x: Optional[Tensor], adj: Tensor, nptr: Tensor, gid: Tensor):
-        logits, x, adj = _c(logits), _c(x), _c(adj)
+        if adj.dtype not in (torch.float32, torch.uint8):
+            raise TypeError(f"the dense adjacency is float32 or uint8 (got {adj.dtype})")
+        logits, x, adj = _c(logits), _c(x), adj.contiguous()
         N, K = logits.shape
         B, nmax = adj.shape[0], adj.shape[1]
         dev = logits.device
@@ -397,7 +399,7 @@ class MinCutDenseRaggedFn(Function):
         px = torch.empty(B, K, Fx, dtype=torch.float32, device=dev) if x is not None else None
         padj = torch.empty(B, K, K, dtype=torch.float32, device=dev)
         losses = torch.empty(2, dtype=torch.float32, device=dev)
-        call("hscn_mincut_dense_ragged_fwd", ptr(x), ptr(adj), ptr(logits), ptr(nptr), N, B, nmax, K, Fx, ptr(S), ptr(AS),
+        call("hscn_mincut_dense_ragged_fwd", ptr(x), ptr(adj), adj.element_size(), ptr(logits), ptr(nptr), N, B, nmax, K, Fx, ptr(S), ptr(AS),
              ptr(deg), ptr(stats), ptr(ss), ptr(px), ptr(padj), ptr(losses), stream())
         ctx.save_for_backward(adj, S, AS, deg, stats, ss, nptr, gid)
         ctx.set_materialize_grads(False)
@@ -416,7 +418,7 @@ class MinCutDenseRaggedFn(Function):
         SG = torch.empty_like(S)
         Gss = torch.empty_like(ss)
         g_logits = torch.empty_like(S)
-        call("hscn_mincut_dense_ragged_bwd", ptr(adj), ptr(S), ptr(AS), ptr(deg), ptr(stats), ptr(ss), ptr(gl), ptr(nptr),
+        call("hscn_mincut_dense_ragged_bwd", ptr(adj), adj.element_size(), ptr(S), ptr(AS), ptr(deg), ptr(stats), ptr(ss), ptr(gl), ptr(nptr),
              ptr(gid), N, B, nmax, K, ptr(AtS), ptr(SG), ptr(Gss), ptr(g_logits), stream())
         return g_logits, None, None, None, None
 

@@ -46,12 +46,19 @@ def to_dense_adj_batched(edge_index: Tensor, num_graphs: int, nodes_per_graph: i
 
 
 def to_dense_adj_ragged(edge_index: Tensor, nptr: Tensor, gid: Tensor, num_graphs: int, max_nodes: int,
-                        raw: bool = False) -> Tensor:
+                        raw: bool = False, as_bytes: bool = False, flag: Optional[Tensor] = None) -> Tensor:
     """``to_dense_adj(edge_index, batch)`` for a block-diagonal batch of graphs of different sizes: ``[B, nmax, nmax]``,
     zero beyond a graph's own nodes.  ``raw=True``: ``edge_index`` is the RAW edge list and the result is what
     ``gcn_norm(add_self_loops=True)`` followed by ``to_dense_adj`` gives -- off-diagonal counts plus the identity
     (train/train_clustering.py:37-42, model/hscn.py:61) -- without building the self-looped list first."""
     B, n = int(num_graphs), int(max_nodes)
+    if as_bytes:
+        # the counts as bytes, rows padded to a multiple of 32: what the batched dense route streams through the
+        # matrix cores (a quarter of the float adjacency's bytes; exact up to 255 parallel edges, flag bit 16 beyond)
+        adj8 = torch.zeros(B, n, (n + 31) // 32 * 32, dtype=torch.uint8, device=edge_index.device)
+        call("hscn_to_dense_adj_ragged_u8", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()),
+             edge_index.size(1), ptr(nptr), ptr(gid), int(gid.numel()), B, n, 1 if raw else 0, ptr(adj8), ptr(flag), stream())
+        return adj8
     adj = torch.zeros(B, n, n, dtype=torch.float32, device=edge_index.device)
     call("hscn_to_dense_adj_ragged", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()),
          edge_index.size(1), ptr(nptr), ptr(gid), int(gid.numel()), B, n, 1 if raw else 0, ptr(adj), stream())

@@ -218,12 +218,15 @@ int hscn_mincut_sparse_bwd(const float* S, const float* stats, const float* ss,
  * operands (logits, x, S, AS, deg, AtS, sg_ws, g_logits) are flat [N, width] arrays -- graph b owns rows
  * [nptr[b], nptr[b + 1]) -- the adjacency is [B, nmax, nmax] with zeros beyond a graph's n_b (nmax = the largest n_b),
  * the per-graph results (stats [B,4], ss / pooled_adj [B,K,K], pooled_x [B,K,F]) keep their shapes.  gid [N] int32 = graph
- * of every node.  Values per graph identical to the uniform entry points on that graph alone; losses = mean over graphs. */
-int hscn_mincut_dense_ragged_fwd(const float* x /*[N,F] or NULL*/, const float* adj /*[B,nmax,nmax]*/,
+ * of every node.  Values per graph identical to the uniform entry points on that graph alone; losses = mean over graphs.
+ * adj_elem_bytes = 4: float adjacency [B, nmax, nmax]; = 1: the same counts as bytes, [B, nmax, lda8] with
+ * lda8 = nmax rounded up to 32 (hscn_to_dense_adj_ragged_u8): the A S / A^T S products stream the adjacency, a quarter
+ * of the bytes, converted exactly on the way to the matrix cores (v_mfma_f32_32x32x2_f32, 128-row tiles). */
+int hscn_mincut_dense_ragged_fwd(const float* x /*[N,F] or NULL*/, const void* adj, int adj_elem_bytes,
                                  const float* logits /*[N,K]*/, const int32_t* nptr /*[B+1]*/, int64_t N, int64_t B,
                                  int nmax, int K, int F, float* S, float* AS, float* deg /*[N]*/, float* stats,
                                  float* ss, float* pooled_x, float* pooled_adj, float* losses /*[2]*/, void* stream);
-int hscn_mincut_dense_ragged_bwd(const float* adj, const float* S, const float* AS, const float* deg,
+int hscn_mincut_dense_ragged_bwd(const void* adj, int adj_elem_bytes, const float* S, const float* AS, const float* deg,
                                  const float* stats, const float* ss, const float* g_losses /*[2]*/,
                                  const int32_t* nptr, const int32_t* gid /*[N]*/, int64_t N, int64_t B, int nmax, int K,
                                  float* AtS, float* sg_ws, float* gss_ws /*[B,K,K]*/, float* g_logits, void* stream);
@@ -293,6 +296,11 @@ int hscn_to_dense_adj_batched(const int64_t* row, const int64_t* col, int64_t E,
 int hscn_to_dense_adj_ragged(const int64_t* row, const int64_t* col, int64_t E, const int32_t* nptr /*[B+1]*/,
                              const int32_t* gid /*[N]*/, int64_t N, int64_t B, int64_t nmax, int mode, float* adj,
                              void* stream);
+/* ... as bytes: adj8 [B, nmax, lda8], lda8 = nmax rounded up to 32, ZERO on entry (4-byte aligned); flag (optional) gets
+ * bit 16 when an entry would pass 255. */
+int hscn_to_dense_adj_ragged_u8(const int64_t* row, const int64_t* col, int64_t E, const int32_t* nptr,
+                                const int32_t* gid, int64_t N, int64_t B, int64_t nmax, int mode, uint8_t* adj8,
+                                int32_t* flag, void* stream);
 /* gcn_norm's self-loop bookkeeping (PyG add_remaining_self_loops; train/train_clustering.py:37-42) with a STATIC output
  * shape [E + N] -- capturable, no data-dependent size: the E input edges keep their slots (an input self loop stays
  * in place with weight 0, its weight moves to the node's loop), then one loop per node (weight = the moved one or

@@ -232,8 +232,10 @@ def test_scn_dense_mfma_route_matches_oracle_through_the_model(route, K):
     assert abs(float(ob) - np.mean([s[2] for s in singles])) < 1e-6
 
 
-@pytest.mark.parametrize("K,sizes", [(64, (395, 500, 479, 431, 463)), (16, (40, 7, 129)), (64, (2, 64, 65, 128, 500))])
-def test_scn_dense_route_on_a_ragged_batch_matches_the_oracle_loop(K, sizes):
+@pytest.mark.parametrize("adj_format", ["u8", "f32"])
+@pytest.mark.parametrize("K,sizes", [(64, (395, 500, 479, 431, 463)), (16, (40, 7, 129)), (64, (2, 64, 65, 128, 500)),
+                                     (32, (130, 257, 33))])
+def test_scn_dense_route_on_a_ragged_batch_matches_the_oracle_loop(K, sizes, adj_format, monkeypatch):
     """BASELINE.json configs[3] with its REAL size spread (PascalVOC-SP: n in [395, 500]): a batch of graphs of
     different sizes through ``forward_graphs`` on the dense route (adjacency [B, nmax, nmax] zero beyond each graph,
     node-indexed tensors flat, hscn_mincut_dense_ragged_*) against the oracle's reference loop -- one graph at a
