@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -94,6 +94,11 @@ _SIGNATURES = {
     "hscn_to_dense_adj_ragged_u8": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
     "hscn_to_dense_adj_ragged": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int, P, P]),
     "hscn_gcn_norm_self_loops": (c_int, [P, P, P, c_int64, c_int64, c_float, P, P, P, P]),
+    "hscn_norm_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "hscn_layer_norm_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_float, P]),
+    "hscn_layer_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, P, c_size_t, P]),
+    "hscn_batch_norm_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_float, c_int, P, c_size_t, P]),
+    "hscn_batch_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, P, c_size_t, P]),
     "hscn_comm_alloc": (c_int, [c_size_t, c_int, P]),
     "hscn_comm_free": (c_int, [P]),
     "hscn_comm_ipc_export": (c_int, [P, P]),

@@ -5,11 +5,10 @@ convolution's node outputs.  Everything numerical runs in the HIP library: GCNCo
 normalised CSR gather-reduce with the ReLU in its epilogue), the activation, the counter-based
 dropout and the segment mean.
 
-What the reference's constructor cannot build is refused here too, by name:
-* ``use_batch_norm=True`` without ``use_layer_norm`` reads ``self.bns``, which model/mpnn.py:35-38 only
-  creates under ``use_layer_norm`` (AttributeError in the reference);
-* the normalisation layers themselves are outside the scope table ("lowest
-  value") and raise NotImplementedError instead of running through eager PyTorch.
+Normalisation layers (model/mpnn.py:34-44,53-56) are built and applied exactly as the reference does, quirk
+included: BOTH module lists -- ``bns`` (BatchNorm1d) and ``lns`` (LayerNorm) -- are created under ``use_layer_norm``
+(mpnn.py:35 tests the wrong flag), so ``use_batch_norm=True`` alone reads a ``self.bns`` that does not exist and the
+forward raises AttributeError, as the reference's does.  The layers compute through csrc/norm.hip.
 """
 from __future__ import annotations
 
@@ -21,6 +20,7 @@ from torch import Tensor
 
 from ..config.config import ACT_DICT, CONV_DICT, MPNNConfig
 from ..nn import functional as Fh
+from ..nn.norm import BatchNorm1d, LayerNorm
 from ..nn.pool import global_mean_pool
 
 
@@ -29,16 +29,18 @@ class MPNN(nn.Module):
                  num_classes: int, num_layers: int, dropout: float = 0.0, use_batch_norm: bool = False,
                  use_layer_norm: bool = False) -> None:
         super().__init__()
-        if use_batch_norm or use_layer_norm:
-            raise NotImplementedError("MPNN normalisation layers are not on the MI355X hot path "
-                                      "(and use_batch_norm alone fails in the reference, model/mpnn.py:35-38,54)")
         self.num_layers = num_layers
         self.conv_layers = nn.ModuleList()                                  # mpnn.py:27-32
         self.conv_layers.append(conv(num_features, hidden_channels))
         for _ in range(num_layers - 2):
             self.conv_layers.append(conv(hidden_channels, hidden_channels))
         self.conv_layers.append(conv(hidden_channels, num_classes))
-        self.use_batch_norm, self.use_layer_norm = use_batch_norm, use_layer_norm
+        self.use_batch_norm = use_batch_norm
+        if use_layer_norm:                                                  # mpnn.py:35-38 (sic: not use_batch_norm)
+            self.bns = nn.ModuleList(BatchNorm1d(hidden_channels) for _ in range(num_layers - 1))
+        self.use_layer_norm = use_layer_norm
+        if use_layer_norm:                                                  # mpnn.py:41-44
+            self.lns = nn.ModuleList(LayerNorm(hidden_channels) for _ in range(num_layers - 1))
         self.activation = activation
         self.dropout = dropout
         self.dropout_seed: Optional[int] = None     # tests pin the mask; None = torch.initial_seed() + call counter
@@ -48,7 +50,12 @@ class MPNN(nn.Module):
         act_name = getattr(self.activation, "hscn_name", None)
         for i in range(self.num_layers - 1):
             x = self.conv_layers[i](x, edge_index, act="relu")              # F.relu(conv(x)) in the epilogue
-            if act_name not in ("relu", "identity", "elu"):                 # relu / elu are the identity on x >= 0
+            if self.use_batch_norm:
+                x = self.bns[i](x)                                          # mpnn.py:53-54
+            if self.use_layer_norm:
+                x = self.lns[i](x)                                          # mpnn.py:55-56
+            normed = self.use_batch_norm or self.use_layer_norm             # (a normalised x is no longer >= 0)
+            if normed or act_name not in ("relu", "identity", "elu"):       # relu / elu are the identity on x >= 0
                 x = self.activation(x)
             seed = None if self.dropout_seed is None else self.dropout_seed + i
             x = Fh.dropout(x, p=self.dropout, training=self.training, seed=seed)

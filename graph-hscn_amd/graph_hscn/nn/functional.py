@@ -377,6 +377,71 @@ def _pack_loss_grads(g_mc: Optional[Tensor], g_o: Optional[Tensor], dev) -> Tens
 # --------------------------------------------------------------------------- #
 # MinCUT pooling, dense route (matrix cores)
 # --------------------------------------------------------------------------- #
+def _norm_ws(N: int, H: int, dev) -> Tensor:
+    return torch.empty(max(1, _hip.lib().hscn_norm_workspace_bytes(N, H) // 4), dtype=torch.float32, device=dev)
+
+
+class LayerNormFn(Function):
+    """torch.nn.functional.layer_norm over the last dim of [N, H] (reference model/mpnn.py:55-56)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        N, H = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(max(N, 1), dtype=torch.float32, device=x.device)
+        rstd = torch.empty(max(N, 1), dtype=torch.float32, device=x.device)
+        call("hscn_layer_norm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), N, H, float(eps), stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        N, H = x.shape
+        gy = _c(gy)
+        gx = torch.empty_like(x)
+        gg = torch.empty(H, dtype=torch.float32, device=x.device)
+        gb = torch.empty(H, dtype=torch.float32, device=x.device)
+        ws = _norm_ws(N, H, x.device)
+        call("hscn_layer_norm_bwd", ptr(gy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(gx), ptr(gg), ptr(gb), N, H,
+             ptr(ws), ws.numel() * 4, stream())
+        return gx, gg, gb, None
+
+
+class BatchNormFn(Function):
+    """torch.nn.functional.batch_norm on [N, H] (reference model/mpnn.py:53-54): batch statistics and the running
+    update in training mode, running statistics in eval mode."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor],
+                running_var: Optional[Tensor], training: bool, momentum: float, eps: float):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        N, H = x.shape
+        y = torch.empty_like(x)
+        sm = torch.empty(H, dtype=torch.float32, device=x.device)
+        sr = torch.empty(H, dtype=torch.float32, device=x.device)
+        ws = _norm_ws(N, H, x.device)
+        call("hscn_batch_norm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(y), ptr(sm),
+             ptr(sr), N, H, float(eps), float(momentum), 1 if training else 0, ptr(ws), ws.numel() * 4, stream())
+        ctx.save_for_backward(x, gamma, sm, sr)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, sm, sr = ctx.saved_tensors
+        N, H = x.shape
+        gy = _c(gy)
+        gx = torch.empty_like(x)
+        gg = torch.empty(H, dtype=torch.float32, device=x.device)
+        gb = torch.empty(H, dtype=torch.float32, device=x.device)
+        ws = _norm_ws(N, H, x.device)
+        call("hscn_batch_norm_bwd", ptr(gy), ptr(x), ptr(gamma), ptr(sm), ptr(sr), ptr(gx), ptr(gg), ptr(gb), N, H,
+             1 if ctx.training else 0, ptr(ws), ws.numel() * 4, stream())
+        return gx, gg, gb, None, None, None, None, None
+
+
 class MinCutDenseRaggedFn(Function):
     """``MinCutDenseFn`` for a batch of graphs of DIFFERENT sizes: (logits [N,K], x [N,F] | None, adj [B,nmax,nmax]
     float32 -- or uint8 [B,nmax,round_up(nmax,32)] -- zero beyond each graph, nptr int32 [B+1], gid int32 [N]) -> (S [N,K], mincut, ortho, pooled_x, pooled_adj);

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 15
+#define HSCN_ABI_VERSION 16
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -745,6 +745,28 @@ int hscn_scn_resident_bwd_f16(const hscn_half* x, const int64_t* edge_index, int
 int hscn_adam_step(float* const* params_host, const int32_t* seg_off_host, int nseg, const float* grads,
                    float* exp_avg, float* exp_avg_sq, int64_t P, float* step_dev, double* beta_pows_dev,
                    const double* lr_dev, double beta1, double beta2, double eps, double weight_decay, int decoupled, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Normalisation layers of the MPNN baseline: torch.nn.LayerNorm(H) / torch.nn.BatchNorm1d(H) on [N, H] activations,
+ * reference graph_hscn/model/mpnn.py:34-44 (construction) and :53-56 (use after every hidden convolution).
+ * LayerNorm: per row, biased variance, eps inside the root; mean / rstd [N] are saved for the backward.
+ * BatchNorm1d, training != 0: batch statistics per column (two passes), running_mean / running_var (either may be
+ *   NULL) updated with `momentum` (unbiased variance), save_mean / save_rstd [H] for the backward; training == 0:
+ *   running statistics (save_* receive them).  Parameter gradients and column statistics are ordered sums over row
+ *   chunks (workspace: hscn_norm_workspace_bytes(N, H)); no float atomics.
+ * ------------------------------------------------------------------------- */
+size_t hscn_norm_workspace_bytes(int64_t N, int H);
+int hscn_layer_norm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int64_t N, int H, float eps, void* stream);
+int hscn_layer_norm_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        float* gx, float* g_gamma, float* g_beta, int64_t N, int H, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int hscn_batch_norm_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float* y, float* save_mean, float* save_rstd, int64_t N, int H, float eps, float momentum,
+                        int training, void* workspace, size_t workspace_bytes, void* stream);
+int hscn_batch_norm_bwd(const float* gy, const float* x, const float* gamma, const float* save_mean,
+                        const float* save_rstd, float* gx, float* g_gamma, float* g_beta, int64_t N, int H,
+                        int training, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Data-parallel exchange: one-shot peer-to-peer all-reduce of the flat gradient buffer.

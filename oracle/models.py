@@ -146,12 +146,19 @@ class HSCN(nn.Module):
 class MPNN(nn.Module):
     """model/mpnn.py:13-62 with ``conv = GCNConv`` (config/config.py:19-23, configs/GCN/peptides_func_GCN.yaml:6):
     GCNConv(add_self_loops=True) stack, ``F.relu`` then the configured activation then dropout after every
-    hidden layer, ``scatter_mean`` over the batch vector at the end.  Normalisation layers are not restated
-    (``use_batch_norm`` alone is an AttributeError in the reference, mpnn.py:35-38,54)."""
+    hidden layer, ``scatter_mean`` over the batch vector at the end.  Normalisation layers as the reference builds
+    them (mpnn.py:34-44): BOTH lists under ``use_layer_norm`` (``use_batch_norm`` alone is an AttributeError at
+    mpnn.py:54), plain ``torch.nn.BatchNorm1d`` / ``torch.nn.LayerNorm``."""
 
     def __init__(self, activation: Callable, num_features: int, hidden_channels: int, num_classes: int,
-                 num_layers: int, dropout: float = 0.0):
+                 num_layers: int, dropout: float = 0.0, use_batch_norm: bool = False, use_layer_norm: bool = False):
         super().__init__()
+        self.use_batch_norm = use_batch_norm
+        if use_layer_norm:
+            self.bns = nn.ModuleList(nn.BatchNorm1d(hidden_channels) for _ in range(num_layers - 1))
+        self.use_layer_norm = use_layer_norm
+        if use_layer_norm:
+            self.lns = nn.ModuleList(nn.LayerNorm(hidden_channels) for _ in range(num_layers - 1))
         self.num_layers = num_layers
         self.conv_layers = nn.ModuleList()
         self.conv_layers.append(P.GCNConv(num_features, hidden_channels))
@@ -167,6 +174,10 @@ class MPNN(nn.Module):
         with a known mask can be compared element for element."""
         for i in range(self.num_layers - 1):
             x = F.relu(self.conv_layers[i](x, edge_index))
+            if self.use_batch_norm:
+                x = self.bns[i](x)
+            if self.use_layer_norm:
+                x = self.lns[i](x)
             x = self.activation(x)
             if masks is not None:
                 x = x * masks[i] * (1.0 / (1.0 - self.dropout))

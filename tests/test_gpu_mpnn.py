@@ -51,7 +51,12 @@ def _pair(F, H, C, L, act, dropout, seed):
 
 
 def _check_grads(om, pm, atol=1e-4, rtol=1e-3):
-    for (n_, po), (_, pp) in zip(om.named_parameters(), pm.named_parameters()):
+    prod = dict(pm.named_parameters())
+    for n_, po in om.named_parameters():
+        pp = prod[n_]
+        if po.grad is None:                 # (a module the forward never calls: mpnn.py builds bns under use_layer_norm)
+            assert pp.grad is None, n_
+            continue
         assert close(pp.grad, po.grad, atol=atol, rtol=rtol), n_
 
 
@@ -177,3 +182,72 @@ def test_train_epoch_runs_the_mpnn_branch():
         last = train_epoch(e, None, loader, model, opt, "cross_entropy", None, 1, False)[0]
     assert math.isfinite(last) and last < first
     assert math.isfinite(eval_epoch(0, None, loader, model, "cross_entropy", None, "Validation")[0])
+
+
+@pytest.mark.parametrize("use_bn,use_ln,act", [(False, True, "relu"), (True, True, "elu"), (True, True, "tanh")])
+def test_mpnn_with_normalisation_layers_matches_oracle(use_bn, use_ln, act):
+    """model/mpnn.py:34-44,53-56: LayerNorm alone, and BatchNorm1d + LayerNorm (both lists exist under
+    use_layer_norm), forward / gradients in training mode -- batch statistics and the running-statistics update --
+    then eval mode on the updated running statistics."""
+    from graph_hscn.config.config import ACT_DICT, CONV_DICT
+    from graph_hscn.model.mpnn import MPNN
+    b = _peptides_batch(12, seed=5)
+    torch.manual_seed(3)
+    om = OM.MPNN(OM.ACT[act], 9, 16, 10, 3, 0.0, use_batch_norm=use_bn, use_layer_norm=use_ln)
+    with torch.no_grad():
+        for n_, p in om.named_parameters():
+            if n_.endswith("bias") or "bns" in n_ or "lns" in n_:
+                p.add_(torch.randn_like(p) * 0.2)
+    pm = MPNN(CONV_DICT["gcn"], ACT_DICT[act], 9, 16, 10, 3, 0.0, use_batch_norm=use_bn, use_layer_norm=use_ln).to(DEV)
+    assert sorted(pm.state_dict()) == sorted(om.state_dict())
+    pm.load_state_dict(om.state_dict())
+    d = _dev(b)
+    g = torch.randn(12, 10, generator=torch.Generator().manual_seed(1))
+    om.train(); pm.train()
+    for step in range(2):                                   # twice: the running statistics move twice
+        om.zero_grad(); pm.zero_grad()
+        out_o = om(b.x.float(), b.edge_index, b.batch, 12)
+        out_d = pm(d)
+        assert close(out_d, out_o, atol=2e-5, rtol=1e-4)
+        out_o.backward(g)
+        out_d.backward(g.to(DEV))
+        _check_grads(om, pm, atol=2e-4, rtol=2e-3)
+    pbuf = dict(pm.named_buffers())
+    for n_, bo in om.named_buffers():
+        assert close(pbuf[n_].float(), bo.float(), atol=1e-5, rtol=1e-5), n_
+    om.eval(); pm.eval()
+    with torch.no_grad():
+        assert close(pm(d), om(b.x.float(), b.edge_index, b.batch, 12), atol=2e-5, rtol=1e-4)
+
+
+def test_mpnn_batch_norm_alone_fails_as_in_the_reference():
+    """mpnn.py:35 creates ``bns`` under use_layer_norm, :53-54 reads it under use_batch_norm: AttributeError."""
+    from graph_hscn.config.config import ACT_DICT, CONV_DICT
+    from graph_hscn.model.mpnn import MPNN
+    pm = MPNN(CONV_DICT["gcn"], ACT_DICT["relu"], 9, 16, 10, 3, 0.0, use_batch_norm=True).to(DEV)
+    with pytest.raises(AttributeError):
+        pm(_dev(_peptides_batch(3, seed=1)))
+
+
+@pytest.mark.parametrize("N,H", [(1, 16), (300, 16), (1000, 33), (70, 128)])
+def test_norm_layers_match_torch(N, H):
+    from graph_hscn.nn import BatchNorm1d, LayerNorm
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn(N, H, generator=g) * 3 + 1
+    gy = torch.randn(N, H, generator=g)
+    for cls_p, cls_o in ((LayerNorm, torch.nn.LayerNorm), (BatchNorm1d, torch.nn.BatchNorm1d)):
+        if cls_p is BatchNorm1d and N < 2:
+            continue
+        mo, mp = cls_o(H), cls_p(H).to(DEV)
+        with torch.no_grad():
+            mo.weight.add_(torch.randn(H, generator=g) * 0.3); mo.bias.add_(torch.randn(H, generator=g) * 0.3)
+        mp.load_state_dict(mo.state_dict())
+        xo = x.clone().requires_grad_(True)
+        xp = x.clone().to(DEV).requires_grad_(True)
+        yo, yp = mo(xo), mp(xp)
+        yo.backward(gy); yp.backward(gy.to(DEV))
+        assert close(yp, yo, atol=2e-5, rtol=1e-5)
+        assert close(xp.grad, xo.grad, atol=2e-5, rtol=1e-4)
+        assert close(mp.weight.grad, mo.weight.grad, atol=1e-4, rtol=1e-4) and close(mp.bias.grad, mo.bias.grad, atol=1e-4, rtol=1e-4)
+        for (n_, bo), (_, bp) in zip(mo.named_buffers(), mp.named_buffers()):
+            assert close(bp.float(), bo.float(), atol=1e-5, rtol=1e-5), n_

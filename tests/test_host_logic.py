@@ -180,8 +180,13 @@ def test_mpnn_config_and_factory():
     assert isinstance(m, MPNN) and len(m.conv_layers) == 3 and m.dropout == 0.2
     assert sorted(m.state_dict()) == sorted(OM.MPNN(OM.ACT["relu"], 9, 16, 10, 3).state_dict())
     assert [tuple(c.lin.weight.shape) for c in m.conv_layers] == [(16, 9), (16, 16), (10, 16)]
-    with pytest.raises(NotImplementedError):
-        build_mpnn(MPNNConfig("gcn", "relu", use_layer_norm=True), 9, 10)
+    # normalisation layers as the reference builds them (mpnn.py:34-44): BOTH lists under use_layer_norm, none under
+    # use_batch_norm alone; names and buffers are torch's
+    mn = build_mpnn(MPNNConfig("gcn", "relu", use_layer_norm=True), 9, 10)
+    ref = OM.MPNN(OM.ACT["relu"], 9, 16, 10, 3, use_layer_norm=True)
+    assert sorted(mn.state_dict()) == sorted(ref.state_dict())
+    assert len(mn.bns) == len(mn.lns) == 2 and isinstance(mn.bns[0], torch.nn.BatchNorm1d)
+    assert not hasattr(build_mpnn(MPNNConfig("gcn", "relu", use_batch_norm=True), 9, 10), "bns")
     with pytest.raises(KeyError):
         build_mpnn(MPNNConfig("gin", "relu"), 9, 10)          # GINConv(dim, dim) is a TypeError in PyG
 
