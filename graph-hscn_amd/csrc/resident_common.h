@@ -378,7 +378,9 @@ __device__ void build_csr_multisplit_lds(const int* ek, const int* eo, int ne, i
     int rank = 0;
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
-      const int k0 = __shfl(k, leader, 64);
+      // (leader is wave-uniform: v_readlane, one VALU operation -- a ds_bpermute round trip per distinct key made this
+      // loop the long pole of a 32-cluster build)
+      const int k0 = __builtin_amdgcn_readlane(k, leader);
       const unsigned long long m = __ballot(k == k0);
       if (k == k0) rank = __popcll(m & ((1ull << lane) - 1ull));
       if (lane == leader) cnt[k0 * nchunk + c] = __popcll(m);

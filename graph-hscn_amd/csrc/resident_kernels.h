@@ -1034,11 +1034,37 @@ __device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
         // ---- last chunk of cluster v: finish row v ----
         if (lane == 0) ck_arrive[v] = 0;   // ready for the next layer
         float4 z1r = make_float4(0.f, 0.f, 0.f, 0.f), z2r = z1r;
+        // virtual -> virtual GCN row v.  A row of more than eight edges (K = 32 clusters of a trained assignment: up to
+        // 32) is dealt to ALL slots of the wave -- slot s takes edges s, s + S, ... -- and the slots' partial rows are
+        // folded like the lv partials above (one trip instead of eight dependent ones on four lanes); a short row
+        // (the untrained assignment's ~3 clusters) stays on slot 0 in edge order.  Either way separately rounded
+        // products and sums; the grouping of the long rows' sums differs from the reference's edge order by rounding.
+        const int s2 = rowptr_vv[v], t2 = rowptr_vv[v + 1];
+        const float di = dinv_v[v];
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool wide = t2 - s2 > 8;
+        if (wide) {
+          for (int p = s2 + slot; p < t2; p += S) {
+            const int j = col_vv[p];
+            const float w = mul_rn(dinv_v[j], di);
+            const float4 x = *reinterpret_cast<const float4*>(xva + j * H + f);
+            a.x = add_rn(a.x, mul_rn(w, x.x)); a.y = add_rn(a.y, mul_rn(w, x.y));
+            a.z = add_rn(a.z, mul_rn(w, x.z)); a.w = add_rn(a.w, mul_rn(w, x.w));
+          }
+#pragma unroll
+          for (int off = 32; off >= 16 && off >= LPR; off >>= 1) {
+            a.x += __shfl_xor(a.x, off, 64); a.y += __shfl_xor(a.y, off, 64);
+            a.z += __shfl_xor(a.z, off, 64); a.w += __shfl_xor(a.w, off, 64);
+          }
+          if (LPR <= 8) {
+            a.x = row_ror_add<8>(a.x); a.y = row_ror_add<8>(a.y); a.z = row_ror_add<8>(a.z); a.w = row_ror_add<8>(a.w);
+          }
+          if (LPR <= 4) {
+            a.x = row_ror_add<4>(a.x); a.y = row_ror_add<4>(a.y); a.z = row_ror_add<4>(a.z); a.w = row_ror_add<4>(a.w);
+          }
+        }
         if (slot == 0) {
-          // virtual -> virtual GCN row v (edge order, separately rounded)
-          const int s2 = rowptr_vv[v], t2 = rowptr_vv[v + 1];
-          const float di = dinv_v[v];
-          float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!wide) {
           for (int p0 = s2; p0 < t2; p0 += 4) {
             int jj[4];
             float ww[4];
@@ -1059,6 +1085,7 @@ __device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
                 a.w = add_rn(a.w, mul_rn(ww[u], xx[u].w));
               }
             }
+          }
           }
           float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
           for (int c2 = 0; c2 < cntv; ++c2) {

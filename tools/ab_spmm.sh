@@ -1,7 +1,7 @@
 #!/bin/bash
 # streaming SpMM variants on one box: tools/ab_spmm.sh <tag>
 OUT=$PWD/gpurun_out/${1:-spmm}; mkdir -p $OUT
-for cfg in "HSCN_SPMM_PIPE=0" "HSCN_SPMM_PIPE=1" "HSCN_SPMM_PIPE=1 HSCN_SPMM_NT=1" "HSCN_SPMM_PIPE=1 HSCN_SPMM_BLOCKS=4096" "HSCN_SPMM_PIPE=1 HSCN_SPMM_BLOCKS=16384" "HSCN_SPMM_PIPE=1 HSCN_SPMM_NV=1"; do
+for cfg in "HSCN_SPMM_PIPE=1" "HSCN_SPMM_PASSES=1" "HSCN_SPMM_PASSES=2 HSCN_SPMM_XCD=1" "HSCN_SPMM_PASSES=4 HSCN_SPMM_XCD=1" "HSCN_SPMM_PASSES=8 HSCN_SPMM_XCD=1" "HSCN_SPMM_PASSES=16 HSCN_SPMM_XCD=1" "HSCN_SPMM_PASSES=8 HSCN_SPMM_XCD=0"; do
   echo "== $cfg"
   env $cfg python3 tools/bench_spmm.py --hidden 16 128 --iters 40 2>/dev/null | python3 -c "
 import sys, json

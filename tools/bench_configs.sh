@@ -4,7 +4,7 @@
 TAG=${1:-cfg}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-COMMON="--no-cpu-baseline --no-streaming-spmm --steps 200"
+COMMON="--no-cpu-baseline --no-streaming-spmm --no-stage-a-dense --steps 200"
 run() {  # name, args...
   name=$1; shift
   timeout -k 10 300 python bench.py "$@" $COMMON 2>/dev/null | tail -1 > $OUT/$name.json

@@ -27,13 +27,15 @@ def main():
     dev = torch.device("cuda:0")
     lib = _hip.lib()
     ids = "uniform" if "uniform" in sys.argv[1:] else "scn_untrained"
-    hb_host, graphs, _ = bench.build_hetero_batch("peptides_func", 128, 16, 0, dev, ids)
+    wl = next((w for w in bench.WORKLOADS if w in sys.argv[1:]), "peptides_func")      # e.g. peptides_struct, pcqm_contact
+    shape, B0, K0, C0, loss0 = bench.WORKLOADS[wl]
+    hb_host, graphs, _ = bench.build_hetero_batch(shape, B0, K0, 0, dev, ids)
     hb = hb_host.to(dev)
     if "f16" in sys.argv[1:]:
         hb = hb.with_feature_dtype(torch.float16)
     torch.manual_seed(0)
     Lyr = 3
-    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], 9, 16, 10, Lyr).to(dev)
+    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], hb_host["local"].x.size(1), 16, C0, Lyr).to(dev)
     B = hb.num_graphs
     buf = torch.zeros(2 * B, 64, dtype=torch.int64, device=dev)
     lib.hscn_diag_set_stamp_buffer.argtypes = [ctypes.c_void_p]
@@ -43,7 +45,7 @@ def main():
     if "resident" in sys.argv[1:]:
         from graph_hscn.engine import build_structure
         structure = build_structure(hb)
-    rs = ResidentTrainStep(model, hb, "cross_entropy", one_launch=True, structure=structure)
+    rs = ResidentTrainStep(model, hb, loss0, one_launch=True, structure=structure)
     for _ in range(3):
         rs.run()
     torch.cuda.synchronize()

@@ -9,7 +9,7 @@ TAG=${1:-sq}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-COMMON="--mode eager --steps 30 --warmup 5 --no-cpu-baseline --no-streaming-spmm --no-other-ids"
+COMMON="--mode eager --steps 30 --warmup 5 --no-cpu-baseline --no-streaming-spmm --no-other-ids --no-stage-a-dense"
 P1="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"
 P2="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"
 rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d $OUT/p1 -- python3 bench.py $COMMON > $OUT/bench_p1.json 2> $OUT/p1.err || { tail -5 $OUT/p1.err; exit 1; }
