@@ -113,6 +113,23 @@ class OptimConfig:  # config.py:96-112
 
 
 @dataclass
+class PEConfig:  # config.py:115-130 (defaults.py:19-28)
+    dim_in: int
+    dim_emb: int
+    dim_pe: int
+    model: str = "DeepSet"
+    layers: int = 1
+    post_layers: int = 1
+    eigen_max_freqs: int = 10
+    eigvec_norm: str = "L2"
+    eigen_laplacian_norm: str = "sym"
+    phi_hidden_dim: int = 32
+    phi_out_dim: int = 4
+    pass_as_var: bool = False
+    use_bn: bool = False
+
+
+@dataclass
 class TrainingConfig:  # config.py:133-152
     model_type: str
     loss_fn: str
