@@ -66,8 +66,9 @@ def parse():
                          "lists; dataset-resident: they were built once (hscn_resident_structure; graph structure is "
                          "epoch-invariant) and the step loads them -- a second, labelled line; cached: the layered "
                          "engine's per-batch cache")
-    ap.add_argument("--steps-per-graph", type=int, default=4,
-                    help="graph mode: capture this many consecutive steps (each with its gradient all-reduce) in one "
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="0 (default): the largest divisor of --steps that is <= 20.  "
+                         "graph mode: capture this many consecutive steps (each with its gradient all-reduce) in one "
                          "hipGraph -- the host's replay overhead (~4 us per graph launch) is then paid once per group, as "
                          "in a training loop that captures several iterations per replay; the timed region is still "
                          "exactly --steps steps, and the line carries the 1-step-per-graph figure beside it")
@@ -104,7 +105,10 @@ def parse():
                          "B = 128, K = 64, MinCUT coarsening step on the dense MFMA route, with its MFMA roofline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps_per_graph <= 0:
+        args.steps_per_graph = max(d for d in range(1, 21) if args.steps % d == 0) if args.steps > 0 else 1
+    return args
 
 
 def build_hetero_batch(workload, B, K, seed, dev, cluster_ids="scn_untrained"):
@@ -237,6 +241,10 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+MAIN_SETTLE_S = 0.1          # one rank: untimed replays for this long before the --warmup steps
+MAIN_SETTLE_STEPS = 2000     # ranks with a collective in the step: a fixed number instead (same count on every rank)
+
+
 def capture(fn, warmup=3):
     """Warm ``fn`` up on a side stream, then capture it as one hipGraph."""
     side = torch.cuda.Stream()
@@ -344,6 +352,10 @@ class TimedStep:
             self.spg = spg_override
         if self.spg > 1:
             self.multi = capture(lambda: [body() for _ in range(self.spg)], warmup=1)
+            # the first launch of an instantiated graph uploads it (kernel arguments, node records): do that here, not
+            # inside a timed region whose --warmup is shorter than one replay of this graph
+            self.multi.replay()
+            torch.cuda.synchronize()
 
         def run(n):
             if self.multi is not None:
@@ -357,7 +369,7 @@ class TimedStep:
         self.run = run
 
 
-def time_steps(ts, steps, warmup, barrier, settle_s=0.0):
+def time_steps(ts, steps, warmup, barrier, settle_s=0.0, settle_steps=0):
     """`warmup` untimed steps, then exactly `steps` timed ones between two barriers.  settle_s (secondary legs only):
     keep replaying untimed for that long first -- those legs start after seconds of host-only work (building another
     batch), and 20 warm-up steps (< 1 ms) were seen to leave the timed steps at twice their duration now and then."""
@@ -366,6 +378,9 @@ def time_steps(ts, steps, warmup, barrier, settle_s=0.0):
         while time.perf_counter() < t_end:
             ts.run(max(1, warmup))
             torch.cuda.synchronize()
+    if settle_steps > 0:      # the multi-rank form: every rank issues the same number of exchanges
+        ts.run(settle_steps)
+        torch.cuda.synchronize()
     ts.run(warmup)
     barrier()
     t0 = time.perf_counter()
@@ -640,7 +655,10 @@ def main():
         torch.cuda.synchronize()
 
     ts = TimedStep(args, model, hb, loss_fn, reducer, B, world)
-    dt = time_steps(ts, args.steps, args.warmup, barrier)
+    # settle: the step has just been captured after seconds of host-only work (batch building, instantiation); 0.1 s of
+    # untimed replays first, then the --warmup steps, then exactly --steps timed ones (reported as config.settle_s)
+    dt = time_steps(ts, args.steps, args.warmup, barrier, settle_s=MAIN_SETTLE_S if reducer is None else 0.0,
+                    settle_steps=0 if reducer is None else MAIN_SETTLE_STEPS)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -946,6 +964,8 @@ def main():
                        "vv_edges_per_gpu": int(hb[("virtual", "to", "virtual")].edge_index.size(1)),
                        "mode": args.mode, "engine": model.last_engine, "structure_build": args.structure,
                        "steps_per_graph": spg,
+                       "settle": (f"{MAIN_SETTLE_S} s of untimed replays" if reducer is None else f"{MAIN_SETTLE_STEPS} untimed steps")
+                                 + " before the --warmup steps",
                        "step_issue": ("direct C-ABI launches (graph_hscn.step.ResidentTrainStep)" if ts.fused is not None
                                       else "autograd"),
                        "allreduce": (None if reducer is None else
