@@ -140,6 +140,14 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   const float r2 = __int_as_float(__builtin_amdgcn_readlane(r, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(r, 48));
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+__device__ __forceinline__ int wave_max_int(int v) {   // fully active wave
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 // reductions over aligned groups of KP consecutive lanes (KP a power of two; every lane of the group
 // receives the result): DPP inside a 16-lane row (xor 1, xor 2, mirror inside 8, mirror inside 16),
 // bpermute only across rows
@@ -174,6 +182,29 @@ __device__ __forceinline__ float row_ror_add(float v) {
 template <int K>
 __device__ __forceinline__ float row_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xF, 0xF, true));
+}
+// the value lane U of each aligned group of four lanes holds, in all four (DPP quad_perm [U,U,U,U])
+template <int U>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), U * 0x55, 0xF, 0xF, true));
+}
+template <int U>
+__device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, U * 0x55, 0xF, 0xF, true);
+}
+// out[r] = acc + sum_k z[k] Wt[k * 16 + r], k ascending, for a 16-vector z that lives four features per lane
+// (lane u of a DPP row holds z[4u .. 4u+3], u = 0 .. 3) and a 16 x 16 matrix in LDS; r = this lane's index in its row
+template <int KQ = 0>
+__device__ __forceinline__ float row_matvec16(const float4& z, const float* Wt, int r, float acc) {
+  if constexpr (KQ < 4) {
+    acc = fmaf(row_bcast<KQ>(z.x), Wt[(4 * KQ + 0) * 16 + r], acc);
+    acc = fmaf(row_bcast<KQ>(z.y), Wt[(4 * KQ + 1) * 16 + r], acc);
+    acc = fmaf(row_bcast<KQ>(z.z), Wt[(4 * KQ + 2) * 16 + r], acc);
+    acc = fmaf(row_bcast<KQ>(z.w), Wt[(4 * KQ + 3) * 16 + r], acc);
+    return row_matvec16<KQ + 1>(z, Wt, r, acc);
+  } else {
+    return acc;
+  }
 }
 // acc = fmaf(x_k, w[k], acc) for k = 0 .. N-1 in ascending order, x_k = the value of lane k of this lane's DPP row:
 // one row of a small matrix-vector product whose vector lives one element per lane

@@ -535,7 +535,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int H, int C, int max_n, int max
   Y.cursorV = scratch(max_v + 1);
   Y.tmpV = scratch(max_evv);
   Y.ck_tab = take(max_v ? maxck : 0);
-  Y.ck_first = take(max_v ? max_v + 1 : 0);
+  Y.ck_first = take(max_v ? max_v + 2 : 0);     // + the chunk count and the largest cluster's size
   Y.ck_arrive = take(max_v ? max_v + 1 : 0);   // + the work counter of the chunk list (ck_arrive[max_v])
   Y.total = o;
   return Y;
@@ -617,13 +617,14 @@ __device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
 
   // softmax work list (layer independent), built by ONE wave: cluster v is cut into
   // max(1, ceil(size/64)) chunks of 64 members; entry k = (v << 8) | index inside v,
-  // ck_first[v] = first chunk of v, ck_first[nv] = number of chunks
+  // ck_first[v] = first chunk of v, ck_first[nv] = number of chunks, ck_first[nv + 1] = size of the largest cluster
   auto build_chunk_table = [&]() {
     const int lane = threadIdx.x & 63;
-    int carry = 0;
+    int carry = 0, maxsz = 0;
     for (int base = 0; base < nv; base += 64) {
       const int v = base + lane;
       const int sz = v < nv ? rowptr_lv[v + 1] - rowptr_lv[v] : 0;
+      maxsz = max(maxsz, wave_max_int(sz));
       const int cnt = v < nv ? (sz > 64 ? (sz + 63) >> 6 : 1) : 0;
       const int incl = wave_incl_scan(cnt);
       const int first = carry + incl - cnt;
@@ -634,7 +635,7 @@ __device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
       }
       carry += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (lane == 0) ck_first[nv] = carry;
+    if (lane == 0) { ck_first[nv] = carry; ck_first[nv + 1] = maxsz; }
   };
 
   // ---- prologue: request every global input of this graph, then consume -----------------------
@@ -953,6 +954,112 @@ __device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
       // not depend on who runs it, a cluster is finished by its last arriver in chunk order: same bits as before.
       int* ck_next = ck_arrive + cap_v;
       (void)G_;
+      if constexpr (H == 16) {
+        // ---- many small clusters (a balanced assignment: K = 16 .. 32 clusters of a few members each) ----
+        // One wave per cluster leaves most of the wave idle and takes nv / NW rounds.  Here a 16-lane DPP row owns a
+        // cluster, four clusters per wave: lane r of the row computes the attention logit of member (r % 4) * 4 + r / 4
+        // of the current 16-member tile, so the four lanes of quad q hold members q, q+4, q+8, q+12 -- exactly the
+        // members slot q (= the quad, four lanes x float4 = one 16-feature row) accumulates, reached by quad
+        // broadcasts; softmax max / sum are row reductions, the slots fold by row rotations, and the two 16 x 16
+        // transforms read their vector through row broadcasts.  No LDS traffic besides the operands themselves.
+        // Same arithmetic per element as the chunk path below, another summation order (members of a cluster
+        // interleaved over four slots instead of sixteen).
+        const int maxsz = ck_first[nv + 1];
+        if (maxsz <= 16 || (maxsz <= 64 && nv > NW)) {
+          const int grp = lane >> 4, r = lane & 15, q = r >> 2, u4 = r & 3;
+          const int pm = u4 * 4 + q, fq = u4 * 4;
+          const int nq = (nv + 3) >> 2;
+          const float* Ws = W + H * H;                     // Wt_src[k][o]
+          const float* Wv = W + 3 * H * H;                 // Wt_vv[k][o]
+          for (;;) {
+            int ck = 0;
+            if (lane == 0) ck = __hip_atomic_fetch_add(ck_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ck = __builtin_amdgcn_readfirstlane(ck);
+            if (ck >= nq) break;
+            const int v = 4 * ck + grp;
+            const bool vok = v < nv;
+            const int vc = vok ? v : nv - 1;               // (a row past the last cluster: empty ranges, nothing stored)
+            const int s = rowptr_lv[vc], t = vok ? rowptr_lv[vc + 1] : s;
+            const int s2 = rowptr_vv[vc], t2 = vok ? rowptr_vv[vc + 1] : s2;
+            const float ad = a_d[vc], di = dinv_v[vc];
+            const int cnt = t - s, cnt2 = t2 - s2;
+            const int tiles = (max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                                   max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48))) + 15) >> 4;
+            const int tiles2 = (max(max(__builtin_amdgcn_readlane(cnt2, 0), __builtin_amdgcn_readlane(cnt2, 16)),
+                                    max(__builtin_amdgcn_readlane(cnt2, 32), __builtin_amdgcn_readlane(cnt2, 48))) + 15) >> 4;
+            float e[4];
+            int jm[4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+              e[ti] = -INFINITY;
+              jm[ti] = 0;
+              if (ti < tiles) {
+                const int p = s + ti * 16 + pm;
+                const bool on = p < t;
+                jm[ti] = on ? col_lv[p] : 0;
+                e[ti] = on ? leaky(a_s[jm[ti]] + ad, A.slope) : -INFINITY;
+                m = fmaxf(m, e[ti]);
+              }
+            }
+            m = row16_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+              if (ti < tiles) {
+                e[ti] = e[ti] > -INFINITY ? expf(e[ti] - m) : 0.f;
+                sum += e[ti];
+              }
+            }
+            const float denom = row16_sum(sum) + 1e-16f;
+            float4 z1 = make_float4(0.f, 0.f, 0.f, 0.f), z2 = z1;
+            auto lv_trip = [&](float au, int ju) {
+              const float4 x = *reinterpret_cast<const float4*>(xa + ju * H + fq);
+              if (au != 0.f) {
+                z1.x = fmaf(au, x.x, z1.x); z1.y = fmaf(au, x.y, z1.y);
+                z1.z = fmaf(au, x.z, z1.z); z1.w = fmaf(au, x.w, z1.w);
+              }
+            };
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+              if (ti < tiles) {
+                const float al = e[ti] / denom;
+                lv_trip(quad_bcast<0>(al), quad_bcast<0>(jm[ti]));
+                lv_trip(quad_bcast<1>(al), quad_bcast<1>(jm[ti]));
+                lv_trip(quad_bcast<2>(al), quad_bcast<2>(jm[ti]));
+                lv_trip(quad_bcast<3>(al), quad_bcast<3>(jm[ti]));
+              }
+            }
+            // virtual -> virtual GCN row: separately rounded products and sums, as in the chunk path
+            auto vv_trip = [&](float wu, int ju, int ou) {
+              const float4 x = *reinterpret_cast<const float4*>(xva + ju * H + fq);
+              if (ou) {
+                z2.x = add_rn(z2.x, mul_rn(wu, x.x)); z2.y = add_rn(z2.y, mul_rn(wu, x.y));
+                z2.z = add_rn(z2.z, mul_rn(wu, x.z)); z2.w = add_rn(z2.w, mul_rn(wu, x.w));
+              }
+            };
+            for (int ti = 0; ti < tiles2; ++ti) {
+              const int p = s2 + ti * 16 + pm;
+              const int on = p < t2;
+              const int jj = on ? col_vv[p] : 0;
+              const float w = on ? mul_rn(dinv_v[jj], di) : 0.f;
+              vv_trip(quad_bcast<0>(w), quad_bcast<0>(jj), quad_bcast<0>(on));
+              vv_trip(quad_bcast<1>(w), quad_bcast<1>(jj), quad_bcast<1>(on));
+              vv_trip(quad_bcast<2>(w), quad_bcast<2>(jj), quad_bcast<2>(on));
+              vv_trip(quad_bcast<3>(w), quad_bcast<3>(jj), quad_bcast<3>(on));
+            }
+            // fold the four slots (every lane ends with the same sum: a + b is commutative bit for bit)
+            z1.x = row_ror_add<8>(z1.x); z1.y = row_ror_add<8>(z1.y); z1.z = row_ror_add<8>(z1.z); z1.w = row_ror_add<8>(z1.w);
+            z2.x = row_ror_add<8>(z2.x); z2.y = row_ror_add<8>(z2.y); z2.z = row_ror_add<8>(z2.z); z2.w = row_ror_add<8>(z2.w);
+            z1.x = row_ror_add<4>(z1.x); z1.y = row_ror_add<4>(z1.y); z1.z = row_ror_add<4>(z1.z); z1.w = row_ror_add<4>(z1.w);
+            z2.x = row_ror_add<4>(z2.x); z2.y = row_ror_add<4>(z2.y); z2.z = row_ror_add<4>(z2.z); z2.w = row_ror_add<4>(z2.w);
+            const float og = row_matvec16(z1, Ws, r, 0.f);
+            const float ov = row_matvec16(z2, Wv, r, 0.f);
+            if (vok) xvb[v * H + r] = rnd<TS>(fmaxf((ov + b_vv[r]) + (og + b_gat[r]), 0.f));
+          }
+          return;
+        }
+      }
       for (;;) {
         int ck = 0;
         if (lane == 0) ck = __hip_atomic_fetch_add(ck_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2350,8 +2457,13 @@ int impl_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t
   hipStream_t st = hscn_stream(stream_);
   int rc = H == 16 ? launch_step<16, TS>(S, job ? &V : nullptr, st) : launch_step<32, TS>(S, job ? &V : nullptr, st);
   if (rc) return rc;
+#ifdef HSCN_DIAG_REDUCE_BLOCKS   // measurement builds only (tools/build_variant.sh): what the launch costs without its work
+  k_param_reduce<<<HSCN_DIAG_REDUCE_BLOCKS, 256, 0, st>>>(partials, grads, (int)B, S.P, S.Pn, S.inv_count,
+                                                          S.ready ? sync : nullptr);
+#else
   k_param_reduce<<<hscn_blocks(S.P, 32), 256, 0, st>>>(partials, grads, (int)B, S.P, S.Pn, S.inv_count,
                                                        S.ready ? sync : nullptr);
+#endif
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
