@@ -10,6 +10,7 @@
 // MFMA-bound only at PascalVOC-SP sizes (n ~ 480, K = 64: 33 MFLOP per graph); at Peptides
 // sizes the sparse route (mincut.hip) does 8x less work.
 #include "hscn_common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -374,7 +375,7 @@ k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restri
 // (4 registers per slab for bytes); only the S slab (L2-resident, shared by the graph's workgroups) goes through LDS,
 // read as rows 16 h + j.  The row sums (degrees) are the sums of the operands a lane feeds, its two halves folded by
 // one cross-half shuffle.
-template <typename AT, int NT, bool RS>
+template <typename AT, int NT, bool RS, bool KV = true>
 __global__ void __launch_bounds__(256)
 k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
                const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
@@ -402,13 +403,21 @@ k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* _
   for (int q = 0; q < NT; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int k_last = ((n - 1) / BK) * BK;    // first column of the last slab
   auto fetchA = [&](int k0, unsigned (&ra)[AR]) {
+    if constexpr (U8) {
+      // branch-free: rows are padded to 32 columns and zero filled (no column guard); a row past the graph reads row 0
+      // (its products land in accumulator rows that are never stored, its row sum is never stored); a slab past the
+      // end re-reads the last one and is never multiplied.  An unconditional load keeps the request in flight across
+      // the slab barrier instead of behind an exec branch with its own wait.
+      const uint4 w = *reinterpret_cast<const uint4*>(arow + (k0 < k_last ? k0 : k_last));
+      ra[0] = w.x; ra[1] = w.y; ra[2] = w.z; ra[3] = w.w;
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < AR; ++u) ra[u] = 0u;
     if (row < n && k0 < n) {
-      if constexpr (U8) {            // (rows are padded to 32 and zero filled: no column guard)
-        const uint4 w = *reinterpret_cast<const uint4*>(arow + k0);
-        ra[0] = w.x; ra[1] = w.y; ra[2] = w.z; ra[3] = w.w;
+      if constexpr (U8) {
       } else {
         const float* p = reinterpret_cast<const float*>(arow) + k0;
         const int c = k0 + 16 * lh;
@@ -432,26 +441,44 @@ k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* _
     if constexpr (U8) return (float)((ra[j >> 2] >> (8 * (j & 3))) & 0xffu);
     else return __uint_as_float(ra[j]);
   };
+  // KV (K % 4 == 0, what the route's cluster counts are): the S slab is requested branch-free -- clamped addresses,
+  // 16-byte pieces -- and rows / columns outside the graph become exact zeros by a select applied when the piece is
+  // PARKED (after the slab's MFMAs), so nothing consumes the load before then.
   float4 rb[2];
+  bool rok[2];
   auto fetchB = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int gr = k0 + (t >> 4) + 16 * u, c4 = (t & 15) * 4;
-      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < n && c4 < Kc && c4 < 32 * NT) {
-        const float* p = Sb + (size_t)gr * K + c4;
-        if (c4 + 3 < Kc) rb[u] = ld4u(p);
-        else {
-          rb[u].x = p[0];
-          if (c4 + 1 < Kc) rb[u].y = p[1];
-          if (c4 + 2 < Kc) rb[u].z = p[2];
+      if constexpr (KV) {
+        const int grc = gr < n ? gr : n - 1, cc = c4 + 4 <= Kc ? c4 : Kc - 4;
+        rb[u] = ld4u(Sb + (size_t)grc * K + cc);
+        rok[u] = gr < n && c4 < Kc && c4 < 32 * NT;
+      } else {
+        rok[u] = true;
+        rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < n && c4 < Kc && c4 < 32 * NT) {
+          const float* p = Sb + (size_t)gr * K + c4;
+          if (c4 + 3 < Kc) rb[u] = ld4u(p);
+          else {
+            rb[u].x = p[0];
+            if (c4 + 1 < Kc) rb[u].y = p[1];
+            if (c4 + 2 < Kc) rb[u].z = p[2];
+          }
         }
       }
     }
   };
   auto parkB = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Bs[buf][((t >> 4) + 16 * u) * BS_ST + (t & 15) * 4]) = rb[u];
+    for (int u = 0; u < 2; ++u) {
+      const float4 v = rb[u];
+      const bool ok = rok[u];
+      // rows 16 .. 31 (the operands of lane half 1) sit 32 columns over, modulo the row: the two halves of a wave read
+      // rows 16 apart -- 1 024 words, the same banks -- in one instruction; now they hit disjoint halves of the banks
+      *reinterpret_cast<float4*>(&Bs[buf][((t >> 4) + 16 * u) * BS_ST + (((t & 15) * 4) ^ (32 * u))]) =
+          make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
   };
   unsigned a0[AR], a1[AR], a2[AR];
   fetchA(0, a0);
@@ -461,23 +488,40 @@ k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* _
   __syncthreads();
   int buf = 0;
   float rs = 0.f;
-  for (int k0 = 0; k0 < n; k0 += BK) {
-    const bool more = k0 + BK < n;
-    fetchA(k0 + 2 * BK, a2);                  // two slabs ahead (past the end: zeros, no request)
+  // One slab: request S of the next slab and A of the slab after next, multiply, park S, barrier.  The three operand
+  // register sets ROTATE BY NAME (the loop is unrolled three slabs deep): copying them down the pipeline would make
+  // every slab wait for the load it has just issued.  The S request goes out before the A request, so the wait in front
+  // of parkB (vmcnt counts in order) leaves the A loads in flight; the barrier waits for LDS only (`lds_barrier`, not
+  // __syncthreads, which drains the vector-memory counter too): an A load has two full slabs to arrive.
+  auto slab = [&](auto has_next, const unsigned (&cur)[AR], unsigned (&tgt)[AR], int k0) {
+    const bool more = decltype(has_next)::value || k0 + BK < n;
     if (more) fetchB(k0 + BK);
-    const float* bs = Bs[buf] + lh * 16 * BS_ST + li;
+    fetchA(k0 + 2 * BK, tgt);                 // two slabs ahead (past the end: the last slab again, never multiplied)
+    const float* bs = Bs[buf] + lh * 16 * BS_ST;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float a = a_of(a0, j);
+      const float a = a_of(cur, j);
       if (RS) rs += a;
 #pragma unroll
-      for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[j * BS_ST + q * 32], acc[q], 0, 0, 0);
+      for (int q = 0; q < NT; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[j * BS_ST + ((q * 32 + li) ^ (32 * lh))], acc[q], 0, 0, 0);
     }
     if (more) parkB(buf ^ 1);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     buf ^= 1;
-#pragma unroll
-    for (int u = 0; u < AR; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; }
+  };
+  // main loop: triples of slabs that all have a successor (no conditionals inside: the compiler's wait counters stay
+  // exact across the back edge); then the one to three slabs that are left
+  int k0 = 0;
+  for (; k0 + 3 * BK < n; k0 += 3 * BK) {
+    slab(std::true_type{}, a0, a2, k0);
+    slab(std::true_type{}, a1, a0, k0 + BK);
+    slab(std::true_type{}, a2, a1, k0 + 2 * BK);
+  }
+  slab(std::false_type{}, a0, a2, k0);
+  if (k0 + BK < n) {
+    slab(std::false_type{}, a1, a0, k0 + BK);
+    if (k0 + 2 * BK < n) slab(std::false_type{}, a2, a1, k0 + 2 * BK);
   }
   if (RS) {
     rs += __shfl_xor(rs, 32, 64);
@@ -615,13 +659,17 @@ int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int
     return 0;
   }
   if (!transA && !via_lds) {
-    // K > 32 with byte adjacency: two workgroups per row tile, 32 columns each (HSCN_DENSE_SPLIT=0: one, 64 columns)
-    static const bool split_env = !(getenv("HSCN_DENSE_SPLIT") && atoi(getenv("HSCN_DENSE_SPLIT")) == 0);
+    // K > 32: one workgroup per row tile with two 32-column accumulators per wave (two independent MFMA chains, A read
+    // once); HSCN_DENSE_SPLIT=1: two workgroups of 32 columns each (measured 2 us slower on the forward call)
+    static const bool split_env = getenv("HSCN_DENSE_SPLIT") && atoi(getenv("HSCN_DENSE_SPLIT")) == 1;
     const bool split = NT == 2 && sizeof(AT) == 1 && split_env;
     dim3 gd(grid.x, grid.y, split ? 2 : 1);
-#define HSCN_ADJ_D(NT_, RS_) k_adj_s_direct<AT, NT_, RS_><<<gd, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K)
-    if (rsum) { if (NT == 2 && !split) HSCN_ADJ_D(2, true); else HSCN_ADJ_D(1, true); }
-    else { if (NT == 2 && !split) HSCN_ADJ_D(2, false); else HSCN_ADJ_D(1, false); }
+    static const int lds_pad = getenv("HSCN_DENSE_LDS_PAD") ? atoi(getenv("HSCN_DENSE_LDS_PAD")) : 0;   // A/B: workgroups per CU
+#define HSCN_ADJ_D(NT_, RS_, KV_) k_adj_s_direct<AT, NT_, RS_, KV_><<<gd, 256, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K)
+#define HSCN_ADJ_DK(NT_, RS_) do { if ((K & 3) == 0) HSCN_ADJ_D(NT_, RS_, true); else HSCN_ADJ_D(NT_, RS_, false); } while (0)
+    if (rsum) { if (NT == 2 && !split) HSCN_ADJ_DK(2, true); else HSCN_ADJ_DK(1, true); }
+    else { if (NT == 2 && !split) HSCN_ADJ_DK(2, false); else HSCN_ADJ_DK(1, false); }
+#undef HSCN_ADJ_DK
 #undef HSCN_ADJ_D
     HSCN_RETURN_IF_LAUNCH_FAILED();
     return 0;

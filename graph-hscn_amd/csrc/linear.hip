@@ -3,6 +3,7 @@
 // 99-100,112-113).  Widths are 9..128, so W lives in LDS and rows stream from HBM
 // once; weight gradients reduce in two ordered stages (no float atomics).
 #include "hscn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -128,6 +129,69 @@ k_linear_bwd_w_partial(const float* __restrict__ gy, const float* __restrict__ x
   }
 }
 
+// The same partials on the matrix cores (O a multiple of 16, TO x TI <= 8 accumulator tiles): gW = gy^T [x | 1] is a
+// product with the ROWS as the reduction index, so a wave owns a row chunk and walks it four rows per
+// v_mfma_f32_16x16x4_f32 -- A[i = lane & 15][k = lane >> 4] = gy[r + k][16 to + i], B[k][j = lane & 15] =
+// [x | 1][r + k][16 ti + j] -- with both operands loaded STRAIGHT from global memory into the operand registers (a
+// half-row of 64 B per row and instruction; eight steps = 32 rows of requests in flight per trip): no LDS tile, no
+// barrier, no load -> sync -> multiply -> sync serialisation per 32 rows (the scalar kernel above spends 26 us on
+// 57 k rows x 64 x 17 for that reason).  The MFMA is a k-ordered fmaf chain: a chunk's partial is the fmaf chain over
+// its rows in row order, like the scalar kernel's.  One wave per workgroup: 512 chunks fill the chip.
+template <int TO, int TI>
+__global__ void __launch_bounds__(64)
+k_linear_bwd_w_mfma(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ partial,
+                    int64_t rows, int I, int O, int64_t rows_per_chunk, int P) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+  const int I1 = I + 1;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
+  int64_t r_end = r_begin + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  f32x4 acc[TO][TI];
+#pragma unroll
+  for (int a = 0; a < TO; ++a)
+#pragma unroll
+    for (int b = 0; b < TI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = (TO + TI) <= 3 ? 8 : 4;      // k-steps of requests in flight per trip
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 4 * U) {
+    float av[U][TO], bv[U][TI];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + 4 * u + lk;
+      const bool ok = r < r_end;
+      const int64_t rc = ok ? r : r_begin;       // (a row past the chunk: any valid address, the value is dropped)
+#pragma unroll
+      for (int a = 0; a < TO; ++a) {
+        const float v = gy[rc * O + 16 * a + li];
+        av[u][a] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < TI; ++b) {
+        const int c = 16 * b + li;
+        float v = c == I ? 1.f : 0.f;
+        if (c < I) v = x[rc * I + c];
+        bv[u][b] = ok ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int a = 0; a < TO; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+  }
+  float* out = partial + (size_t)blockIdx.x * P;
+#pragma unroll
+  for (int a = 0; a < TO; ++a)
+#pragma unroll
+    for (int b = 0; b < TI; ++b) {
+      const int i = 16 * b + li;
+      if (i >= I1) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[(16 * a + 4 * lk + q) * I1 + i] = acc[a][b][q];
+    }
+}
+
 // gW / gb [p] = sum over the G row chunks of partial[g][p], in a FIXED tree (bitwise reproducible): a block owns 32
 // parameters x 8 contiguous slices of chunks, a slice is summed in chunk order with 16 loads in flight, the slices are
 // folded in slice order.  (One thread walking all G <= 512 chunks in a dependent chain took 55 us at G = 235.)
@@ -180,7 +244,7 @@ __global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, in
 }
 
 inline int chunks_for(int64_t rows) {
-  int64_t g = (rows + 255) / 256;
+  int64_t g = (rows + 63) / 64;
   if (g < 1) g = 1;
   if (g > 512) g = 512;
   return (int)g;
@@ -247,8 +311,20 @@ int hscn_linear_bwd_w(const float* gy, const float* x, float* gW, float* gb, int
   while (T > 1 && (size_t)T * (O + I + 1) * 4 > 64 * 1024) T >>= 1;
   size_t lds = (size_t)T * (O + I + 1) * 4;
   if (lds > 64 * 1024) return HSCN_E_UNSUPPORTED;
-  dim3 grid(G, (P + BW_PAIRS - 1) / BW_PAIRS);
-  k_linear_bwd_w_partial<<<grid, LIN_THREADS, lds, st>>>(gy, x, (float*)workspace, rows, I, O, rpc, P, T);
+  const int TO = O / 16, TI = (I + 1 + 15) / 16;
+  static const bool no_mfma = getenv("HSCN_LINEAR_BWD_W") && atoi(getenv("HSCN_LINEAR_BWD_W")) == 0;   // A/B
+  bool done = false;
+  if (!no_mfma && O % 16 == 0 && TO * TI <= 8 && TO <= 4 && TI <= 4) {
+#define HSCN_BWM(TO_, TI_) if (TO == TO_ && TI == TI_) { k_linear_bwd_w_mfma<TO_, TI_><<<G, 64, 0, st>>>(gy, x, (float*)workspace, rows, I, O, rpc, P); done = true; }
+    HSCN_BWM(1, 1) HSCN_BWM(1, 2) HSCN_BWM(1, 3) HSCN_BWM(1, 4)
+    HSCN_BWM(2, 1) HSCN_BWM(2, 2) HSCN_BWM(2, 3) HSCN_BWM(2, 4)
+    HSCN_BWM(3, 1) HSCN_BWM(3, 2) HSCN_BWM(4, 1) HSCN_BWM(4, 2)
+#undef HSCN_BWM
+  }
+  if (!done) {
+    dim3 grid(G, (P + BW_PAIRS - 1) / BW_PAIRS);
+    k_linear_bwd_w_partial<<<grid, LIN_THREADS, lds, st>>>(gy, x, (float*)workspace, rows, I, O, rpc, P, T);
+  }
   k_linear_bwd_w_reduce<<<hscn_blocks(P, 32), 256, 0, st>>>((const float*)workspace, gW, gb, G, I, O, P,
                                                             accumulate);
   HSCN_RETURN_IF_LAUNCH_FAILED();
