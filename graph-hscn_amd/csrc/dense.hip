@@ -216,7 +216,7 @@ k_bgemm(const float* __restrict__ A, const BRhs3 R, int M, int Kd, int64_t lda, 
 // AT = uint8_t: the counts as bytes ([B, nmax, lda8], lda8 = nmax rounded up to 32, zero filled; what the model's own
 // batched route builds): 4x less traffic, converted exactly on the way into LDS (v_cvt_f32_ubyte*).
 // RS (TA = 0): also the row sums of A (degrees), from the LDS image.
-template <typename AT, int TA, int NT, bool RS>
+template <typename AT, int TA, int NT, bool RS, bool KV = false>
 __global__ void __launch_bounds__(256)
 k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
         const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
@@ -241,21 +241,35 @@ k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restri
   // staging registers: the A slab is 128 x 32 (TA = 0) or 32 x 128 (TA = 1) elements, 16 per thread; the S slab 32 x 64
   float ra[16];
   float4 rb[2];
+  uint4 wraw = make_uint4(0u, 0u, 0u, 0u);
+  bool rok[2] = {true, true};
+  // KV (byte adjacency, K % 4 == 0): both slabs are requested branch-free from clamped addresses and nothing touches
+  // the loaded registers until they are PARKED behind the slab's MFMAs (the byte -> float conversion and the zeroing of
+  // rows / columns outside the graph happen there): a request issued at the top of a slab has the whole slab to arrive.
+  // Entries of A outside the graph may then be any byte -- they only ever meet rows of S that are exact zeros, or land
+  // in output rows that are not stored.
   auto fetch = [&](int k0) {
+    if constexpr (sizeof(AT) == 1 && KV) {
+      const int r = TA ? (t >> 3) : (t >> 1), c16 = TA ? (t & 7) * 16 : (t & 1) * 16;
+      const int gr = TA ? k0 + r : m0 + r, gc = TA ? m0 + c16 : k0 + c16;
+      const int grc = gr < n ? gr : n - 1, gcc = gc + 16 <= lda ? gc : (int)lda - 16;
+      wraw = *reinterpret_cast<const uint4*>(Ab + (size_t)grc * lda + gcc);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int sr = k0 + (t >> 4) + 16 * u, c4 = (t & 15) * 4;
+        const int src = sr < n ? sr : n - 1, cc = c4 + 4 <= K ? c4 : K - 4;
+        rb[u] = ld4u(Sb + (size_t)src * K + cc);
+        rok[u] = sr < n && c4 < K;
+      }
+      return;
+    }
     if constexpr (sizeof(AT) == 1) {
       // 16 consecutive bytes per thread (rows are padded to 32 and zero filled: no column guard)
       const int r = TA ? (t >> 3) : (t >> 1), c16 = TA ? (t & 7) * 16 : (t & 1) * 16;
       const int gr = TA ? k0 + r : m0 + r, gc = TA ? m0 + c16 : k0 + c16;
       uint4 w = make_uint4(0u, 0u, 0u, 0u);
       if (gr < n && gc < lda) w = *reinterpret_cast<const uint4*>(Ab + (size_t)gr * lda + gc);
-      const unsigned ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ra[4 * j + 0] = (float)(ww[j] & 0xffu);
-        ra[4 * j + 1] = (float)((ww[j] >> 8) & 0xffu);
-        ra[4 * j + 2] = (float)((ww[j] >> 16) & 0xffu);
-        ra[4 * j + 3] = (float)(ww[j] >> 24);
-      }
+      wraw = w;
     } else {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -293,6 +307,14 @@ k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restri
   auto park = [&](int buf) {
     float* as = As[buf];
     if constexpr (sizeof(AT) == 1) {
+      const unsigned ww[4] = {wraw.x, wraw.y, wraw.z, wraw.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ra[4 * j + 0] = (float)(ww[j] & 0xffu);
+        ra[4 * j + 1] = (float)((ww[j] >> 8) & 0xffu);
+        ra[4 * j + 2] = (float)((ww[j] >> 16) & 0xffu);
+        ra[4 * j + 3] = (float)(ww[j] >> 24);
+      }
       if (TA) {      // 16 consecutive m of row k
         const int k = t >> 3, c16 = (t & 7) * 16;
 #pragma unroll
@@ -318,7 +340,12 @@ k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restri
     }
     float* bs = Bs[buf];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&bs[((t >> 4) + 16 * u) * BS_ST + (t & 15) * 4]) = rb[u];
+    for (int u = 0; u < 2; ++u) {
+      const float4 v = rb[u];
+      const bool ok = rok[u];
+      *reinterpret_cast<float4*>(&bs[((t >> 4) + 16 * u) * BS_ST + (t & 15) * 4]) =
+          make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
   };
   fetch(0);
   park(0);
@@ -675,6 +702,12 @@ int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int
     return 0;
   }
 #define HSCN_ADJ_S(TA_, NT_, RS_) k_adj_s<AT, TA_, NT_, RS_><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K)
+  if (transA && sizeof(AT) == 1 && (K & 3) == 0 && lda >= 16) {     // the branch-free requests (see k_adj_s, KV)
+    if (NT == 2) k_adj_s<AT, 1, 2, false, true><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
+    else k_adj_s<AT, 1, 1, false, true><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
+    HSCN_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
   if (transA) { if (NT == 2) HSCN_ADJ_S(1, 2, false); else HSCN_ADJ_S(1, 1, false); }
   else if (rsum) { if (NT == 2) HSCN_ADJ_S(0, 2, true); else HSCN_ADJ_S(0, 1, true); }
   else { if (NT == 2) HSCN_ADJ_S(0, 2, false); else HSCN_ADJ_S(0, 1, false); }
