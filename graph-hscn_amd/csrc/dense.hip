@@ -355,6 +355,7 @@ k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restri
   for (int k0 = 0; k0 < n; k0 += BK) {
     const bool more = k0 + BK < n;
     if (more) fetch(k0 + BK);
+    if constexpr (KV) __builtin_amdgcn_sched_barrier(0);   // the requests go out here, not where the scheduler sinks them
     const float* as = As[buf];
     const float* bs = Bs[buf];
     if (RS && !TA) {      // thread (m = t & 127, half = t >> 7) adds 16 of the slab's 32 entries of row m
@@ -373,6 +374,7 @@ k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restri
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[q], 0, 0, 0);
       }
     }
+    if constexpr (KV) __builtin_amdgcn_sched_barrier(0);
     if (more) park(buf ^ 1);
     __syncthreads();
     buf ^= 1;
@@ -402,12 +404,15 @@ k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restri
 // (4 registers per slab for bytes); only the S slab (L2-resident, shared by the graph's workgroups) goes through LDS,
 // read as rows 16 h + j.  The row sums (degrees) are the sums of the operands a lane feeds, its two halves folded by
 // one cross-half shuffle.
-template <typename AT, int NT, bool RS, bool KV = true>
-__global__ void __launch_bounds__(256)
+// WV: waves per workgroup = 32-row groups per row tile (4: 128 rows; 2: 64 rows -- half the padding of a ragged graph's
+// last tile and twice as many, smaller units for the dispatcher to balance).
+template <typename AT, int NT, bool RS, bool KV = true, int WV = 4>
+__global__ void __launch_bounds__(64 * WV)
 k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
                const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
   typedef float f32x16 __attribute__((ext_vector_type(16)));
-  constexpr int BM = 128, BK = 32, BS_ST = 64;
+  constexpr int BM = 32 * WV, BK = 32, BS_ST = 64;
+  constexpr int BP = 128 / (16 * WV), BR = 4 * WV;   // S slab: passes per thread, rows per pass (16 float4 per row)
   constexpr bool U8 = sizeof(AT) == 1;
   constexpr int AR = U8 ? 4 : 16;           // registers of one slab's A entries
   __shared__ __align__(16) float Bs[2][BK * BS_ST];
@@ -471,59 +476,61 @@ k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* _
   // KV (K % 4 == 0, what the route's cluster counts are): the S slab is requested branch-free -- clamped addresses,
   // 16-byte pieces -- and rows / columns outside the graph become exact zeros by a select applied when the piece is
   // PARKED (after the slab's MFMAs), so nothing consumes the load before then.
-  float4 rb[2];
-  bool rok[2];
-  auto fetchB = [&](int k0) {
+  // Three register sets for the S slab too: the slab parked at the end of step s was requested at the top of step s - 1.
+  struct BSet { float4 v[BP]; };
+  auto fetchB = [&](int k0, BSet& rb) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int gr = k0 + (t >> 4) + 16 * u, c4 = (t & 15) * 4;
+    for (int u = 0; u < BP; ++u) {
+      const int gr = k0 + (t >> 4) + BR * u, c4 = (t & 15) * 4;
       if constexpr (KV) {
-        const int grc = gr < n ? gr : n - 1, cc = c4 + 4 <= Kc ? c4 : Kc - 4;
-        rb[u] = ld4u(Sb + (size_t)grc * K + cc);
-        rok[u] = gr < n && c4 < Kc && c4 < 32 * NT;
+        const int grl = n - 1, grc = gr < n ? gr : grl, cc = c4 + 4 <= Kc ? c4 : Kc - 4;
+        rb.v[u] = ld4u(Sb + (size_t)grc * K + cc);
       } else {
-        rok[u] = true;
-        rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < n && c4 < Kc && c4 < 32 * NT) {
           const float* p = Sb + (size_t)gr * K + c4;
-          if (c4 + 3 < Kc) rb[u] = ld4u(p);
+          if (c4 + 3 < Kc) rb.v[u] = ld4u(p);
           else {
-            rb[u].x = p[0];
-            if (c4 + 1 < Kc) rb[u].y = p[1];
-            if (c4 + 2 < Kc) rb[u].z = p[2];
+            rb.v[u].x = p[0];
+            if (c4 + 1 < Kc) rb.v[u].y = p[1];
+            if (c4 + 2 < Kc) rb.v[u].z = p[2];
           }
         }
       }
     }
   };
-  auto parkB = [&](int buf) {
+  auto parkB = [&](int buf, int k0, const BSet& rb) {      // (k0: the slab the set holds)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float4 v = rb[u];
-      const bool ok = rok[u];
+    for (int u = 0; u < BP; ++u) {
+      const float4 v = rb.v[u];
+      const int sr = (t >> 4) + BR * u;                       // row of the slab
+      const int gr = k0 + sr, c4 = (t & 15) * 4;
+      const bool ok = !KV || (gr < n && c4 < Kc && c4 < 32 * NT);
       // rows 16 .. 31 (the operands of lane half 1) sit 32 columns over, modulo the row: the two halves of a wave read
       // rows 16 apart -- 1 024 words, the same banks -- in one instruction; now they hit disjoint halves of the banks
-      *reinterpret_cast<float4*>(&Bs[buf][((t >> 4) + 16 * u) * BS_ST + (((t & 15) * 4) ^ (32 * u))]) =
+      *reinterpret_cast<float4*>(&Bs[buf][sr * BS_ST + (((t & 15) * 4) ^ (32 * (sr >> 4)))]) =
           make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
   };
   unsigned a0[AR], a1[AR], a2[AR];
+  BSet s0, s1, s2;
+  fetchB(0, s0);
   fetchA(0, a0);
+  fetchB(BK, s1);              // (past the end: clamped rows, never parked)
   fetchA(BK, a1);
-  fetchB(0);
-  parkB(0);
+  parkB(0, 0, s0);
   __syncthreads();
   int buf = 0;
   float rs = 0.f;
-  // One slab: request S of the next slab and A of the slab after next, multiply, park S, barrier.  The three operand
-  // register sets ROTATE BY NAME (the loop is unrolled three slabs deep): copying them down the pipeline would make
-  // every slab wait for the load it has just issued.  The S request goes out before the A request, so the wait in front
-  // of parkB (vmcnt counts in order) leaves the A loads in flight; the barrier waits for LDS only (`lds_barrier`, not
-  // __syncthreads, which drains the vector-memory counter too): an A load has two full slabs to arrive.
-  auto slab = [&](auto has_next, const unsigned (&cur)[AR], unsigned (&tgt)[AR], int k0) {
-    const bool more = decltype(has_next)::value || k0 + BK < n;
-    if (more) fetchB(k0 + BK);
-    fetchA(k0 + 2 * BK, tgt);                 // two slabs ahead (past the end: the last slab again, never multiplied)
+  // One slab: request S and A of the slab after next, multiply, park the NEXT slab's S (requested a slab ago), barrier.
+  // The register sets ROTATE BY NAME (the loop is unrolled three slabs deep): copying them down the pipeline would make
+  // every slab wait for the load it has just issued.  The barrier waits for LDS only (`s_waitcnt lgkmcnt(0)`, not
+  // __syncthreads, which drains the vector-memory counter too): a request has two full slabs to arrive.
+  auto slab = [&](auto steady, const unsigned (&cur)[AR], unsigned (&tgt)[AR], const BSet& spark, BSet& sfetch, int k0) {
+    const bool more = decltype(steady)::value || k0 + BK < n;
+    if (decltype(steady)::value || k0 + 2 * BK < n) fetchB(k0 + 2 * BK, sfetch);
+    fetchA(k0 + 2 * BK, tgt);                 // (past the end: the last slab again, never multiplied)
+    __builtin_amdgcn_sched_barrier(0);        // the requests go out HERE: the scheduler had sunk them behind the MFMAs
     const float* bs = Bs[buf] + lh * 16 * BS_ST;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -533,22 +540,23 @@ k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* _
       for (int q = 0; q < NT; ++q)
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[j * BS_ST + ((q * 32 + li) ^ (32 * lh))], acc[q], 0, 0, 0);
     }
-    if (more) parkB(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) parkB(buf ^ 1, k0 + BK, spark);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     buf ^= 1;
   };
-  // main loop: triples of slabs that all have a successor (no conditionals inside: the compiler's wait counters stay
-  // exact across the back edge); then the one to three slabs that are left
+  // main loop: triples of slabs whose requests all lie inside the graph (no conditionals: the compiler's wait counters
+  // stay exact across the back edge); then the same rotation with the conditions evaluated for what is left
   int k0 = 0;
-  for (; k0 + 3 * BK < n; k0 += 3 * BK) {
-    slab(std::true_type{}, a0, a2, k0);
-    slab(std::true_type{}, a1, a0, k0 + BK);
-    slab(std::true_type{}, a2, a1, k0 + 2 * BK);
+  for (; k0 + 4 * BK < n; k0 += 3 * BK) {
+    slab(std::true_type{}, a0, a2, s1, s2, k0);
+    slab(std::true_type{}, a1, a0, s2, s0, k0 + BK);
+    slab(std::true_type{}, a2, a1, s0, s1, k0 + 2 * BK);
   }
-  slab(std::false_type{}, a0, a2, k0);
-  if (k0 + BK < n) {
-    slab(std::false_type{}, a1, a0, k0 + BK);
-    if (k0 + 2 * BK < n) slab(std::false_type{}, a2, a1, k0 + 2 * BK);
+  for (; k0 < n; k0 += 3 * BK) {
+    slab(std::false_type{}, a0, a2, s1, s2, k0);
+    if (k0 + BK < n) slab(std::false_type{}, a1, a0, s2, s0, k0 + BK);
+    if (k0 + 2 * BK < n) slab(std::false_type{}, a2, a1, s0, s1, k0 + 2 * BK);
   }
   if (RS) {
     rs += __shfl_xor(rs, 32, 64);
@@ -692,7 +700,14 @@ int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int
     const bool split = NT == 2 && sizeof(AT) == 1 && split_env;
     dim3 gd(grid.x, grid.y, split ? 2 : 1);
     static const int lds_pad = getenv("HSCN_DENSE_LDS_PAD") ? atoi(getenv("HSCN_DENSE_LDS_PAD")) : 0;   // A/B: workgroups per CU
-#define HSCN_ADJ_D(NT_, RS_, KV_) k_adj_s_direct<AT, NT_, RS_, KV_><<<gd, 256, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K)
+    // 128-row tiles (four waves) by default.  HSCN_DENSE_ROWS=64 / 256: two / eight waves per workgroup (A/B; 64 rows:
+    // +18 us on the forward call -- every workgroup stages its own S slabs, and halving the rows doubles that share)
+    static const int rows_env = getenv("HSCN_DENSE_ROWS") ? atoi(getenv("HSCN_DENSE_ROWS")) : 128;
+    dim3 gd2((unsigned)((nmax + 63) / 64), gd.y, gd.z), gd8((unsigned)((nmax + 255) / 256), gd.y, gd.z);
+#define HSCN_ADJ_D(NT_, RS_, KV_) do { \
+      if (rows_env == 64) k_adj_s_direct<AT, NT_, RS_, KV_, 2><<<gd2, 128, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); \
+      else if (rows_env == 256) k_adj_s_direct<AT, NT_, RS_, KV_, 8><<<gd8, 512, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); \
+      else k_adj_s_direct<AT, NT_, RS_, KV_, 4><<<gd, 256, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); } while (0)
 #define HSCN_ADJ_DK(NT_, RS_) do { if ((K & 3) == 0) HSCN_ADJ_D(NT_, RS_, true); else HSCN_ADJ_D(NT_, RS_, false); } while (0)
     if (rsum) { if (NT == 2 && !split) HSCN_ADJ_DK(2, true); else HSCN_ADJ_DK(1, true); }
     else { if (NT == 2 && !split) HSCN_ADJ_DK(2, false); else HSCN_ADJ_DK(1, false); }

@@ -954,6 +954,7 @@ __device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
       // not depend on who runs it, a cluster is finished by its last arriver in chunk order: same bits as before.
       int* ck_next = ck_arrive + cap_v;
       (void)G_;
+#ifndef HSCN_NO_QUAD_CLUSTERS
       if constexpr (H == 16) {
         // ---- many small clusters (a balanced assignment: K = 16 .. 32 clusters of a few members each) ----
         // One wave per cluster leaves most of the wave idle and takes nv / NW rounds.  Here a 16-lane DPP row owns a
@@ -1060,6 +1061,7 @@ __device__ __forceinline__ void hscn_fwd_body(const AT& A, const int g) {
           return;
         }
       }
+#endif
       for (;;) {
         int ck = 0;
         if (lane == 0) ck = __hip_atomic_fetch_add(ck_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
