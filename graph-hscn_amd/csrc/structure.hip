@@ -150,6 +150,126 @@ __global__ void k_rank(const int64_t* __restrict__ key, const int64_t* __restric
   eid[s + rank] = me;
 }
 
+// ---- both CSRs of one edge list (hscn_csr_build_pair): side 0 keyed by dst, side 1 keyed by src ----------------
+struct CsrSide {
+  int64_t nrows;            // rows of this side's CSR
+  int32_t* rowptr;          // [nrows + 1]
+  int32_t* cursor;          // [nrows]
+  int32_t* tmp;             // [E]
+  int32_t* col;             // [E]
+  int32_t* eid;             // [E]
+  int32_t* blocksum;        // scan scratch
+};
+struct CsrPair {
+  CsrSide s[2];
+};
+
+__global__ void k_zero_pair(const CsrPair P) {
+  const int64_t n0 = P.s[0].nrows + 1, c0 = P.s[0].nrows, n1 = P.s[1].nrows + 1, c1 = P.s[1].nrows;
+  const int64_t total = n0 + c0 + n1 + c1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n0) P.s[0].rowptr[i] = 0;
+    else if (i < n0 + c0) P.s[0].cursor[i - n0] = 0;
+    else if (i < n0 + c0 + n1) P.s[1].rowptr[i - n0 - c0] = 0;
+    else P.s[1].cursor[i - n0 - c0 - n1] = 0;
+  }
+}
+
+__global__ void k_hist_pair(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, const CsrPair P,
+                            int32_t* __restrict__ flag) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t u = src[e], v = dst[e];
+  if (v < 0 || v >= P.s[0].nrows || u < 0 || u >= P.s[1].nrows) {
+    if (flag) atomicOr(flag, 1);
+    return;
+  }
+  atomicAdd(&P.s[0].rowptr[v + 1], 1);
+  atomicAdd(&P.s[1].rowptr[u + 1], 1);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partial_pair(const CsrPair P) {
+  __shared__ int lds[SCAN_THREADS / 64];
+  const CsrSide& S = P.s[blockIdx.y];
+  const int64_t n = S.nrows + 1;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  if ((int64_t)blockIdx.x * SCAN_TILE >= n) return;      // (the grid is sized for the longer side)
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    if (idx < n) s += S.rowptr[idx];
+  }
+  int total;
+  block_exclusive_scan(s, lds, total);
+  if (threadIdx.x == 0) S.blocksum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_blocksums_pair(const CsrPair P) {
+  __shared__ int lds[16];
+  const CsrSide& S = P.s[blockIdx.x];
+  const int nblocks = (int)((S.nrows + 1 + SCAN_TILE - 1) / SCAN_TILE);
+  int carry = 0;
+  for (int base = 0; base < nblocks; base += 1024) {
+    int idx = base + threadIdx.x;
+    int v = idx < nblocks ? S.blocksum[idx] : 0;
+    int total;
+    int ex = block_exclusive_scan(v, lds, total);
+    if (idx < nblocks) S.blocksum[idx] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_final_pair(const CsrPair P) {
+  __shared__ int lds[SCAN_THREADS / 64];
+  const CsrSide& S = P.s[blockIdx.y];
+  const int64_t n = S.nrows + 1;
+  if ((int64_t)blockIdx.x * SCAN_TILE >= n) return;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    v[i] = idx < n ? S.rowptr[idx] : 0;
+    s += v[i];
+  }
+  int total;
+  int ex = block_exclusive_scan(s, lds, total) + S.blocksum[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    int64_t idx = base + i;
+    ex += v[i];
+    if (idx < n) S.rowptr[idx] = ex;  // inclusive
+  }
+}
+
+__global__ void k_fill_pair(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, const CsrPair P) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t u = src[e], v = dst[e];
+  if (v < 0 || v >= P.s[0].nrows || u < 0 || u >= P.s[1].nrows) return;
+  const int p0 = atomicAdd(&P.s[0].cursor[v], 1);
+  P.s[0].tmp[P.s[0].rowptr[v] + p0] = (int32_t)e;
+  const int p1 = atomicAdd(&P.s[1].cursor[u], 1);
+  P.s[1].tmp[P.s[1].rowptr[u] + p1] = (int32_t)e;
+}
+
+__global__ void k_rank_pair(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, const CsrPair P) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t u = src[e], v = dst[e];
+  if (v < 0 || v >= P.s[0].nrows || u < 0 || u >= P.s[1].nrows) return;
+  const CsrSide& S = P.s[blockIdx.y];
+  const int64_t k = blockIdx.y == 0 ? v : u, o = blockIdx.y == 0 ? u : v;
+  const int s = S.rowptr[k], t = S.rowptr[k + 1];
+  int rank = 0;
+  const int me = (int)e;
+  for (int q = s; q < t; ++q) rank += (S.tmp[q] < me) ? 1 : 0;
+  S.col[s + rank] = (int32_t)o;
+  S.eid[s + rank] = me;
+}
+
 __global__ void k_inv_pos(const int32_t* __restrict__ eid, int64_t E, int32_t* __restrict__ inv) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < E) inv[eid[p]] = (int32_t)p;
@@ -375,6 +495,53 @@ int hscn_csr_build(const int64_t* key, const int64_t* other, int64_t E, int64_t 
     k_rank<<<hscn_blocks(E, 256), 256, 0, st>>>(key, other, E, num_rows, num_cols, rowptr, tmp, col, eid);
     HSCN_RETURN_IF_LAUNCH_FAILED();
   }
+  return 0;
+}
+
+size_t hscn_csr_pair_workspace_bytes(int64_t E, int64_t num_src, int64_t num_dst) {
+  size_t b = 0;
+  b += align_up((size_t)(num_dst > 0 ? num_dst : 1) * 4, 256) + align_up((size_t)(num_src > 0 ? num_src : 1) * 4, 256);
+  b += 2 * align_up((size_t)(E > 0 ? E : 1) * 4, 256);
+  b += align_up((size_t)((num_dst + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 4, 256);
+  b += align_up((size_t)((num_src + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 4, 256);
+  return b;
+}
+
+int hscn_csr_build_pair(const int64_t* src, const int64_t* dst, int64_t E, int64_t num_src, int64_t num_dst,
+                        int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* rowptr_t, int32_t* col_t, int32_t* eid_t,
+                        int32_t* flag, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (E < 0 || num_src < 0 || num_dst < 0 || !rowptr || !rowptr_t || !workspace ||
+      (E > 0 && (!src || !dst || !col || !eid || !col_t || !eid_t)))
+    return HSCN_E_BADARG;
+  if (E > INT32_MAX || num_src >= INT32_MAX || num_dst >= INT32_MAX) return HSCN_E_UNSUPPORTED;
+  if (workspace_bytes < hscn_csr_pair_workspace_bytes(E, num_src, num_dst)) return HSCN_E_WORKSPACE;
+  hipStream_t st = hscn_stream(stream_);
+  char* ws = (char*)workspace;
+  auto take = [&](size_t bytes) { char* p = ws; ws += align_up(bytes, 256); return (int32_t*)p; };
+  CsrPair P;
+  P.s[0] = CsrSide{num_dst, rowptr, nullptr, nullptr, col, eid, nullptr};
+  P.s[1] = CsrSide{num_src, rowptr_t, nullptr, nullptr, col_t, eid_t, nullptr};
+  P.s[0].cursor = take((size_t)(num_dst > 0 ? num_dst : 1) * 4);
+  P.s[1].cursor = take((size_t)(num_src > 0 ? num_src : 1) * 4);
+  P.s[0].tmp = take((size_t)(E > 0 ? E : 1) * 4);
+  P.s[1].tmp = take((size_t)(E > 0 ? E : 1) * 4);
+  const int nblk0 = (int)((num_dst + 1 + SCAN_TILE - 1) / SCAN_TILE), nblk1 = (int)((num_src + 1 + SCAN_TILE - 1) / SCAN_TILE);
+  P.s[0].blocksum = take((size_t)(nblk0 + 1) * 4);
+  P.s[1].blocksum = take((size_t)(nblk1 + 1) * 4);
+  const int64_t zt = 2 * (num_dst + num_src) + 2;
+  unsigned zb = hscn_blocks(zt, 256);
+  if (zb > 2048) zb = 2048;
+  k_zero_pair<<<zb, 256, 0, st>>>(P);
+  if (E > 0) k_hist_pair<<<hscn_blocks(E, 256), 256, 0, st>>>(src, dst, E, P, flag);
+  const int nblk = nblk0 > nblk1 ? nblk0 : nblk1;
+  k_scan_partial_pair<<<dim3((unsigned)nblk, 2), SCAN_THREADS, 0, st>>>(P);
+  k_scan_blocksums_pair<<<2, 1024, 0, st>>>(P);
+  k_scan_final_pair<<<dim3((unsigned)nblk, 2), SCAN_THREADS, 0, st>>>(P);
+  if (E > 0) {
+    k_fill_pair<<<hscn_blocks(E, 256), 256, 0, st>>>(src, dst, E, P);
+    k_rank_pair<<<dim3(hscn_blocks(E, 256), 2), 256, 0, st>>>(src, dst, E, P);
+  }
+  HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
 

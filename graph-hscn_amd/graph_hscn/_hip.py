@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -27,6 +27,8 @@ _SIGNATURES = {
     "hscn_strerror": (c_char_p, [c_int]),
     "hscn_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "hscn_csr_build": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, P, P, P, c_size_t, P]),
+    "hscn_csr_pair_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "hscn_csr_build_pair": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, P, P, P, P, P, P, c_size_t, P]),
     "hscn_csr_cross_positions": (c_int, [P, P, c_int64, P, P, P]),
     "hscn_gcn_dinv": (c_int, [P, c_int64, P, P]),
     "hscn_gcn_norm_weights": (c_int, [P, P, P, P, c_int64, P, P, P]),

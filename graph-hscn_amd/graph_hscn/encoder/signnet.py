@@ -57,7 +57,7 @@ class GINConv(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
         N = x.shape[-2]
-        rel = relation_of(edge_index, N, N)
+        rel = relation_of(edge_index, N, N, both=torch.is_grad_enabled() and x.requires_grad)
         if x.dim() == 3:
             K, _, C = x.shape
             rows = x.permute(1, 0, 2).reshape(N, K * C)

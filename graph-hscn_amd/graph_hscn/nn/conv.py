@@ -64,10 +64,10 @@ class Linear(nn.Module):
         return Fh.linear(x, self.weight, self.bias, act)
 
 
-def _relation(edge_index: Union[Tensor, Relation], num_src: int, num_dst: int) -> Relation:
+def _relation(edge_index: Union[Tensor, Relation], num_src: int, num_dst: int, both: bool = False) -> Relation:
     if isinstance(edge_index, Relation):
         return edge_index
-    return relation_of(edge_index, num_src, num_dst)
+    return relation_of(edge_index, num_src, num_dst, both=both)
 
 
 class GraphConv(nn.Module):
@@ -83,7 +83,8 @@ class GraphConv(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Union[Tensor, Relation], edge_weight: Optional[Tensor] = None,
                 act: str = "identity") -> Tensor:
-        rel = _relation(edge_index, x.size(0), x.size(0))
+        # (sum_j w_ji x_j) W_rel + x W_root: only a gradient w.r.t. x walks the source-keyed CSR
+        rel = _relation(edge_index, x.size(0), x.size(0), both=torch.is_grad_enabled() and x.requires_grad)
         return Fh.GraphConvFn.apply(x, edge_weight, self.lin_rel.weight, self.lin_rel.bias,
                                     self.lin_root.weight, rel, ACT[act])
 
@@ -106,10 +107,13 @@ class GCNConv(nn.Module):
         self.lin.materialize(x.size(-1), x)
         if isinstance(edge_index, Relation):
             rel = edge_index                      # the caller built the structure (loops included if wanted)
-        elif self.add_self_loops:
-            rel = self_loop_relation_of(edge_index, x.size(0))
         else:
-            rel = relation_of(edge_index, x.size(0), x.size(0))
+            # A_hat (X W): with gradients on, the backward walks the source-keyed CSR for the weight gradient already
+            both = torch.is_grad_enabled()
+            if self.add_self_loops:
+                rel = self_loop_relation_of(edge_index, x.size(0), both=both)
+            else:
+                rel = relation_of(edge_index, x.size(0), x.size(0), both=both)
         return Fh.GCNConvFn.apply(x, self.lin.weight, self.bias, rel, ACT[act])
 
 
@@ -139,7 +143,7 @@ class GATConv(nn.Module):
         x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
         self.lin_src.materialize(x_src.size(-1), x_src)
         self.lin_dst.materialize(x_dst.size(-1), x_dst)
-        rel = _relation(edge_index, x_src.size(0), x_dst.size(0))
+        rel = _relation(edge_index, x_src.size(0), x_dst.size(0), both=torch.is_grad_enabled())
         return Fh.GATConvFn.apply(x_src, x_dst, self.lin_src.weight, self.lin_dst.weight, self.att_src,
                                   self.att_dst, self.bias, rel, self.negative_slope, ACT[act])
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 16
+#define HSCN_ABI_VERSION 17
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -67,6 +67,17 @@ int hscn_csr_build(const int64_t* key, const int64_t* other, int64_t num_edges,
                    int64_t num_rows, int64_t num_cols,
                    int32_t* rowptr /*[num_rows+1]*/, int32_t* col /*[E]*/, int32_t* eid /*[E]*/,
                    int32_t* flag /*[1] or NULL*/, void* workspace, size_t workspace_bytes, void* stream);
+/* ABI 17: BOTH stable CSRs of one edge list in one go -- keyed by target (what the forward gathers through: rowptr / col /
+ * eid, num_dst rows) and keyed by source (what the backward of the same MessagePassing.propagate call gathers through:
+ * rowptr_t / col_t / eid_t, num_src rows) -- with 7 launches instead of the 16 of two hscn_csr_build calls (one zeroing
+ * launch, one histogram and one fill pass that serve both keys, the scans and the in-row ranking of the two sides as the
+ * two halves of one grid).  Results are bit-identical to hscn_csr_build(dst, src, ...) and hscn_csr_build(src, dst, ...).
+ * An edge with an endpoint out of range is skipped on both sides and raises flag[0]. */
+size_t hscn_csr_pair_workspace_bytes(int64_t num_edges, int64_t num_src, int64_t num_dst);
+int hscn_csr_build_pair(const int64_t* src, const int64_t* dst, int64_t num_edges, int64_t num_src, int64_t num_dst,
+                        int32_t* rowptr /*[num_dst+1]*/, int32_t* col /*[E]*/, int32_t* eid /*[E]*/,
+                        int32_t* rowptr_t /*[num_src+1]*/, int32_t* col_t /*[E]*/, int32_t* eid_t /*[E]*/,
+                        int32_t* flag /*[1] or NULL*/, void* workspace, size_t workspace_bytes, void* stream);
 
 /* inv_pos[eid[p]] = p  and  pos_t[q] = inv_pos[eid_t[q]]: CSR slot of the edge
  * at slot q of the transposed CSR (used by backward passes that stored

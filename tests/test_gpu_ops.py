@@ -10,15 +10,16 @@ from tests.helpers import ATOL, DEV, close, rand_graph
 pytestmark = pytest.mark.gpu
 
 
-def _rel(ei, ns, nd):
+def _rel(ei, ns, nd, both=None):
     from graph_hscn.structure import Relation
-    return Relation(ei.to(DEV), ns, nd)
+    return Relation(ei.to(DEV), ns, nd, both=both)
 
 
+@pytest.mark.parametrize("both", [True, False])      # True: hscn_csr_build_pair; False: two hscn_csr_build calls
 @pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (7, 0, 1), (50, 200, 2), (3000, 20000, 3), (70000, 300000, 4)])
-def test_csr_build_is_stable_and_exact(n, e, seed):
+def test_csr_build_is_stable_and_exact(n, e, seed, both):
     ei = rand_graph(n, e, seed, self_loops=True) if e else torch.zeros(2, 0, dtype=torch.long)
-    rel = _rel(ei, n, n)
+    rel = _rel(ei, n, n, both)
     rel.check()
     for csr, key, other in ((rel.csr, ei[1], ei[0]), (rel.csr_t, ei[0], ei[1])):
         order = torch.argsort(key, stable=True)
@@ -34,12 +35,25 @@ def test_csr_build_is_stable_and_exact(n, e, seed):
         assert torch.equal(rel.pos_t.cpu().long(), inv[rel.csr_t.eid.cpu().long()])
 
 
-def test_csr_build_flags_out_of_range():
+@pytest.mark.parametrize("both", [True, False])
+def test_csr_build_flags_out_of_range(both):
     ei = torch.tensor([[0, 1, 9], [1, 0, 2]])
-    rel = _rel(ei, 3, 3)
+    rel = _rel(ei, 3, 3, both)
     with pytest.raises(IndexError):
         rel.check()
     assert rel.csr.rowptr.cpu().tolist() == [0, 1, 2, 2]
+    assert rel.csr_t.rowptr.cpu().tolist() == [0, 1, 2, 2]
+
+
+def test_csr_pair_build_of_a_bipartite_relation_equals_the_two_single_builds():
+    """num_src != num_dst, both sides beyond the single-block scan (the two halves of the pair's scan grid differ in
+    length): every array of hscn_csr_build_pair equals hscn_csr_build(dst, src) / hscn_csr_build(src, dst)."""
+    g = torch.Generator().manual_seed(5)
+    ns, nd, E = 40000, 9000, 150000
+    ei = torch.stack([torch.randint(0, ns, (E,), generator=g), torch.randint(0, nd, (E,), generator=g)])
+    a, b = _rel(ei, ns, nd, True), _rel(ei, ns, nd, False)
+    for x, y in ((a.csr, b.csr), (a.csr_t, b.csr_t)):
+        assert torch.equal(x.rowptr, y.rowptr) and torch.equal(x.col, y.col) and torch.equal(x.eid, y.eid)
 
 
 @pytest.mark.parametrize("rows,i,o,act", [(1, 9, 16, "identity"), (333, 16, 16, "relu"), (1000, 9, 10, "elu"),
