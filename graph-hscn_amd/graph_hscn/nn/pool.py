@@ -9,7 +9,7 @@ from torch import Tensor
 
 from .. import _hip
 from .._hip import call, ptr, stream
-from ..structure import CSR, Relation, build_csr, relation_of, segments_from_batch
+from ..structure import CSR, Relation, adopt_relation, build_csr, relation_of, segments_from_batch
 from . import functional as Fh
 
 
@@ -87,6 +87,7 @@ def gcn_norm_static(edge_index: Tensor, edge_weight: Optional[Tensor] = None, nu
     dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
     w = torch.empty(max(E + N, 1), dtype=torch.float32, device=dev)
     call("hscn_gcn_norm_weights", ptr(csr.rowptr), ptr(csr.col), ptr(csr.eid), ptr(w_in), N, ptr(dinv), ptr(w), stream())
+    adopt_relation(ei, N, N, csr)      # the GraphConv that receives `ei` walks this very CSR: no second build
     return ei, w[: E + N]
 
 

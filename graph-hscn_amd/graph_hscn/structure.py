@@ -84,7 +84,8 @@ class Relation:
     """One edge type ``src -> dst``: forward CSR (keyed by target), and lazily
     the transposed CSR (keyed by source), cross positions and GCN degree norm."""
 
-    def __init__(self, edge_index: Tensor, num_src: int, num_dst: int, both: Optional[bool] = None):
+    def __init__(self, edge_index: Tensor, num_src: int, num_dst: int, both: Optional[bool] = None,
+                 csr: Optional[CSR] = None):
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be [2, E]")
         self.edge_index = edge_index
@@ -94,7 +95,9 @@ class Relation:
         self._csr_t: Optional[CSR] = None
         # both = True: the caller knows a backward through the propagate is coming (it needs the source-keyed CSR): the
         # two CSRs then come out of ONE build (hscn_csr_build_pair); otherwise the source-keyed one is built on first use
-        if both:
+        if csr is not None:        # the caller has the target-keyed CSR of this very list already (adopt_relation)
+            self.csr = csr
+        elif both:
             self.csr, self._csr_t = build_csr_pair(edge_index[0], edge_index[1], self.num_src, self.num_dst)
         else:
             self.csr = build_csr(edge_index[1], edge_index[0], self.num_dst, self.num_src)
@@ -150,6 +153,18 @@ def relation_of(edge_index: Tensor, num_src: int, num_dst: int, cache: bool = Tr
         _CACHE.move_to_end(key)
         return rel
     rel = Relation(edge_index, num_src, num_dst, both)
+    _CACHE[key] = rel
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)
+    return rel
+
+
+def adopt_relation(edge_index: Tensor, num_src: int, num_dst: int, csr: CSR) -> Relation:
+    """Enter a target-keyed CSR that was built for ``edge_index`` anyway (gcn_norm builds one for the degrees) into the
+    relation cache, so that the conv layer that receives this tensor next does not build it a second time."""
+    rel = Relation(edge_index, num_src, num_dst, csr=csr)
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
+           int(num_src), int(num_dst))
     _CACHE[key] = rel
     while len(_CACHE) > _CACHE_MAX:
         _CACHE.popitem(last=False)
