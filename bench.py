@@ -512,20 +512,46 @@ def stage_a_line(args):
         rag = any(ev[0].startswith("hscn_mincut_dense_ragged") for ev in timer.events)
         t_f = avg("hscn_mincut_dense_ragged_fwd" if rag else "hscn_mincut_dense_fwd")
         t_b = avg("hscn_mincut_dense_ragged_bwd" if rag else "hscn_mincut_dense_bwd")
+        # the dominant kernel by itself: the A S launch (hscn_dense_adj_s = what the forward call issues for it), on the
+        # forward call's own operands, 20 launches between one HIP-event pair on the stream they are launched on
+        t_as = None
+        if rag:
+            fa = [ev[1] for ev in timer.events if ev[0] == "hscn_mincut_dense_ragged_fwd"][-1]
+            # (x, adj, adj_elem_bytes, logits, nptr, N, B, nmax, K, F, S, AS, deg, ...)
+            as_args = (fa[1], fa[2], fa[10], fa[4], fa[6], fa[7], fa[8], 0, fa[11], fa[12], fa[-1])
+            for _ in range(3):
+                orig("hscn_dense_adj_s", *as_args)
+            torch.cuda._sleep(400000)
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(20):
+                orig("hscn_dense_adj_s", *as_args)
+            e_.record()
+            torch.cuda.synchronize()
+            t_as = s_.elapsed_time(e_) * 1e-3 / 20
         # S^T A S = 2 K n^2 + 2 n K^2 flops per graph, summed over the batch's actual sizes
         fl_sas = float(np.sum(2.0 * K * sizes * sizes + 2.0 * sizes * K * K))
         fl_f = float(np.sum(2.0 * sizes * sizes * K + 2.0 * K * sizes * K + 2.0 * K * sizes * K + 2.0 * K * sizes * 16))   # + S^T S + S^T X
         PEAK = 157.3
-        roofline = {"bound": "mfma", "kernel": "hscn_mincut_dense_fwd (softmax, k_bgemm A S, merged S^T(AS) | S^T S | S^T X, "
-                    "statistics: v_mfma_f32_16x16x4_f32)", "achieved": fl_sas / t_f / 1e12, "peak": PEAK, "unit": "TFLOP/s",
-                    "frac": fl_sas / t_f / 1e12 / PEAK, "traffic": None,
+        fl_as = float(np.sum(2.0 * K * sizes * sizes))          # the A S launch: 2 K n^2 per graph
+        if t_as is not None:
+            kern, ach, t_dom = ("k_adj_s_direct (hscn_dense_adj_s: A S of a ragged batch on v_mfma_f32_32x32x2_f32, the "
+                                "adjacency read as byte counts straight into the operand registers)"), fl_as / t_as / 1e12, t_as
+        else:
+            kern, ach, t_dom = ("hscn_mincut_dense_fwd (softmax, A S, merged S^T(AS) | S^T S | S^T X, statistics)",
+                                fl_sas / t_f / 1e12, t_f)
+        roofline = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": PEAK, "unit": "TFLOP/s",
+                    "frac": ach / PEAK, "traffic": None, "avg_launch_us": t_dom * 1e6,
+                    "flops_per_launch": fl_as if t_as is not None else fl_sas,
                     "flops_per_launch_SAS": fl_sas, "flops_per_launch_all_contractions": fl_f,
-                    "frac_all_contractions": fl_f / t_f / 1e12 / PEAK, "avg_launch_us": t_f * 1e6,
+                    "fwd_call_us": t_f * 1e6, "frac_SAS_over_fwd_call": fl_sas / t_f / 1e12 / PEAK,
+                    "frac_all_contractions": fl_f / t_f / 1e12 / PEAK,
                     "bwd_launch_us": t_b * 1e6, "adjacency_bytes": float(np.sum(sizes * sizes) * 4),
                     "adjacency_GBs_fwd": float(np.sum(sizes * sizes) * 4) / t_f / 1e9,
                     "nodes_per_graph_min_max": [int(sizes.min()), int(sizes.max())],
-                    "note": "the C call spans several launches (softmax, A S, the merged cluster-space contractions, "
-                            "statistics); MFMA-busy of the A S launch alone: profiles/*pmc_mfma_dense*.json"}
+                    "note": "frac = the A S launch alone (2 K n^2 flops per graph over its own duration); the forward C call "
+                            "spans several launches (softmax, A S, the merged cluster-space contractions, statistics): "
+                            "fwd_call_us / frac_SAS_over_fwd_call; MFMA-busy from the PMC pass: profiles/r03_dense_mfma_busy.txt"}
     out = {"metric": f"graphs/sec (fwd+bwd) on {args.workload} stage A (MinCUT coarsening)", "value": B * args.steps / dt,
            "unit": "graphs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -1128,4 +1128,19 @@ int hscn_mincut_dense_ragged_bwd(const void* adj, int adj_elem_bytes, const floa
                                AtS, sg_ws, gss_ws, g_logits, hscn_stream(stream_), adj_elem_bytes == 1);
 }
 
+// The adjacency product of dense_mincut_pool alone: out = op(A) S for every graph of a ragged batch (op = transpose for the
+// backward's A^T S), deg (optional, transA = 0) = the row sums of A.  What hscn_mincut_dense_ragged_fwd / _bwd launch
+// for it, as an entry point of its own so that the route's dominant kernel can be timed and profiled by itself.
+int hscn_dense_adj_s(const void* adj, int adj_elem_bytes, const float* S, const int32_t* nptr, int64_t B, int nmax, int K,
+                     int transA, float* out, float* deg, void* stream_) {
+  if (B < 1 || nmax < 1 || K < 1 || K > 64 || !adj || !S || !nptr || !out) return HSCN_E_BADARG;
+  if (adj_elem_bytes != 4 && adj_elem_bytes != 1) return HSCN_E_BADARG;
+  hipStream_t st = hscn_stream(stream_);
+  if (adj_elem_bytes == 1)
+    return launch_adj_s<uint8_t>(static_cast<const uint8_t*>(adj), S, out, transA ? nullptr : deg, nptr, B, nmax, nmax,
+                                 (nmax + 31) & ~31, K, transA, st);
+  return launch_adj_s<float>(static_cast<const float*>(adj), S, out, transA ? nullptr : deg, nptr, B, nmax, nmax, nmax, K,
+                             transA, st);
+}
+
 }  // extern "C"

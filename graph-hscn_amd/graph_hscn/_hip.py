@@ -93,6 +93,7 @@ _SIGNATURES = {
     "hscn_collate_gather_structure": (c_int, [P, P, P, c_int64, P, P, P, P, P, P]),
     "hscn_mincut_dense_ragged_fwd": (c_int, [P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
     "hscn_mincut_dense_ragged_bwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int, c_int, P, P, P, P, P]),
+    "hscn_dense_adj_s": (c_int, [P, c_int, P, P, c_int64, c_int, c_int, c_int, P, P, P]),
     "hscn_to_dense_adj_ragged_u8": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
     "hscn_to_dense_adj_ragged": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int, P, P]),
     "hscn_gcn_norm_self_loops": (c_int, [P, P, P, c_int64, c_int64, c_float, P, P, P, P]),

@@ -241,6 +241,14 @@ int hscn_mincut_dense_ragged_bwd(const void* adj, int adj_elem_bytes, const floa
                                  const float* stats, const float* ss, const float* g_losses /*[2]*/,
                                  const int32_t* nptr, const int32_t* gid /*[N]*/, int64_t N, int64_t B, int nmax, int K,
                                  float* AtS, float* sg_ws, float* gss_ws /*[B,K,K]*/, float* g_logits, void* stream);
+/* ABI 17: the adjacency product of the dense route by itself -- out [N,K] = op(A) S per graph of a ragged batch (the
+ * A S of dense_mincut_pool, reference model/hscn.py:63 -> PyG dense_mincut_pool's `torch.matmul(adj, s)`; transA = 1: the
+ * A^T S its backward needs), deg [N] (optional, transA = 0) = row sums of A.  The launch hscn_mincut_dense_ragged_fwd /
+ * _bwd issue for it; exposed so the route's dominant kernel can be timed alone (bench.py's stage_a_dense roofline). */
+int hscn_dense_adj_s(const void* adj, int adj_elem_bytes, const float* S /*[N,K]*/, const int32_t* nptr /*[B+1]*/,
+                     int64_t B, int nmax, int K, int transA, float* out /*[N,K]*/, float* deg /*[N] or NULL*/,
+                     void* stream);
+
 
 /* ------------------------------------------------------------------------- *
  * a6  dense_mincut_pool, dense route on the matrix cores (reference model/hscn.py:61-63

@@ -15,7 +15,7 @@ import json, glob, sys, os
 for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
     try:
         d = json.load(open(f)); r = d["roofline"]
-        print(f"{os.path.basename(f):28s} step {1e3*d['ms_per_step']:8.1f} us  fwd call {r['avg_launch_us']:7.1f} us  bwd {r['bwd_launch_us']:7.1f} us  frac {r['frac']:.3f}")
+        print(f"{os.path.basename(f):28s} step {1e3*d['ms_per_step']:8.1f} us  A S {r['avg_launch_us']:6.1f} us  fwd call {r.get('fwd_call_us', 0.0):7.1f} us  bwd {r['bwd_launch_us']:7.1f} us  frac {r['frac']:.3f}")
     except Exception as e:
         print(f, "unreadable", e)
 PY

@@ -42,7 +42,7 @@ for n in ("stage_a_dense", "stage_a_sparse", "stage_a_peptides"):
     try:
         d = json.load(open(f"{sys.argv[1]}/{n}.json"))
         r = d.get("roofline") or {}
-        print(f'{n:28s} {round(d["value"]):>9d} graphs/s {d["ms_per_step"]*1e3:8.1f} us | {d["config"]["step_issue"][:60]} | roofline frac {r.get("frac")} fwd {r.get("avg_launch_us")} us bwd {r.get("bwd_launch_us")} us')
+        print(f'{n:28s} {round(d["value"]):>9d} graphs/s {d["ms_per_step"]*1e3:8.1f} us | {d["config"]["step_issue"][:60]} | roofline frac {r.get("frac")} dominant {r.get("avg_launch_us")} us fwd call {r.get("fwd_call_us")} us bwd {r.get("bwd_launch_us")} us')
     except Exception as e:
         print(n, "FAILED", e)
 PY

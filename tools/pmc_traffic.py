@@ -48,7 +48,7 @@ def main():
         print(f"{k:44s} fetch {fm:10.1f} KiB  write {wm:10.1f} KiB  traffic {res[k]['traffic_bytes'] / 1e6:8.2f} MB  n={res[k]['launches']}")
     # the streaming SpMM at its scaled shape (bench.py's streaming_spmm_scaled leg: 4 096 graphs, H = 128): the
     # k_spmm<4,0,2> launches of the run
-    for k in res:
+    for k in list(res):
         if k.startswith("k_spmm<4,0,2>"):
             res["k_spmm_scaled_H128"] = res[k]
     doc = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (each with --kernel-trace only), "

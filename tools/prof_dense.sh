@@ -15,7 +15,7 @@ python3 - <<PY
 import json
 for n in ("dense_u8", "dense_u8_lds", "dense_f32", "dense_f32_16x16"):
     d = json.load(open("$OUT/" + n + ".json")); r = d["roofline"]
-    print(f"{n:18s} step {1e3*d['ms_per_step']:8.1f} us  fwd C call {r['avg_launch_us']:7.1f} us  bwd {r['bwd_launch_us']:7.1f} us  frac {r['frac']:.3f}  ({d['config']['step_issue'][:40]})")
+    print(f"{n:18s} step {1e3*d['ms_per_step']:8.1f} us  A S {r['avg_launch_us']:6.1f} us  fwd C call {r.get('fwd_call_us', 0.0):7.1f} us  bwd {r['bwd_launch_us']:7.1f} us  frac {r['frac']:.3f}  ({d['config']['step_issue'][:40]})")
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $A > $OUT/traced.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;

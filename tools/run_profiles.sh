@@ -19,7 +19,7 @@ find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/step_kernel_stats.csv
 echo stats done
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_f -- python3 bench.py --mode eager --steps 30 --warmup 5 $COMMON > $OUT/bench_pmc_f.json 2> $OUT/pmc_f.err || { tail -5 $OUT/pmc_f.err; exit 1; }
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_w -- python3 bench.py --mode eager --steps 30 --warmup 5 $COMMON > $OUT/bench_pmc_w.json 2> $OUT/pmc_w.err || { tail -5 $OUT/pmc_w.err; exit 1; }
-python3 tools/pmc_traffic.py $(find $OUT/pmc_f -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_w -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json ${HSCN_COMMIT:-unrecorded} > $OUT/pmc_traffic.txt
+python3 tools/pmc_traffic.py $(find $OUT/pmc_f -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_w -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json ${HSCN_COMMIT:-unrecorded} > $OUT/pmc_traffic.txt || { echo "pmc_traffic.py failed"; exit 1; }
 echo traffic done
 rm -rf $OUT/trace $OUT/pmc_f $OUT/pmc_w
 bash tools/run_sq_counters.sh $TAG/sq > /dev/null 2>&1 && cp $OUT/sq/sq_summary.txt $OUT/sq_counters.txt
