@@ -1037,10 +1037,14 @@ __device__ __forceinline__ void scn_bwd_tail(const ScnArgs& A, int n0, int n, fl
 // k_scn_epoch's optimizer state: the thread that folds parameter element p (P <= SRT) keeps its moments in registers
 // across the visits, the counters travel as values; the updated weights go to global memory AND to their transposed
 // slots in LDS, where the next visit reads them.
+// Only the two moments are per-thread; everything uniform lives in a few LDS words (the counters double-buffered by
+// visit parity: every thread reads this visit's pair, thread 0 writes the next visit's) -- as registers these eleven
+// values were live across every phase of the visit loop and cost 9 - 17 vector spills (scratch reloads inside the loop).
 struct ScnEpochState {
-  float m, v, step;
-  double b1t, b2t;
-  float gmc, go;   // the upstream gradients, read once for the whole chain
+  float m, v;
+  const double* pows;    // LDS: {beta1^t, beta2^t} as this visit reads them
+  double* pows_next;     // LDS: where thread 0 leaves the next visit's pair
+  float* f;              // LDS: [0..3] num, den, nrm, o of the last visit  [4] g_mc  [5] g_o  [6] step counter
 };
 template <int H, typename TS, int NTC>
 __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const float* Sl, const float* yl, float* DL,
@@ -1052,8 +1056,8 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
   const int K = A.K, NT = (K + 15) >> 4;
   const int wave = wave_id(), lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
   const int ntile = (n + 15) >> 4;
-  const float gmc = ES ? ES->gmc : (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B;
-  const float go = ES ? ES->go : (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
+  const float gmc = ES ? ES->f[4] : (A.g_mc ? A.g_mc[0] : 0.f) / (float)A.B;
+  const float go = ES ? ES->f[5] : (A.g_o ? A.g_o[0] : 0.f) / (float)A.B;
   const float c_num = -gmc / den, c_den = gmc * num / (den * den);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 gWm[NTC][TD], gWr[TD], gWo[TD];
@@ -1197,7 +1201,7 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
                 : p < oWmlp ? const_cast<float*>(A.W_root) + (p - oWroot)
                 : p < obmlp ? const_cast<float*>(A.W_mlp) + (p - oWmlp) : const_cast<float*>(A.b_mlp) + (p - obmlp);
       const double lr = KA->adam_lr[0];
-      const double b1t = (ES ? ES->b1t : KA->adam_pows[0]) * KA->adam_b1, b2t = (ES ? ES->b2t : KA->adam_pows[1]) * KA->adam_b2;
+      const double b1t = (ES ? ES->pows[0] : KA->adam_pows[0]) * KA->adam_b1, b2t = (ES ? ES->pows[1] : KA->adam_pows[1]) * KA->adam_b2;
       const float step_size = (float)(lr / (1.0 - b1t)), bc2_sqrt = (float)sqrt(1.0 - b2t);
       const float w1 = (float)(1.0 - KA->adam_b1), w2 = (float)(1.0 - KA->adam_b2), b2f = (float)KA->adam_b2;
       float pv, m, vv;
@@ -1225,10 +1229,12 @@ __device__ __forceinline__ void scn_bwd_tiles(const ScnArgs& A, int n, const flo
       else { KA->adam_m[p] = m; KA->adam_v[p] = vv; }
     }
   }
-  if (ES) {   // (every thread carries the counters)
-    ES->b1t = ES->b1t * KA->adam_b1;
-    ES->b2t = ES->b2t * KA->adam_b2;
-    ES->step += 1.0f;
+  if (ES) {   // the next visit's counters (the other parity: this visit's pair may still be being read)
+    if (threadIdx.x == 0) {
+      ES->pows_next[0] = ES->pows[0] * KA->adam_b1;
+      ES->pows_next[1] = ES->pows[1] * KA->adam_b2;
+      ES->f[6] += 1.0f;
+    }
   } else if (KA->adam_m) {
     lds_barrier();   // every thread has read the counters
     if (threadIdx.x == 0) {
@@ -1452,20 +1458,29 @@ __global__ void __launch_bounds__(SRT) k_scn_epoch(const ScnArgs A0) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NW = SRT / 64;
   ScnArgsK KA = late_args();
+  __shared__ double es_pows[4];     // two parities of {beta1^t, beta2^t}
+  __shared__ float es_f[8];
   ScnEpochState ES;
   {
     const int p = threadIdx.x;
     ES.m = p < A0.P ? KA->adam_m[p] : 0.f;
     ES.v = p < A0.P ? KA->adam_v[p] : 0.f;
-    ES.step = KA->adam_step[0];
-    ES.b1t = KA->adam_pows[0];
-    ES.b2t = KA->adam_pows[1];
-    ES.gmc = A0.g_mc ? A0.g_mc[0] : 0.f;   // (B = 1: no division)
-    ES.go = A0.g_o ? A0.g_o[0] : 0.f;
+    ES.f = es_f;
+    if (p == 0) {
+      es_pows[0] = KA->adam_pows[0]; es_pows[1] = KA->adam_pows[1];
+      es_f[0] = 0.f; es_f[1] = 1.f; es_f[2] = 0.f; es_f[3] = 0.f;
+      es_f[4] = A0.g_mc ? A0.g_mc[0] : 0.f;   // (B = 1: no division)
+      es_f[5] = A0.g_o ? A0.g_o[0] : 0.f;
+      es_f[6] = KA->adam_step[0];
+    }
   }
-  float num = 0.f, den = 1.f, nrm = 0.f, o = 0.f;
+  lds_barrier();
+  int par = 0;      // parity of the counters the next executed visit reads
   bool have_w = false;
   for (long long v = A0.visit0; v < A0.visit0 + A0.visits; ++v) {
+    float num, den, nrm, o;
+    ES.pows = es_pows + 2 * par;
+    ES.pows_next = es_pows + 2 * (par ^ 1);
     ScnArgs A = A0;
     {   // per-visit opaque copies of what the phases' index arithmetic is derived from
       int K_ = A.K, F_ = A.F, mn = A.max_n, me = A.max_e, P_ = A.P;
@@ -1511,6 +1526,8 @@ __global__ void __launch_bounds__(SRT) k_scn_epoch(const ScnArgs A0) {
     ScnStats R;
     scn_stats<NW, true>(A, Sl, rowptr_s, col_s, rowptr_d, col_d, dout, red, Sl + (size_t)A.max_n * K, ssl, R, DL, n, g);
     num = R.num; den = R.den; nrm = R.nrm; o = R.o;
+    if (threadIdx.x == 0) { es_f[0] = num; es_f[1] = den; es_f[2] = nrm; es_f[3] = o; }
+    par ^= 1;
     {
       const float inner = R.inner;
       const float isk = 1.0f / sqrtf((float)K);
@@ -1531,7 +1548,8 @@ __global__ void __launch_bounds__(SRT) k_scn_epoch(const ScnArgs A0) {
     const int p = threadIdx.x;
     if (p < A0.P) { KA->adam_m[p] = ES.m; KA->adam_v[p] = ES.v; }
     if (p == 0) {
-      KA->adam_step[0] = ES.step; KA->adam_pows[0] = ES.b1t; KA->adam_pows[1] = ES.b2t;
+      const float num = es_f[0], den = es_f[1], nrm = es_f[2], o = es_f[3];
+      KA->adam_step[0] = es_f[6]; KA->adam_pows[0] = es_pows[2 * par]; KA->adam_pows[1] = es_pows[2 * par + 1];
       if (A0.stats) { A0.stats[0] = num; A0.stats[1] = den; A0.stats[2] = nrm; A0.stats[3] = o; }
       if (A0.losses) { const float a = -(num / den); A0.losses[0] = a; A0.losses[1] = o; A0.losses[2] = a + o; }
     }
