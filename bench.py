@@ -419,10 +419,17 @@ def stage_a_line(args):
     big.x = big.x.float()
     N, E = int(big.num_nodes), int(big.edge_index.size(1))
     roofline = None
+    spg_a, gm = 1, None
     if args.route == "sparse" and scn.resident_ok(big):
         st = ScnTrainStep(scn, big)
         g = capture(st.run)
         step = g.replay
+        # like stage C: --steps-per-graph consecutive steps share one hipGraph (the replay overhead is paid once per group)
+        spg_a = max(1, int(args.steps_per_graph))
+        if spg_a > 1:
+            gm = capture(lambda: [st.run() for _ in range(spg_a)], warmup=1)
+            gm.replay()
+            torch.cuda.synchronize()
         issue = ("hipGraph replay of the one-launch stage-A step + ordered fold (graph_hscn.step.ScnTrainStep)" if st.one_launch
                  else "hipGraph replay of the forward / backward launch pair + ordered fold (graph_hscn.step.ScnTrainStep)")
     else:
@@ -445,12 +452,17 @@ def stage_a_line(args):
                 issue = "hipGraph replay of the layered operators + csrc/dense.hip (autograd captured once)"
             except RuntimeError as e:      # pragma: no cover
                 issue += f" [capture refused: {str(e)[:80]}]"
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n, one, many):
+        if spg_a > 1:
+            for _ in range(n // spg_a):
+                many()
+            n %= spg_a
+        for _ in range(n):
+            one()
+    run_steps(args.warmup, step, gm.replay if spg_a > 1 else None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps, step, gm.replay if spg_a > 1 else None)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cached = None
@@ -472,12 +484,14 @@ def stage_a_line(args):
         st2 = ScnTrainStep(scn, big, structure_pool=ScnStructurePool(dev, N, E, B))
         st2.run()                                  # the visit that builds and stores the structure
         g2 = capture(st2.run)
-        for _ in range(args.warmup):
-            g2.replay()
+        g2m = None
+        if spg_a > 1:
+            g2m = capture(lambda: [st2.run() for _ in range(spg_a)], warmup=1)
+            g2m.replay()
+        run_steps(args.warmup, g2.replay, g2m.replay if g2m else None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            g2.replay()
+        run_steps(args.steps, g2.replay, g2m.replay if g2m else None)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t0
         st2.check()
@@ -557,7 +571,8 @@ def stage_a_line(args):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Graph-HSCN stage A (gcn_norm + SCN fwd + (mincut+ortho) bwd) on {args.workload}-shaped graphs",
                       "route": args.route, "graphs_per_gpu": B, "num_clusters": K, "nodes_per_gpu": N,
-                      "edges_per_gpu": E, "nodes_per_graph": fixed_n, "step_issue": issue, "parallelism": "dp1"},
+                      "edges_per_gpu": E, "nodes_per_graph": fixed_n, "step_issue": issue, "steps_per_graph": spg_a,
+                      "parallelism": "dp1"},
            "roofline": roofline, "cpu_baseline": None}
     if cached is not None:
         out["structure_cached"] = cached
@@ -939,19 +954,22 @@ def main():
         bigd.x = bigd.x.half() if args.dtype == "f16" else bigd.x.float()
         if scn.resident_ok(bigd):
             a_step = ScnTrainStep(scn, bigd)      # (mc + o).backward() as ONE launch + the ordered fold, no autograd in the capture
-            ga = capture(a_step.run)
-            for _ in range(20):
+            # the same grouping as the headline: steps_per_graph consecutive steps per hipGraph
+            spg_a = max(1, int(spg))
+            ga = capture(lambda: [a_step.run() for _ in range(spg_a)], warmup=1)
+            n_rep = max(1, args.steps // spg_a)
+            for _ in range(max(2, 20 // spg_a)):
                 ga.replay()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(n_rep):
                 ga.replay()
             torch.cuda.synchronize()
-            ta = (time.perf_counter() - t0) / args.steps
+            ta = (time.perf_counter() - t0) / (n_rep * spg_a)
             a_step.check()
             stage_a = {"what": "gcn_norm + SCN fwd + (mincut+ortho) bwd, batched, graph-resident "
                                + ("one-launch step" if a_step.one_launch else "launch pair"),
-                       "ms_per_step": ta * 1e3, "graphs_per_s": B / ta,
+                       "steps_per_graph": spg_a, "ms_per_step": ta * 1e3, "graphs_per_s": B / ta,
                        "combined_A_plus_C_graphs_per_s": B / (ta + dt / args.steps)}
 
     # ---- secondary line: BASELINE.json configs[3] -- the MinCUT coarsening step on PascalVOC-SP-shaped graphs (real
