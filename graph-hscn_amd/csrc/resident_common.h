@@ -390,6 +390,60 @@ __device__ bool build_csr_pair_ell(const int* ek, const int* eo, int ne, int nro
   return true;
 }
 
+// ---- the same two structures as 16-byte ROW RECORDS (rows of at most ELL_D = 6 edges, at most 65 535 rows) ------------
+// rec[r] = {id0 | id1 << 16, id2 | id3 << 16, id4 | id5 << 16, r | count << 16}: the row's neighbours in ascending edge
+// order as uint16 (unused slots hold r itself: a valid row to read with weight zero), the count in the top half of the
+// last word.  A consumer reads a row's whole neighbourhood with ONE 16-byte LDS load, where rowptr -> col takes two
+// dependent ones -- and the build needs no prefix sum: phase 1 as build_csr_pair_ell (slots drawn by LDS atomics), phase 2
+// a thread per row (rank the <= 6 edge numbers in registers, store the record).  rec_a: rows keyed by ek, neighbours eo;
+// rec_t: rows keyed by eo, neighbours ek.  cnt_*, ovf zero on entry.  Returns false (for every thread alike) when a row
+// holds more than ELL_D edges: the caller takes the general CSR build then.
+__device__ bool build_ell16_pair(const int* ek, const int* eo, int ne, int nrows, uint4* rec_a, uint4* rec_t, float* dinv,
+                                 int* cnt_a, int* ell_a, int* cnt_t, int* ell_t, int* ovf, int RTn) {
+  for (int e = threadIdx.x; e < ne; e += RTn) {
+    const int k = ek[e], o = eo[e];
+    if (k >= 0) {
+      const int pa = atomicAdd(&cnt_a[k], 1), pt = atomicAdd(&cnt_t[o], 1);
+      if (pa < ELL_D) ell_a[k * ELL_D + pa] = e; else ovf[0] = 1;
+      if (pt < ELL_D) ell_t[o * ELL_D + pt] = e; else ovf[0] = 1;
+    }
+  }
+  lds_barrier();
+  if (ovf[0] != 0) return false;
+  for (int idx = threadIdx.x; idx < 2 * nrows; idx += RTn) {
+    const bool tside = idx >= nrows;
+    const int r = tside ? idx - nrows : idx;
+    const int* cnt = tside ? cnt_t : cnt_a;
+    const int* ell = tside ? ell_t : ell_a;
+    const int* other = tside ? ek : eo;
+    const int c = cnt[r];
+    int ev[ELL_D], ov[ELL_D];
+#pragma unroll
+    for (int j = 0; j < ELL_D; ++j) ev[j] = j < c ? ell[r * ELL_D + j] : 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < ELL_D; ++j) ov[j] = other[j < c ? ev[j] : 0];
+    unsigned id[ELL_D];
+#pragma unroll
+    for (int j = 0; j < ELL_D; ++j) id[j] = (unsigned)r;
+#pragma unroll
+    for (int j = 0; j < ELL_D; ++j) {
+      int rank = 0;
+#pragma unroll
+      for (int m = 0; m < ELL_D; ++m) rank += ev[m] < ev[j] ? 1 : 0;
+      // (edge numbers are distinct, so the ranks of the c real entries are 0 .. c-1)
+#pragma unroll
+      for (int q = 0; q < ELL_D; ++q)
+        if (j < c && rank == q) id[q] = (unsigned)ov[j];
+    }
+    const uint4 rec = make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16),
+                                 (unsigned)r | ((unsigned)c << 16));
+    (tside ? rec_t : rec_a)[r] = rec;
+    if (!tside && dinv) dinv[r] = c > 0 ? 1.0f / sqrtf((float)c) : 0.f;
+  }
+  lds_barrier();
+  return true;
+}
+
 // ---- stable CSR, few rows of high degree (local -> virtual: rows are clusters) ----------------
 // Wave-ballot multisplit: edges are cut into 64-edge chunks (one wave each, in edge order);
 // cnt[row][chunk] by ballot, one scan over (row-major, chunk-minor) gives every

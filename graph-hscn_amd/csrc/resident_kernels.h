@@ -328,7 +328,11 @@ __device__ void lin_mfma(const float* X, const float* Wt, float* Y, int n, const
 // pool_part (optional, [H] words of this wave): the column sums of the rows this wave produced -- the wave's share of
 // global_mean_pool, taken from the accumulators (rows of a tile in row order, tiles in tile order, then the four row
 // groups of the lanes): the pooling pass over the finished layer and its barrier do not exist.
-template <int H, typename TS>
+// E16: the structure comes as one 16-byte RECORD per row instead of rowptr / col (build_ell16_pair: rows of at most six
+// edges): six neighbour ids as uint16 in edge order (unused slots hold the row itself) + the count in the top half of
+// the last word.  One LDS read delivers the row's whole neighbourhood: the gather's dependent chain is two LDS round
+// trips (record -> neighbour rows) instead of three (rowptr -> col -> rows).  Same edges in the same order: same bits.
+template <int H, typename TS, bool E16 = false>
 __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, const float* X, const float* Wt,
                           const float* bias, float* Y, TS* __restrict__ gout, int n, const Grp& G,
                           float* pool_part = nullptr) {
@@ -385,7 +389,36 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
     float z[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) z[s] = 0.f;
-    if (i < n) {
+    if (E16) {
+      if (i < n) {
+        const uint4 rec = reinterpret_cast<const uint4*>(rowptr)[i];
+        const float di = dinv[i];
+        const int c = (int)(rec.w >> 16);
+        const int jr[8] = {(int)(rec.x & 0xffffu), (int)(rec.x >> 16), (int)(rec.y & 0xffffu), (int)(rec.y >> 16),
+                           (int)(rec.z & 0xffffu), (int)(rec.z >> 16), (int)(rec.w & 0xffffu), (int)(rec.w & 0xffffu)};
+#pragma unroll
+        for (int p = 0; p < 8; p += 4) {
+          if (p < c) {
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = p + u < c ? dinv[jr[p + u]] * di : 0.f;
+#pragma unroll
+            for (int q = 0; q < KS / 4; ++q) {
+              float4 v[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xq + jr[p + u] * H + 4 * q);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                z[4 * q + 0] = fmaf(w[u], v[u].x, z[4 * q + 0]);
+                z[4 * q + 1] = fmaf(w[u], v[u].y, z[4 * q + 1]);
+                z[4 * q + 2] = fmaf(w[u], v[u].z, z[4 * q + 2]);
+                z[4 * q + 3] = fmaf(w[u], v[u].w, z[4 * q + 3]);
+              }
+            }
+          }
+        }
+      }
+    } else if (i < n) {
       const int s0 = rowptr[i], t0 = rowptr[i + 1];
       const float di = dinv[i];
       for (int p = s0; p < t0; p += 4) {

@@ -57,7 +57,8 @@ struct StepArgs {
 struct StepLayout {
   size_t A, dinv, wt, headw, part, vec, red, rowptr, col, rowptr_t, col_t, wsum, total;
   size_t ek, eo, cursorA, tmpA, cursorT, tmpT;
-  size_t cntA, cntT, ellA, ellT, ovf;   // the two-barrier build for low-degree rows (build_csr_pair_ell)
+  size_t cntA, cntT, ellA, ellT, ovf;   // the two-barrier build for low-degree rows (build_csr_pair_ell / build_ell16_pair)
+  size_t recT;                          // source-keyed row records (the target-keyed ones sit at `rowptr`)
   int NB;
   size_t bufw;  // words per n x H buffer
 };
@@ -95,10 +96,16 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   Y.part = take((size_t)2 * (RT_MAX / 64) * H);                    // pool partials, later bias-gradient partials (x2: layer parity)
   Y.vec = take(320);
   Y.red = take((size_t)(RT_MAX / 64) * 256);
-  Y.rowptr = take((size_t)max_n + 1);
-  Y.col = take(max_ell);
-  Y.rowptr_t = take((size_t)max_n + 1);
-  Y.col_t = take(max_ell);
+  // the structure region: two CSRs (rowptr | col | rowptr_t | col_t) or, for low-degree graphs at H = 16, two tables of
+  // 16-byte row records (build_ell16_pair: recA [max_n] | recT [max_n]) -- whichever is larger
+  {
+    const size_t csr_w = 2 * up4((size_t)max_n + 1) + 2 * up4(max_ell), rec_w = 2 * 4 * (size_t)max_n;
+    Y.rowptr = take(csr_w > rec_w ? csr_w : rec_w);
+    Y.col = Y.rowptr + up4((size_t)max_n + 1);
+    Y.rowptr_t = Y.col + up4(max_ell);
+    Y.col_t = Y.rowptr_t + up4((size_t)max_n + 1);
+    Y.recT = Y.rowptr + 4 * (size_t)max_n;
+  }
   Y.wsum = take(32);
   Y.total = o;
   return Y;
@@ -330,10 +337,21 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
   // ---- structure: the two CSRs of the local->local relation side by side (four barriers each) -------------
   // Molecule-like graphs (every row of at most ELL_D edges) take the two-barrier build of both CSRs; a graph with a
   // denser row takes the general one (four barriers after re-zeroing its counters).  Same arrays either way.
+  // H = 16: the structure as 16-byte row records (one LDS load per row in every gather, no prefix sums in the build);
+  // HSCN_CSR_ELL=2 keeps the two-barrier CSR build (A/B), H = 32 always takes it (its two-phase backward walks CSRs)
+  bool e16 = false;
 #if HSCN_CSR_ELL
   if (!pre) {
-    const bool low = build_csr_pair_ell(ib + Y.ek, ib + Y.eo, ne, n, rowptr, col, rowptr_t, col_t, dinv, ib + Y.cntA,
-                                        ib + Y.ellA, ib + Y.cntT, ib + Y.ellT, ib + Y.ovf, RT, wave, NW);
+    bool low;
+    if (H == 16 && HSCN_CSR_ELL == 1) {
+      low = build_ell16_pair(ib + Y.ek, ib + Y.eo, ne, n, reinterpret_cast<uint4*>(ib + Y.rowptr),
+                             reinterpret_cast<uint4*>(ib + Y.recT), dinv, ib + Y.cntA, ib + Y.ellA, ib + Y.cntT,
+                             ib + Y.ellT, ib + Y.ovf, RT);
+      e16 = low;
+    } else {
+      low = build_csr_pair_ell(ib + Y.ek, ib + Y.eo, ne, n, rowptr, col, rowptr_t, col_t, dinv, ib + Y.cntA,
+                               ib + Y.ellA, ib + Y.cntT, ib + Y.ellT, ib + Y.ovf, RT, wave, NW);
+    }
     if (!low) {
       const int NA = NW / 2 > 0 ? NW / 2 : 1;
       const bool inB = wave >= NA && NW > 1;
@@ -434,7 +452,8 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     // the last layer leaves each wave's share of global_mean_pool behind (column sums out of its accumulators)
     float* pool_w = l == L - 1 ? partp + wave * H : nullptr;
     if (wave < NC) {
-      gcn_fused<H, TS>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w);
+      if (e16) gcn_fused<H, TS, true>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w);
+      else gcn_fused<H, TS, false>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w);
     } else if (hand) {
       if (pool_w && lane < H) pool_w[lane] = 0.f;
       if (l >= 2) raise(l - 1);
@@ -754,7 +773,37 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
         if (l == 0) xrows(rt, bxA);
         const int i = rt * 16 + li;
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n) {
+        if (e16) {
+          if (i < n) {
+            const uint4 rec = reinterpret_cast<const uint4*>(ib + Y.recT)[i];
+            const float di = dinv[i];
+            const int c = (int)(rec.w >> 16);
+            const int jr[8] = {(int)(rec.x & 0xffffu), (int)(rec.x >> 16), (int)(rec.y & 0xffffu), (int)(rec.y >> 16),
+                               (int)(rec.z & 0xffffu), (int)(rec.z >> 16), (int)(rec.w & 0xffffu), (int)(rec.w & 0xffffu)};
+#pragma unroll
+            for (int p = 0; p < 8; p += 4) {
+              if (p < c) {
+                float ww[4];
+                float4 vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  ww[u] = mul_rn(dinv[jr[p + u]], di);
+                  vv[u] = *reinterpret_cast<const float4*>(gq + jr[p + u] * H);
+                  if (it == 0) vv[u] = gl4(vv[u], gq4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  if (p + u < c) {
+                    z.x = add_rn(z.x, mul_rn(ww[u], vv[u].x));
+                    z.y = add_rn(z.y, mul_rn(ww[u], vv[u].y));
+                    z.z = add_rn(z.z, mul_rn(ww[u], vv[u].z));
+                    z.w = add_rn(z.w, mul_rn(ww[u], vv[u].w));
+                  }
+                }
+              }
+            }
+          }
+        } else if (i < n) {
           const int s0 = rowptr_t[i], t0 = rowptr_t[i + 1];
           const float di = dinv[i];
           for (int p = s0; p < t0; p += 4) {
