@@ -99,7 +99,7 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   // the structure region: two CSRs (rowptr | col | rowptr_t | col_t) or, for low-degree graphs at H = 16, two tables of
   // 16-byte row records (build_ell16_pair: recA [max_n] | recT [max_n]) -- whichever is larger
   {
-    const size_t csr_w = 2 * up4((size_t)max_n + 1) + 2 * up4(max_ell), rec_w = 2 * 4 * (size_t)max_n;
+    const size_t csr_w = 2 * up4((size_t)max_n + 1) + 2 * up4(max_ell), rec_w = H == 16 ? 2 * 4 * (size_t)max_n : 0;
     Y.rowptr = take(csr_w > rec_w ? csr_w : rec_w);
     Y.col = Y.rowptr + up4((size_t)max_n + 1);
     Y.rowptr_t = Y.col + up4(max_ell);
