@@ -438,3 +438,52 @@ def test_scn_step_with_the_optimizer_in_its_tail(kind, wd, dtype):
             assert torch.equal(x, y)
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] == 12.0
         assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+
+
+def test_one_launch_step_row_records_and_csr_walk_in_one_launch():
+    """The one-launch step keeps a graph's ll structure as 16-byte row records when no node has more than six edges and
+    takes the general CSR build + walk otherwise -- per workgroup.  A batch that mixes molecule-like graphs with graphs
+    that carry a hub (in-degree 7 .. 40, and one node that is the SOURCE of many edges) runs both forms in one launch:
+    virtual features equal the launch pair's bit for bit, prediction / score / gradients to float rounding, and the
+    prediction equals the CPU oracle's to 1e-5."""
+    from oracle import models as OM
+    from tests.helpers import ATOL, grads_close, pool_order_close
+    from graph_hscn.config.config import ACT_DICT
+    from graph_hscn.data import Data, HeteroBatch
+    from graph_hscn.loader.hetero_data import hetero_from_clusters
+    from graph_hscn.loader.synthetic import make_dataset
+    from graph_hscn.model.hscn import HSCN
+    from graph_hscn.step import ResidentTrainStep
+    dev = torch.device("cuda:0")
+    K, C, H, L = 8, 10, 16, 3
+    rng = np.random.default_rng(11)
+    graphs = make_dataset("peptides_func", 10, seed=21)
+    for gi, hub_deg in ((2, 7), (5, 40), (8, 13)):          # add a hub to three of them
+        g = graphs[gi]
+        n = g.num_nodes
+        leaves = torch.from_numpy(rng.choice(np.arange(1, n), size=min(hub_deg, n - 1), replace=False))
+        hub = torch.zeros_like(leaves)
+        extra = torch.cat([torch.stack([leaves, hub]), torch.stack([hub, leaves])], 1) if gi != 8 else torch.stack([hub, leaves])
+        graphs[gi] = Data(x=g.x, edge_index=torch.cat([g.edge_index, extra], 1).contiguous(), y=g.y, num_nodes=n)
+    hs = [hetero_from_clusters(g, rng.integers(0, K, g.num_nodes), K) for g in graphs]
+    for h in hs:
+        h["local"].y = torch.from_numpy((rng.random((1, C)) < 0.4).astype(np.float32))
+    host = HeteroBatch.from_data_list(hs)
+    d = host.to(dev)
+    torch.manual_seed(3)
+    model = HSCN("GAT", "GCN", "GCN", ACT_DICT["relu"], d["local"].x.size(1), H, C, L).to(dev)
+    pair = ResidentTrainStep(model, d, "cross_entropy", one_launch=False)
+    pair.run()
+    one = ResidentTrainStep(model, d, "cross_entropy", one_launch=True)
+    assert one.one_launch
+    one.run()
+    torch.cuda.synchronize()
+    one.check()
+    assert torch.equal(one.virtual, pair.virtual)
+    assert pool_order_close(one.pred, pair.pred) and pool_order_close(one.score, pair.score)
+    assert grads_close(one.grads[:-1], pair.grads[:-1], rel=1e-5)
+    ref = OM.HSCN("GAT", "GCN", "GCN", OM.ACT["relu"], d["local"].x.size(1), H, C, L)
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        want = ref({k: v.float() for k, v in host.x_dict.items()}, host.edge_index_dict, host["local"].batch, host.num_graphs)
+    assert torch.allclose(one.pred.cpu(), want, atol=ATOL, rtol=1e-5), float((one.pred.cpu() - want).abs().max())
