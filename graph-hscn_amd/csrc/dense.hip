@@ -747,6 +747,41 @@ k_softmax_rows_d(const float* __restrict__ logits, float* __restrict__ S, int64_
   }
 }
 
+// The same for K % 4 == 0: a lane owns FOUR columns (one 16-byte load and store), a row sits in LPR = pow2 >= K / 4 <= 16
+// lanes of one DPP row, max and sum cross lanes by DPP (no ds_bpermute round trips): 17.8 -> ~9 us on 57 k x 64.
+__device__ __forceinline__ float seg16_max(float v, int LPR) {
+  if (LPR >= 2) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  if (LPR >= 4) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  if (LPR >= 8) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  if (LPR >= 16) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
+__device__ __forceinline__ float seg16_sum(float v, int LPR) {
+  if (LPR >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  if (LPR >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  if (LPR >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  if (LPR >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+__global__ void __launch_bounds__(256)
+k_softmax_rows4(const float* __restrict__ logits, float* __restrict__ S, int64_t n, int K, int LPR) {
+  const int l = threadIdx.x % LPR;
+  const int64_t rpb = 256 / LPR;
+  const bool on = 4 * l < K;
+  // (every lane of the wave stays in the loop while any row of its trip exists: the DPP exchanges need their partners)
+  for (int64_t i0 = (int64_t)blockIdx.x * rpb; i0 < n; i0 += (int64_t)gridDim.x * rpb) {
+    const int64_t i = i0 + threadIdx.x / LPR;
+    const bool ok = on && i < n;
+    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (ok) v = *reinterpret_cast<const float4*>(logits + i * K + 4 * l);
+    const float m = seg16_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), LPR);
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) e = make_float4(expf(v.x - m), expf(v.y - m), expf(v.z - m), expf(v.w - m));
+    const float sum = seg16_sum((e.x + e.y) + (e.z + e.w), LPR);
+    if (ok) *reinterpret_cast<float4*>(S + i * K + 4 * l) = make_float4(e.x / sum, e.y / sum, e.z / sum, e.w / sum);
+  }
+}
+
 // deg[b][i] = sum_k adj[b][i][k]   (wave per row, ordered fold)
 __global__ void k_rowsum(const float* __restrict__ adj, float* __restrict__ deg, int64_t rows, int n) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -769,10 +804,25 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// the same for NT threads (NT / 64 wave partials folded in wave order)
+template <int NT>
+__device__ __forceinline__ float block_sum_nt(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();   // red may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) t += red[w];
+  return t;
+}
+
 // per graph: num = tr(oa), den = sum_i deg_i |S_i|^2, |ss|_F, ortho; normalise oa in place.
-// One workgroup per graph, all 256 threads in every reduction; oa and ss are staged in LDS with rows
+// One workgroup per graph (NT = 1 024 threads: the pass over S -- 115 KB per PascalVOC-SP graph -- is one trip of
+// requests per thread instead of four), all threads in every reduction; oa and ss are staged in LDS with rows
 // padded by one word (the row sums walk a row per thread).
-__global__ void __launch_bounds__(256)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, const float* __restrict__ ss,
                  float* __restrict__ oa, float* __restrict__ stats, int n, int K, const int32_t* __restrict__ nptr) {
   extern __shared__ float lds[];
@@ -780,7 +830,7 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
   float* oal = lds;                  // [K][KS]
   float* ssl = oal + K * KS;         // [K][KS]
   float* dn = ssl + K * KS;          // [K]
-  float* red = dn + K;               // [4]
+  float* red = dn + K;               // [NT / 64]
   const int g = blockIdx.x;
   const size_t r0 = nptr ? (size_t)nptr[g] : (size_t)g * n;
   if (nptr) n = nptr[g + 1] - nptr[g];
@@ -788,7 +838,7 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
   const float* dg = deg + r0;
   const float* ssg = ss + (size_t)g * KK;
   float* oag = oa + (size_t)g * KK;
-  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+  for (int idx = threadIdx.x; idx < KK; idx += NT) {
     const int a = idx / K, b = idx - a * K;
     oal[a * KS + b] = oag[idx];
     ssl[a * KS + b] = ssg[idx];
@@ -800,12 +850,12 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
     if ((K & 3) == 0) {   // float4 pieces, eight requests in flight per trip
       const int tot4 = tot >> 2, kq = K >> 2;
       const float4* S4 = reinterpret_cast<const float4*>(Sg);
-      for (int base = threadIdx.x; base < tot4; base += 8 * 256) {
+      for (int base = threadIdx.x; base < tot4; base += 8 * NT) {
         float4 v[8];
         float d[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int i4 = base + u * 256;
+          const int i4 = base + u * NT;
           const bool ok = i4 < tot4;
           v[u] = S4[ok ? i4 : 0];
           d[u] = ok ? dg[i4 / kq] : 0.f;
@@ -815,43 +865,43 @@ k_dense_finalize(const float* __restrict__ S, const float* __restrict__ deg, con
           part = fmaf(d[u], (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w), part);
       }
     } else {
-      for (int idx = threadIdx.x; idx < tot; idx += 256) {
+      for (int idx = threadIdx.x; idx < tot; idx += NT) {
         const float v = Sg[idx];
         part = fmaf(dg[idx / K], v * v, part);
       }
     }
   }
-  const float den = block_sum_256(part, red);   // (its barriers also publish oal / ssl)
+  const float den = block_sum_nt<NT>(part, red);   // (its barriers also publish oal / ssl)
   float t = 0.f;
-  for (int a = threadIdx.x; a < K; a += 256) t += oal[a * KS + a];
-  const float num = block_sum_256(t, red);
+  for (int a = threadIdx.x; a < K; a += NT) t += oal[a * KS + a];
+  const float num = block_sum_nt<NT>(t, red);
   t = 0.f;
-  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+  for (int idx = threadIdx.x; idx < KK; idx += NT) {
     const float v = ssl[(idx / K) * KS + idx % K];
     t = fmaf(v, v, t);
   }
-  const float nrm = sqrtf(block_sum_256(t, red));
+  const float nrm = sqrtf(block_sum_nt<NT>(t, red));
   const float isk = 1.0f / sqrtf((float)K);
   t = 0.f;
-  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+  for (int idx = threadIdx.x; idx < KK; idx += NT) {
     const int a = idx / K, b = idx - a * K;
     const float q = ssl[a * KS + b] / nrm - (a == b ? isk : 0.f);
     t = fmaf(q, q, t);
   }
-  const float o2 = block_sum_256(t, red);
+  const float o2 = block_sum_nt<NT>(t, red);
   if (threadIdx.x == 0) {
     stats[g * 4 + 0] = num;
     stats[g * 4 + 1] = den;
     stats[g * 4 + 2] = nrm;
     stats[g * 4 + 3] = sqrtf(o2);
   }
-  for (int a = threadIdx.x; a < K; a += 256) {
+  for (int a = threadIdx.x; a < K; a += NT) {
     float s_ = 0.f;
     for (int b = 0; b < K; ++b) s_ += (a == b) ? 0.f : oal[a * KS + b];
     dn[a] = sqrtf(s_) + 1e-15f;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < KK; idx += 256) {
+  for (int idx = threadIdx.x; idx < KK; idx += NT) {
     const int a = idx / K, b = idx - a * K;
     oag[idx] = (a == b) ? 0.f : (oal[a * KS + b] / dn[b]) / dn[a];
   }
@@ -1009,7 +1059,13 @@ int mincut_dense_fwd_impl(const float* x, const float* adj, const float* logits,
                           int64_t B, int n, int K, int F, float* S, float* AS, float* deg, float* stats, float* ss,
                           float* pooled_x, float* pooled_adj, float* losses, hipStream_t st, int adj8 = 0) {
   const int64_t rows = nptr ? N : B * n;
-  {
+  if ((K & 3) == 0 && K <= 64) {     // four columns per lane, DPP reductions
+    int LPR = 1;
+    while (LPR * 4 < K) LPR <<= 1;
+    unsigned nb = hscn_blocks(rows, 256 / LPR);
+    if (nb > 8192) nb = 8192;
+    k_softmax_rows4<<<nb, 256, 0, st>>>(logits, S, rows, K, LPR);
+  } else {
     int KP = 1;
     while (KP < K) KP <<= 1;
     unsigned nb = hscn_blocks(rows, 256 / KP);
@@ -1037,7 +1093,7 @@ int mincut_dense_fwd_impl(const float* x, const float* adj, const float* logits,
     if (x && pooled_x && F > 0) R.r[nr++] = BRhs{x, pooled_x, F, F, F, (int64_t)n * F, (int64_t)K * F, rg, 0};
     if ((rc = bgemm_multi(S, R, nr, B, K, n, K, (int64_t)n * K, 1, st, nullptr, Rag{nptr, 1, 0, 1}))) return rc;
   }
-  k_dense_finalize<<<(unsigned)B, 256, (size_t)(2 * K * (K + 1) + K + 4) * 4, st>>>(S, deg, ss, pooled_adj, stats, n, K, nptr);
+  k_dense_finalize<1024><<<(unsigned)B, 1024, (size_t)(2 * K * (K + 1) + K + 16) * 4, st>>>(S, deg, ss, pooled_adj, stats, n, K, nptr);
   k_losses_d<<<1, 64, 0, st>>>(stats, losses, (int)B);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
