@@ -982,6 +982,25 @@ k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const flo
     const size_t base = (size_t)r * K;
     float dS[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
     float dot = 0.f;
+    if ((K & 3) == 0) {      // whole 16-byte pieces: four loads and one store per lane
+      const int k0 = fl * 4;
+      if (k0 < K) {
+        const float4 s4 = *reinterpret_cast<const float4*>(S + base + k0), a4 = *reinterpret_cast<const float4*>(AS + base + k0);
+        const float4 t4 = *reinterpret_cast<const float4*>(AtS + base + k0), g4 = *reinterpret_cast<const float4*>(SG + base + k0);
+        sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
+        dS[0] = c_num * (a4.x + t4.x) + c_den * 2.f * di * sv[0] + g4.x;
+        dS[1] = c_num * (a4.y + t4.y) + c_den * 2.f * di * sv[1] + g4.y;
+        dS[2] = c_num * (a4.z + t4.z) + c_den * 2.f * di * sv[2] + g4.z;
+        dS[3] = c_num * (a4.w + t4.w) + c_den * 2.f * di * sv[3] + g4.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dot = fmaf(dS[q], sv[q], dot);
+      }
+      for (int off = LPRp >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+      if (k0 < K)
+        *reinterpret_cast<float4*>(g_logits + base + k0) =
+            make_float4(sv[0] * (dS[0] - dot), sv[1] * (dS[1] - dot), sv[2] * (dS[2] - dot), sv[3] * (dS[3] - dot));
+      continue;
+    }
     for (int k0 = fl * 4; k0 < K; k0 += LPRp * 4) {   // one pass when K <= 4*LPRp (always: LPRp = pow2ceil(K/4))
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
