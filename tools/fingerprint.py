@@ -1,6 +1,8 @@
-"""Fingerprint of the kernel sources (graph-hscn_amd/csrc/*.hip, *.h + include/hscn.h): what ties a committed
-profile (PMC traffic, kernel stats) to the code it was collected from.  The GPU box has no .git, so a commit id
-cannot be asked for there; a content hash can."""
+"""Fingerprint of the sources of the kernels whose PMC traffic is committed (profiles/rNN_pmc_traffic.json: the
+graph-resident step kernels and the streaming SpMM) -- graph-hscn_amd/csrc/resident*.h, resident*.hip, spmm.hip,
+hscn_common.h: what ties that profile to the code it was collected from.  The GPU box has no .git, so a commit id
+cannot be asked for there; a content hash can.  (Files of other kernels -- dense.hip, linear.hip, structure.hip ... --
+are left out on purpose: a change there does not make the step's traffic figure stale.)"""
 import glob
 import hashlib
 import os
@@ -10,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def csrc_fingerprint():
     h = hashlib.sha1()
-    files = sorted(glob.glob(os.path.join(ROOT, "graph-hscn_amd", "csrc", "*.hip")) +
-                   glob.glob(os.path.join(ROOT, "graph-hscn_amd", "csrc", "*.h")) +
-                   [os.path.join(ROOT, "include", "hscn.h")])
+    d = os.path.join(ROOT, "graph-hscn_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(d, "resident*.hip")) + glob.glob(os.path.join(d, "resident*.h")) +
+                   [os.path.join(d, "spmm.hip"), os.path.join(d, "hscn_common.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
