@@ -502,7 +502,7 @@ def stage_a_line(args):
         # the dominant launch: A S (a [n,n] x [n,K] product per graph) inside hscn_mincut_dense_ragged_fwd -- time the C call
         sizes = np.array([int(g.num_nodes) for g in graphs], dtype=np.float64)
         timer = KernelTimer(["hscn_mincut_dense_fwd", "hscn_mincut_dense_bwd", "hscn_mincut_dense_ragged_fwd",
-                             "hscn_mincut_dense_ragged_bwd"])
+                             "hscn_mincut_dense_ragged_bwd", "hscn_mincut_dense_ragged_bwd_sym"])
         orig = _hip.call
         Fh.call = lambda name, *a: timer.wrap(name, lambda *b: orig(name, *b), *a)
         for _ in range(5):
@@ -525,7 +525,8 @@ def stage_a_line(args):
             return s_.elapsed_time(e_) * 1e-3 / 20
         rag = any(ev[0].startswith("hscn_mincut_dense_ragged") for ev in timer.events)
         t_f = avg("hscn_mincut_dense_ragged_fwd" if rag else "hscn_mincut_dense_fwd")
-        t_b = avg("hscn_mincut_dense_ragged_bwd" if rag else "hscn_mincut_dense_bwd")
+        t_b = avg(("hscn_mincut_dense_ragged_bwd_sym" if any(ev[0] == "hscn_mincut_dense_ragged_bwd_sym" for ev in timer.events)
+                   else "hscn_mincut_dense_ragged_bwd") if rag else "hscn_mincut_dense_bwd")
         # the dominant kernel by itself: the A S launch (hscn_dense_adj_s = what the forward call issues for it), on the
         # forward call's own operands, 20 launches between one HIP-event pair on the stream they are launched on
         t_as = None

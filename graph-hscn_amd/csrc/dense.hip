@@ -219,7 +219,11 @@ k_bgemm(const float* __restrict__ A, const BRhs3 R, int M, int Kd, int64_t lda, 
 template <typename AT, int TA, int NT, bool RS, bool KV = false>
 __global__ void __launch_bounds__(256)
 k_adj_s(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
-        const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
+        const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K,
+        const int32_t* __restrict__ asym = nullptr) {
+  // asym (A^T S of the backward only): asym[b] == 0 says A_b is symmetric -- A_b^T S = A_b S, which the forward kept:
+  // this graph's workgroups have nothing to do (the consumer reads the forward's product for it)
+  if (asym && asym[blockIdx.y] == 0) return;
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   constexpr int BM = 128, BK = 32, AS_ST = BM + 4, BS_ST = 64;
   __shared__ __align__(16) float As[2][BK * AS_ST];
@@ -678,7 +682,7 @@ k_adj_s_reg(const AT* __restrict__ adj, const float* __restrict__ S, float* __re
 
 template <typename AT>
 int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int32_t* nptr, int64_t B, int n, int nmax,
-                 int64_t lda, int K, int transA, hipStream_t st) {
+                 int64_t lda, int K, int transA, hipStream_t st, const int32_t* asym = nullptr) {
   dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)B);
   const int NT = K > 32 ? 2 : 1;
   static const bool via_lds = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 32;   // A/B: A staged through LDS
@@ -718,8 +722,8 @@ int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int
   }
 #define HSCN_ADJ_S(TA_, NT_, RS_) k_adj_s<AT, TA_, NT_, RS_><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K)
   if (transA && sizeof(AT) == 1 && (K & 3) == 0 && lda >= 16) {     // the branch-free requests (see k_adj_s, KV)
-    if (NT == 2) k_adj_s<AT, 1, 2, false, true><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
-    else k_adj_s<AT, 1, 1, false, true><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
+    if (NT == 2) k_adj_s<AT, 1, 2, false, true><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K, asym);
+    else k_adj_s<AT, 1, 1, false, true><<<grid, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K, asym);
     HSCN_RETURN_IF_LAUNCH_FAILED();
     return 0;
   }
@@ -969,7 +973,7 @@ __global__ void __launch_bounds__(256)
 k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const float* __restrict__ AtS,
             const float* __restrict__ SG, const float* __restrict__ deg, const float* __restrict__ stats,
             const float* __restrict__ g_losses, float* __restrict__ g_logits, int n, int K, int G, int LPRp,
-            const int32_t* __restrict__ gid, int64_t rows_total) {
+            const int32_t* __restrict__ gid, int64_t rows_total, const int32_t* __restrict__ asym = nullptr) {
   const int64_t rows = gid ? rows_total : (int64_t)G * n;
   const int RPB = 256 / LPRp;
   const int rl = threadIdx.x / LPRp, fl = threadIdx.x % LPRp;
@@ -982,11 +986,13 @@ k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const flo
     const size_t base = (size_t)r * K;
     float dS[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
     float dot = 0.f;
+    // a symmetric graph's A^T S was not computed (k_adj_s skipped it): it IS the forward's A S
+    const float* __restrict__ AtSr = (asym && asym[g] == 0) ? AS : AtS;
     if ((K & 3) == 0) {      // whole 16-byte pieces: four loads and one store per lane
       const int k0 = fl * 4;
       if (k0 < K) {
         const float4 s4 = *reinterpret_cast<const float4*>(S + base + k0), a4 = *reinterpret_cast<const float4*>(AS + base + k0);
-        const float4 t4 = *reinterpret_cast<const float4*>(AtS + base + k0), g4 = *reinterpret_cast<const float4*>(SG + base + k0);
+        const float4 t4 = *reinterpret_cast<const float4*>(AtSr + base + k0), g4 = *reinterpret_cast<const float4*>(SG + base + k0);
         sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
         dS[0] = c_num * (a4.x + t4.x) + c_den * 2.f * di * sv[0] + g4.x;
         dS[1] = c_num * (a4.y + t4.y) + c_den * 2.f * di * sv[1] + g4.y;
@@ -1007,7 +1013,7 @@ k_dense_bwd(const float* __restrict__ S, const float* __restrict__ AS, const flo
         const int k = k0 + q;
         if (k < K) {
           sv[q] = S[base + k];
-          dS[q] = c_num * (AS[base + k] + AtS[base + k]) + c_den * 2.f * di * sv[q] + SG[base + k];
+          dS[q] = c_num * (AS[base + k] + AtSr[base + k]) + c_den * 2.f * di * sv[q] + SG[base + k];
           dot = fmaf(dS[q], sv[q], dot);
         }
       }
@@ -1121,13 +1127,15 @@ int mincut_dense_fwd_impl(const float* x, const float* adj, const float* logits,
 int mincut_dense_bwd_impl(const float* adj, const float* S, const float* AS, const float* deg, const float* stats,
                           const float* ss, const float* g_losses, const int32_t* nptr, const int32_t* gid, int64_t N,
                           int64_t B, int n, int K, float* AtS, float* sg_ws, float* gss_ws, float* g_logits,
-                          hipStream_t st, int adj8 = 0) {
+                          hipStream_t st, int adj8 = 0, const int32_t* asym = nullptr) {
   int rc;
   const int rg = nptr ? 1 : 0;
   static const bool old_as = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 16;
   if (adj8) {
-    if ((rc = launch_adj_s<uint8_t>(reinterpret_cast<const uint8_t*>(adj), S, AtS, nullptr, nptr, B, n, n, (n + 31) & ~31, K, 1, st))) return rc;
+    if (!(nptr && (K & 3) == 0)) asym = nullptr;      // (the skipping form exists for the ragged byte route only)
+    if ((rc = launch_adj_s<uint8_t>(reinterpret_cast<const uint8_t*>(adj), S, AtS, nullptr, nptr, B, n, n, (n + 31) & ~31, K, 1, st, asym))) return rc;
   } else if (!old_as) {
+    asym = nullptr;
     if ((rc = launch_adj_s<float>(adj, S, AtS, nullptr, nptr, B, n, n, n, K, 1, st))) return rc;
   } else if ((rc = bgemm(adj, S, AtS, B, n, K, n, n, K, K, (int64_t)n * n, (int64_t)n * K, (int64_t)n * K, 1, st, nullptr,
                          Rag{nptr, 0, 1, 1}, rg, rg)))
@@ -1143,7 +1151,7 @@ int mincut_dense_bwd_impl(const float* adj, const float* S, const float* AS, con
   int64_t nb = (rows + 256 / LPRp - 1) / (256 / LPRp);
   if (nb > 8192) nb = 8192;
   k_dense_bwd<<<(unsigned)nb, 256, 0, st>>>(S, AS, AtS, sg_ws, deg, stats, g_losses, g_logits, n, K, (int)B, LPRp,
-                                            nptr ? gid : nullptr, rows);
+                                            nptr ? gid : nullptr, rows, adj8 ? asym : nullptr);
   HSCN_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -1203,9 +1211,65 @@ int hscn_mincut_dense_ragged_bwd(const void* adj, int adj_elem_bytes, const floa
                                AtS, sg_ws, gss_ws, g_logits, hscn_stream(stream_), adj_elem_bytes == 1);
 }
 
+// asym[b] |= 1 when the byte adjacency of graph b is not symmetric.  A workgroup compares one 64 x 64 tile (I, J), I <= J,
+// with the transpose of tile (J, I): both are read as rows (coalesced), the second one parked in LDS and read back
+// transposed.  Entries beyond a graph's nodes are zero on both sides.
+__global__ void __launch_bounds__(256)
+k_adj_asym_u8(const uint8_t* __restrict__ adj, int nmax, int64_t lda, int32_t* __restrict__ asym) {
+  __shared__ uint8_t tl[64][80];
+  const int T = (nmax + 63) / 64;
+  // blockIdx.x enumerates the pairs I <= J
+  int I = 0, rem = blockIdx.x;
+  while (rem >= T - I) { rem -= T - I; ++I; }
+  const int J = I + rem;
+  const int b = blockIdx.y;
+  const uint8_t* Ab = adj + (size_t)b * nmax * lda;
+  const int r = threadIdx.x >> 2, c16 = (threadIdx.x & 3) * 16;
+  uint4 a = make_uint4(0u, 0u, 0u, 0u), t = a;
+  const int ra = I * 64 + r, ca = J * 64 + c16;      // tile (I, J): row ra, columns ca .. ca + 15
+  const int rb = J * 64 + r, cb = I * 64 + c16;      // tile (J, I)
+  if (ra < nmax && ca + 16 <= lda) a = *reinterpret_cast<const uint4*>(Ab + (size_t)ra * lda + ca);
+  if (rb < nmax && cb + 16 <= lda) t = *reinterpret_cast<const uint4*>(Ab + (size_t)rb * lda + cb);
+  *reinterpret_cast<uint4*>(&tl[r][c16]) = t;
+  __syncthreads();
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w};
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const unsigned mine = (aw[q >> 2] >> (8 * (q & 3))) & 0xffu;      // A[ra][ca + q]
+    const int col = ca + q;
+    // its mirror A[col][ra] sits in tile (J, I) at row col - 64 J, column ra - 64 I = r
+    const unsigned other = tl[c16 + q][r];
+    if (col < nmax && ra < nmax && mine != other) bad = true;
+  }
+  if (bad) atomicOr(&asym[b], 1);
+}
+
 // The adjacency product of dense_mincut_pool alone: out = op(A) S for every graph of a ragged batch (op = transpose for the
 // backward's A^T S), deg (optional, transA = 0) = the row sums of A.  What hscn_mincut_dense_ragged_fwd / _bwd launch
 // for it, as an entry point of its own so that the route's dominant kernel can be timed and profiled by itself.
+int hscn_dense_adj_asymmetry_u8(const void* adj8, int64_t B, int nmax, int32_t* asym, void* stream_) {
+  if (!adj8 || !asym || B < 1 || nmax < 1) return HSCN_E_BADARG;
+  const int T = (nmax + 63) / 64;
+  k_adj_asym_u8<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)B), 256, 0, hscn_stream(stream_)>>>(
+      static_cast<const uint8_t*>(adj8), nmax, (int64_t)((nmax + 31) & ~31), asym);
+  HSCN_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int hscn_mincut_dense_ragged_bwd_sym(const void* adj, int adj_elem_bytes, const float* S, const float* AS, const float* deg,
+                                     const float* stats, const float* ss, const float* g_losses, const int32_t* nptr,
+                                     const int32_t* gid, int64_t N, int64_t B, int nmax, int K, float* AtS, float* sg_ws,
+                                     float* gss_ws, float* g_logits, const int32_t* asym, void* stream_) {
+  if (B < 1 || N < 1 || nmax < 1 || K < 1 || K > GNMAX) return HSCN_E_BADARG;
+  if (adj_elem_bytes != 4 && adj_elem_bytes != 1) return HSCN_E_BADARG;
+  if (!adj || !S || !AS || !deg || !stats || !ss || !g_losses || !nptr || !gid || !AtS || !sg_ws || !gss_ws || !g_logits)
+    return HSCN_E_BADARG;
+  return mincut_dense_bwd_impl(static_cast<const float*>(adj), S, AS, deg, stats, ss, g_losses, nptr, gid, N, B, nmax, K,
+                               AtS, sg_ws, gss_ws, g_logits, hscn_stream(stream_), adj_elem_bytes == 1,
+                               adj_elem_bytes == 1 ? asym : nullptr);
+}
+
 int hscn_dense_adj_s(const void* adj, int adj_elem_bytes, const float* S, const int32_t* nptr, int64_t B, int nmax, int K,
                      int transA, float* out, float* deg, void* stream_) {
   if (B < 1 || nmax < 1 || K < 1 || K > 64 || !adj || !S || !nptr || !out) return HSCN_E_BADARG;

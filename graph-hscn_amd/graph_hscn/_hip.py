@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("HSCN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhscn.so")
 _lib: Optional[ctypes.CDLL] = None
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 ACT = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 
 P = c_void_p
@@ -94,6 +94,8 @@ _SIGNATURES = {
     "hscn_mincut_dense_ragged_fwd": (c_int, [P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
     "hscn_mincut_dense_ragged_bwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int, c_int, P, P, P, P, P]),
     "hscn_dense_adj_s": (c_int, [P, c_int, P, P, c_int64, c_int, c_int, c_int, P, P, P]),
+    "hscn_dense_adj_asymmetry_u8": (c_int, [P, c_int64, c_int, P, P]),
+    "hscn_mincut_dense_ragged_bwd_sym": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int, c_int, P, P, P, P, P, P]),
     "hscn_to_dense_adj_ragged_u8": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
     "hscn_to_dense_adj_ragged": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int, P, P]),
     "hscn_gcn_norm_self_loops": (c_int, [P, P, P, c_int64, c_int64, c_float, P, P, P, P]),

@@ -196,11 +196,18 @@ class SCN(nn.Module):
                 # (the adjacency as bytes: nobody outside this call sees it -- batched calls return None in its slot --
                 # and the products that stream it move a quarter of the bytes; HSCN_DENSE_ADJ=f32 keeps floats)
                 as_bytes = os.environ.get("HSCN_DENSE_ADJ", "u8") != "f32"
+                want_sym = as_bytes and os.environ.get("HSCN_DENSE_SYM", "1") != "0"     # (A/B: 0 = always compute A^T S)
                 if raw_edge_index is not None:
-                    adj = to_dense_adj_ragged(raw_edge_index, node_ptr, node_graph, Bg, ng, raw=True, as_bytes=as_bytes)
+                    adj = to_dense_adj_ragged(raw_edge_index, node_ptr, node_graph, Bg, ng, raw=True, as_bytes=as_bytes,
+                                              symmetry=want_sym)
                 else:
-                    adj = to_dense_adj_ragged(edge_index, node_ptr, node_graph, Bg, ng, as_bytes=as_bytes)
-                S, mc_loss, o_loss, _, _ = Fh.MinCutDenseRaggedFn.apply(s, x, adj, node_ptr, node_graph)
+                    adj = to_dense_adj_ragged(edge_index, node_ptr, node_graph, Bg, ng, as_bytes=as_bytes, symmetry=want_sym)
+                # byte route: one pass flags the graphs whose adjacency is not symmetric; the others (undirected graphs:
+                # the norm) take the backward's A^T S from the forward's A S
+                asym = None
+                if want_sym:
+                    adj, asym = adj
+                S, mc_loss, o_loss, _, _ = Fh.MinCutDenseRaggedFn.apply(s, x, adj, node_ptr, node_graph, asym)
                 self.last_route = "dense-ragged"
                 return S, mc_loss, o_loss, None
             adj = to_dense_adj_batched(edge_index, Bg, ng)

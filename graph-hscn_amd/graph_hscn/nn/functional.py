@@ -448,7 +448,10 @@ class MinCutDenseRaggedFn(Function):
     losses = mean over graphs, every graph's terms equal to the single-graph call's (hscn_mincut_dense_ragged_*)."""
 
     @staticmethod
-    def forward(ctx, logits: Tensor, x: Optional[Tensor], adj: Tensor, nptr: Tensor, gid: Tensor):
+    def forward(ctx, logits: Tensor, x: Optional[Tensor], adj: Tensor, nptr: Tensor, gid: Tensor,
+                asym: Optional[Tensor] = None):
+        """asym (uint8 adjacency only): int32 [B] from ``to_dense_adj_ragged(..., symmetry=True)`` -- graphs flagged 0 are
+        symmetric, and the backward takes their ``A^T S`` from the forward's ``A S`` instead of computing it."""
         if adj.dtype not in (torch.float32, torch.uint8):
             raise TypeError(f"the dense adjacency is float32 or uint8 (got {adj.dtype})")
         logits, x, adj = _c(logits), _c(x), adj.contiguous()
@@ -466,7 +469,11 @@ class MinCutDenseRaggedFn(Function):
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         call("hscn_mincut_dense_ragged_fwd", ptr(x), ptr(adj), adj.element_size(), ptr(logits), ptr(nptr), N, B, nmax, K, Fx, ptr(S), ptr(AS),
              ptr(deg), ptr(stats), ptr(ss), ptr(px), ptr(padj), ptr(losses), stream())
-        ctx.save_for_backward(adj, S, AS, deg, stats, ss, nptr, gid)
+        ctx.has_asym = asym is not None and adj.dtype == torch.uint8
+        if ctx.has_asym:
+            ctx.save_for_backward(adj, S, AS, deg, stats, ss, nptr, gid, asym)
+        else:
+            ctx.save_for_backward(adj, S, AS, deg, stats, ss, nptr, gid)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(S, padj)
         if px is not None:
@@ -475,7 +482,11 @@ class MinCutDenseRaggedFn(Function):
 
     @staticmethod
     def backward(ctx, gS, g_mc, g_o, g_px, g_padj):
-        adj, S, AS, deg, stats, ss, nptr, gid = ctx.saved_tensors
+        if ctx.has_asym:
+            adj, S, AS, deg, stats, ss, nptr, gid, asym = ctx.saved_tensors
+        else:
+            adj, S, AS, deg, stats, ss, nptr, gid = ctx.saved_tensors
+            asym = None
         N, K = S.shape
         B, nmax = adj.shape[0], adj.shape[1]
         gl = _pack_loss_grads(g_mc, g_o, S.device)
@@ -483,9 +494,9 @@ class MinCutDenseRaggedFn(Function):
         SG = torch.empty_like(S)
         Gss = torch.empty_like(ss)
         g_logits = torch.empty_like(S)
-        call("hscn_mincut_dense_ragged_bwd", ptr(adj), adj.element_size(), ptr(S), ptr(AS), ptr(deg), ptr(stats), ptr(ss), ptr(gl), ptr(nptr),
-             ptr(gid), N, B, nmax, K, ptr(AtS), ptr(SG), ptr(Gss), ptr(g_logits), stream())
-        return g_logits, None, None, None, None
+        call("hscn_mincut_dense_ragged_bwd_sym", ptr(adj), adj.element_size(), ptr(S), ptr(AS), ptr(deg), ptr(stats), ptr(ss), ptr(gl),
+             ptr(nptr), ptr(gid), N, B, nmax, K, ptr(AtS), ptr(SG), ptr(Gss), ptr(g_logits), ptr(asym), stream())
+        return g_logits, None, None, None, None, None
 
 
 class MinCutDenseFn(Function):

@@ -46,7 +46,8 @@ def to_dense_adj_batched(edge_index: Tensor, num_graphs: int, nodes_per_graph: i
 
 
 def to_dense_adj_ragged(edge_index: Tensor, nptr: Tensor, gid: Tensor, num_graphs: int, max_nodes: int,
-                        raw: bool = False, as_bytes: bool = False, flag: Optional[Tensor] = None) -> Tensor:
+                        raw: bool = False, as_bytes: bool = False, flag: Optional[Tensor] = None,
+                        symmetry: bool = False):
     """``to_dense_adj(edge_index, batch)`` for a block-diagonal batch of graphs of different sizes: ``[B, nmax, nmax]``,
     zero beyond a graph's own nodes.  ``raw=True``: ``edge_index`` is the RAW edge list and the result is what
     ``gcn_norm(add_self_loops=True)`` followed by ``to_dense_adj`` gives -- off-diagonal counts plus the identity
@@ -55,9 +56,18 @@ def to_dense_adj_ragged(edge_index: Tensor, nptr: Tensor, gid: Tensor, num_graph
     if as_bytes:
         # the counts as bytes, rows padded to a multiple of 32: what the batched dense route streams through the
         # matrix cores (a quarter of the float adjacency's bytes; exact up to 255 parallel edges, flag bit 16 beyond)
-        adj8 = torch.zeros(B, n, (n + 31) // 32 * 32, dtype=torch.uint8, device=edge_index.device)
+        # symmetry=True (as_bytes only): also returns asym int32 [B] -- 1 where a graph's adjacency is NOT symmetric
+        # (hscn_dense_adj_asymmetry_u8); the flags live behind the adjacency in the same zero-filled allocation
+        lda = (n + 31) // 32 * 32
+        nb = B * n * lda
+        buf = torch.zeros(nb + (4 * B if symmetry else 0), dtype=torch.uint8, device=edge_index.device)
+        adj8 = buf[:nb].view(B, n, lda)
         call("hscn_to_dense_adj_ragged_u8", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()),
              edge_index.size(1), ptr(nptr), ptr(gid), int(gid.numel()), B, n, 1 if raw else 0, ptr(adj8), ptr(flag), stream())
+        if symmetry:
+            asym = buf[nb:].view(torch.int32)
+            call("hscn_dense_adj_asymmetry_u8", ptr(adj8), B, n, ptr(asym), stream())
+            return adj8, asym
         return adj8
     adj = torch.zeros(B, n, n, dtype=torch.float32, device=edge_index.device)
     call("hscn_to_dense_adj_ragged", ptr(edge_index[0].contiguous()), ptr(edge_index[1].contiguous()),

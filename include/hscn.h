@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HSCN_ABI_VERSION 17
+#define HSCN_ABI_VERSION 18
 
 #define HSCN_E_BADARG (-1)   /* null pointer, negative size, unsupported width */
 #define HSCN_E_WORKSPACE (-2) /* workspace too small */
@@ -241,6 +241,19 @@ int hscn_mincut_dense_ragged_bwd(const void* adj, int adj_elem_bytes, const floa
                                  const float* stats, const float* ss, const float* g_losses /*[2]*/,
                                  const int32_t* nptr, const int32_t* gid /*[N]*/, int64_t N, int64_t B, int nmax, int K,
                                  float* AtS, float* sg_ws, float* gss_ws /*[B,K,K]*/, float* g_logits, void* stream);
+/* ABI 18: undirected graphs -- the norm in the reference's datasets -- have A^T = A, so the backward's A^T S is the forward's
+ * A S.  hscn_dense_adj_asymmetry_u8 sets asym[b] (int32 [B], ZERO on entry) to 1 for every graph of a ragged byte
+ * adjacency ([B, nmax, lda8], hscn_to_dense_adj_ragged_u8) that is NOT symmetric (one pass of 64 x 64 tile pairs);
+ * hscn_mincut_dense_ragged_bwd_sym = hscn_mincut_dense_ragged_bwd with those flags (asym may be NULL = the general
+ * form): graphs with asym[b] == 0 skip the A^T S product -- the largest launch of the backward -- and read AS.
+ * Same gradients bit for bit (A^T S and A S are the same sums over the same entries in the same order). */
+int hscn_dense_adj_asymmetry_u8(const void* adj8, int64_t B, int nmax, int32_t* asym /*[B]*/, void* stream);
+int hscn_mincut_dense_ragged_bwd_sym(const void* adj, int adj_elem_bytes, const float* S, const float* AS, const float* deg,
+                                     const float* stats, const float* ss, const float* g_losses /*[2] device*/,
+                                     const int32_t* nptr, const int32_t* gid, int64_t N, int64_t B, int nmax, int K,
+                                     float* AtS, float* sg_ws, float* gss_ws, float* g_logits,
+                                     const int32_t* asym /*[B] or NULL*/, void* stream);
+
 /* ABI 17: the adjacency product of the dense route by itself -- out [N,K] = op(A) S per graph of a ragged batch (the
  * A S of dense_mincut_pool, reference model/hscn.py:63 -> PyG dense_mincut_pool's `torch.matmul(adj, s)`; transA = 1: the
  * A^T S its backward needs), deg [N] (optional, transA = 0) = row sums of A.  The launch hscn_mincut_dense_ragged_fwd /

@@ -232,10 +232,11 @@ def test_scn_dense_mfma_route_matches_oracle_through_the_model(route, K):
     assert abs(float(ob) - np.mean([s[2] for s in singles])) < 1e-6
 
 
+@pytest.mark.parametrize("directed", [False, True])
 @pytest.mark.parametrize("adj_format", ["u8", "f32"])
 @pytest.mark.parametrize("K,sizes", [(64, (395, 500, 479, 431, 463)), (16, (40, 7, 129)), (64, (2, 64, 65, 128, 500)),
                                      (32, (130, 257, 33))])
-def test_scn_dense_route_on_a_ragged_batch_matches_the_oracle_loop(K, sizes, adj_format, monkeypatch):
+def test_scn_dense_route_on_a_ragged_batch_matches_the_oracle_loop(K, sizes, adj_format, directed, monkeypatch):
     """BASELINE.json configs[3] with its REAL size spread (PascalVOC-SP: n in [395, 500]): a batch of graphs of
     different sizes through ``forward_graphs`` on the dense route (adjacency [B, nmax, nmax] zero beyond each graph,
     node-indexed tensors flat, hscn_mincut_dense_ragged_*) against the oracle's reference loop -- one graph at a
@@ -248,6 +249,14 @@ def test_scn_dense_route_on_a_ragged_batch_matches_the_oracle_loop(K, sizes, adj
     torch.manual_seed(K + len(sizes))
     rng = np.random.default_rng(K + len(sizes))
     graphs = [make_graph(rng, SHAPES["pascalvoc_sp"], n=nn) for nn in sizes]
+    if directed:
+        # every other graph loses a third of its edges (one direction of them): the batch then mixes symmetric
+        # adjacencies -- whose A^T S the byte route's backward takes from the forward's A S -- with asymmetric ones
+        for gi in range(0, len(graphs), 2):
+            ei = graphs[gi].edge_index
+            keep = torch.from_numpy(rng.random(ei.size(1)) > 0.33) | (ei[0] > ei[1])
+            if int(keep.sum()) < ei.size(1):
+                graphs[gi].edge_index = ei[:, keep].contiguous()
     F = graphs[0].x.size(1)
     om = OM.SCN([16], "elu", F, K)
     pm = SCN([16], "elu", F, K, mincut_route="dense").to(DEV)
