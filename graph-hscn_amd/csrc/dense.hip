@@ -704,9 +704,12 @@ int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int
     const bool split = NT == 2 && sizeof(AT) == 1 && split_env;
     dim3 gd(grid.x, grid.y, split ? 2 : 1);
     static const int lds_pad = getenv("HSCN_DENSE_LDS_PAD") ? atoi(getenv("HSCN_DENSE_LDS_PAD")) : 0;   // A/B: workgroups per CU
-    // 128-row tiles (four waves) by default.  HSCN_DENSE_ROWS=64 / 256: two / eight waves per workgroup (A/B; 64 rows:
-    // +18 us on the forward call -- every workgroup stages its own S slabs, and halving the rows doubles that share)
-    static const int rows_env = getenv("HSCN_DENSE_ROWS") ? atoi(getenv("HSCN_DENSE_ROWS")) : 128;
+    // HSCN_DENSE_ROWS=64 / 128 / 256 forces two / four / eight waves per workgroup (A/B; 64 rows: +18 us on the forward
+    // call -- every workgroup stages its own S slabs, and halving the rows doubles that share)
+    // default: 256-row tiles (eight waves share a staged S slab) whenever they pad the largest graph no further than
+    // 128-row tiles do -- PascalVOC-SP's 395 .. 500 nodes: 512 rows either way; 42.5 vs 44.0 us, MFMA-busy 0.60 vs 0.58
+    static const int rows_forced = getenv("HSCN_DENSE_ROWS") ? atoi(getenv("HSCN_DENSE_ROWS")) : 0;
+    const int rows_env = rows_forced ? rows_forced : (((nmax + 255) / 256) * 256 == ((nmax + 127) / 128) * 128 ? 256 : 128);
     dim3 gd2((unsigned)((nmax + 63) / 64), gd.y, gd.z), gd8((unsigned)((nmax + 255) / 256), gd.y, gd.z);
 #define HSCN_ADJ_D(NT_, RS_, KV_) do { \
       if (rows_env == 64) k_adj_s_direct<AT, NT_, RS_, KV_, 2><<<gd2, 128, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); \
