@@ -424,8 +424,8 @@ k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* _
   const int row0 = nptr ? nptr[b] : b * n_uniform;
   const int n = nptr ? nptr[b + 1] - row0 : n_uniform;
   if (m0 >= n) return;
-  // blockIdx.z: which slice of 32 NT columns of S (and C) this workgroup multiplies -- with byte adjacency re-reading A
-  // per slice is cheap, and twice the waves hide each other's slab barriers and operand latencies
+  // (blockIdx.z: a slice of 32 NT columns of S and C -- the launch uses one slice: splitting K = 64 over two
+  // workgroups was measured 2 us slower)
   const int c0 = blockIdx.z * 32 * NT;
   const AT* Ab = adj + (size_t)b * nmax * lda;
   const float* Sb = S + (size_t)row0 * K + c0;
@@ -577,109 +577,6 @@ k_adj_s_direct(const AT* __restrict__ adj, const float* __restrict__ S, float* _
   }
 }
 
-// ---- A S with BOTH operands in registers: no LDS, no workgroup barrier (TA = 0, byte or float adjacency) ----------
-// A wave owns a 32 x 32 tile of C: 32 rows of A times 32 columns of S.  Per 32-deep slab lane (i, h) loads its 16
-// adjacency entries A[row i][k0 + 16 h ..] (one 16-byte load of bytes, two slabs ahead) and the 16 entries
-// S[k0 + 16 h + j][c0 + (lane & 31)], j = 0 .. 15, of ITS column (16 dword loads, a half wave reads 128 contiguous
-// bytes per load; S is L2-resident and shared by the graph's waves; one slab ahead), then issues 16 MFMAs on one
-// accumulator.  Waves never wait for each other: what one wave's loads cost, the other waves of its SIMD cover.
-template <typename AT, bool RS>
-__global__ void __launch_bounds__(256)
-k_adj_s_reg(const AT* __restrict__ adj, const float* __restrict__ S, float* __restrict__ C, float* __restrict__ rsum,
-            const int32_t* __restrict__ nptr, int n_uniform, int nmax, int64_t lda, int K) {
-  typedef float f32x16 __attribute__((ext_vector_type(16)));
-  constexpr int BK = 32;
-  constexpr bool U8 = sizeof(AT) == 1;
-  constexpr int AR = U8 ? 4 : 16;
-  const int b = blockIdx.y;
-  const int row0 = nptr ? nptr[b] : b * n_uniform;
-  const int n = nptr ? nptr[b + 1] - row0 : n_uniform;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
-  const int m0 = (blockIdx.x * 4 + wave) * 32;       // this wave's row tile
-  if (m0 >= n) return;                                // (no barrier below: a wave may leave alone)
-  const int c0 = blockIdx.z * 32;
-  const AT* Ab = adj + (size_t)b * nmax * lda;
-  const float* Sb = S + (size_t)row0 * K;
-  float* Cb = C + (size_t)row0 * K;
-  const int row = m0 + li, colg = c0 + li;
-  const bool colok = colg < K;
-  const AT* arow = Ab + (size_t)(row < n ? row : 0) * lda + 16 * lh;
-  const float* scol = Sb + (colok ? colg : 0);
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  auto fetchA = [&](int k0, unsigned (&ra)[AR]) {
-#pragma unroll
-    for (int u = 0; u < AR; ++u) ra[u] = 0u;
-    if (row < n && k0 < n) {
-      if constexpr (U8) {
-        const uint4 w = *reinterpret_cast<const uint4*>(arow + k0);
-        ra[0] = w.x; ra[1] = w.y; ra[2] = w.z; ra[3] = w.w;
-      } else {
-        const float* p = reinterpret_cast<const float*>(arow) + k0;
-        const int c = k0 + 16 * lh;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          const int cc = c + 4 * u;
-          if (cc + 3 < n) v = ld4u(p + 4 * u);
-          else {
-            if (cc < n) v.x = p[4 * u];
-            if (cc + 1 < n) v.y = p[4 * u + 1];
-            if (cc + 2 < n) v.z = p[4 * u + 2];
-          }
-          ra[4 * u] = __float_as_uint(v.x); ra[4 * u + 1] = __float_as_uint(v.y);
-          ra[4 * u + 2] = __float_as_uint(v.z); ra[4 * u + 3] = __float_as_uint(v.w);
-        }
-      }
-    }
-  };
-  auto a_of = [&](const unsigned (&ra)[AR], int j) -> float {
-    if constexpr (U8) return (float)((ra[j >> 2] >> (8 * (j & 3))) & 0xffu);
-    else return __uint_as_float(ra[j]);
-  };
-  auto fetchB = [&](int k0, float (&rbv)[16]) {
-    const int kb = k0 + 16 * lh;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const bool ok = colok && kb + j < n;
-      const float v = scol[(size_t)(ok ? kb + j : 0) * K];
-      rbv[j] = ok ? v : 0.f;
-    }
-  };
-  unsigned a0[AR], a1[AR], a2[AR];
-  float b0[16], b1[16];
-  fetchA(0, a0);
-  fetchA(BK, a1);
-  fetchB(0, b0);
-  float rs = 0.f;
-  for (int k0 = 0; k0 < n; k0 += BK) {
-    fetchA(k0 + 2 * BK, a2);
-    if (k0 + BK < n) fetchB(k0 + BK, b1);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float a = a_of(a0, j);
-      if (RS) rs += a;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[j], acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < AR; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) b0[j] = b1[j];
-  }
-  if (RS) {
-    rs += __shfl_xor(rs, 32, 64);
-    if (lh == 0 && row < n && blockIdx.z == 0) rsum[(size_t)row0 + row] = rs;
-  }
-  if (colok) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (orow < n) Cb[(size_t)orow * K + colg] = acc[r];
-    }
-  }
-}
-
 template <typename AT>
 int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int32_t* nptr, int64_t B, int n, int nmax,
                  int64_t lda, int K, int transA, hipStream_t st, const int32_t* asym = nullptr) {
@@ -687,37 +584,25 @@ int launch_adj_s(const AT* adj, const float* S, float* C, float* rsum, const int
   const int NT = K > 32 ? 2 : 1;
   static const bool via_lds = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 32;   // A/B: A staged through LDS
   // measured on a PascalVOC-SP batch (B = 128, K = 64, byte adjacency; profiles/r03_dense_*): S through LDS 51-52 us
-  // (49-57 % MFMA-busy), both operands in registers 65.6 us (HSCN_DENSE_AS=34), A through LDS as well 59 us (=32), the
+  // (49-57 % MFMA-busy), both operands in registers 65.6 us (a kernel since removed), A through LDS as well 59 us (=32), the
   // 16x16x4 kernel on a float adjacency 49 us (=16)
-  static const bool via_reg = getenv("HSCN_DENSE_AS") && atoi(getenv("HSCN_DENSE_AS")) == 34;
-  if (!transA && !via_lds && via_reg) {
-    dim3 gr((unsigned)((nmax + 127) / 128), (unsigned)B, (unsigned)((K + 31) / 32));
-    if (rsum) k_adj_s_reg<AT, true><<<gr, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
-    else k_adj_s_reg<AT, false><<<gr, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K);
-    HSCN_RETURN_IF_LAUNCH_FAILED();
-    return 0;
-  }
   if (!transA && !via_lds) {
     // K > 32: one workgroup per row tile with two 32-column accumulators per wave (two independent MFMA chains, A read
-    // once); HSCN_DENSE_SPLIT=1: two workgroups of 32 columns each (measured 2 us slower on the forward call)
-    static const bool split_env = getenv("HSCN_DENSE_SPLIT") && atoi(getenv("HSCN_DENSE_SPLIT")) == 1;
-    const bool split = NT == 2 && sizeof(AT) == 1 && split_env;
-    dim3 gd(grid.x, grid.y, split ? 2 : 1);
-    static const int lds_pad = getenv("HSCN_DENSE_LDS_PAD") ? atoi(getenv("HSCN_DENSE_LDS_PAD")) : 0;   // A/B: workgroups per CU
-    // HSCN_DENSE_ROWS=64 / 128 / 256 forces two / four / eight waves per workgroup (A/B; 64 rows: +18 us on the forward
-    // call -- every workgroup stages its own S slabs, and halving the rows doubles that share)
-    // default: 256-row tiles (eight waves share a staged S slab) whenever they pad the largest graph no further than
-    // 128-row tiles do -- PascalVOC-SP's 395 .. 500 nodes: 512 rows either way; 42.5 vs 44.0 us, MFMA-busy 0.60 vs 0.58
+    // once).  Measured and removed: 32-column halves on separate workgroups (+2 us on the forward call), 64-row tiles
+    // (+18 us), LDS padding to cap the workgroups per CU (no change).
+    dim3 gd(grid.x, grid.y, 1);
+    // 256-row tiles (eight waves share a staged S slab) whenever they pad the largest graph no further than 128-row tiles
+    // do -- PascalVOC-SP's 395 .. 500 nodes: 512 rows either way; 42.5 vs 44.0 us, MFMA-busy 0.60 vs 0.58.
+    // HSCN_DENSE_ROWS=128 / 256 forces one form (A/B)
     static const int rows_forced = getenv("HSCN_DENSE_ROWS") ? atoi(getenv("HSCN_DENSE_ROWS")) : 0;
     const int rows_env = rows_forced ? rows_forced : (((nmax + 255) / 256) * 256 == ((nmax + 127) / 128) * 128 ? 256 : 128);
-    dim3 gd2((unsigned)((nmax + 63) / 64), gd.y, gd.z), gd8((unsigned)((nmax + 255) / 256), gd.y, gd.z);
+    dim3 gd8((unsigned)((nmax + 255) / 256), gd.y, 1);
 #define HSCN_ADJ_D(NT_, RS_, KV_) do { \
-      if (rows_env == 64) k_adj_s_direct<AT, NT_, RS_, KV_, 2><<<gd2, 128, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); \
-      else if (rows_env == 256) k_adj_s_direct<AT, NT_, RS_, KV_, 8><<<gd8, 512, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); \
-      else k_adj_s_direct<AT, NT_, RS_, KV_, 4><<<gd, 256, lds_pad, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); } while (0)
+      if (rows_env == 256) k_adj_s_direct<AT, NT_, RS_, KV_, 8><<<gd8, 512, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); \
+      else k_adj_s_direct<AT, NT_, RS_, KV_, 4><<<gd, 256, 0, st>>>(adj, S, C, rsum, nptr, n, nmax, lda, K); } while (0)
 #define HSCN_ADJ_DK(NT_, RS_) do { if ((K & 3) == 0) HSCN_ADJ_D(NT_, RS_, true); else HSCN_ADJ_D(NT_, RS_, false); } while (0)
-    if (rsum) { if (NT == 2 && !split) HSCN_ADJ_DK(2, true); else HSCN_ADJ_DK(1, true); }
-    else { if (NT == 2 && !split) HSCN_ADJ_DK(2, false); else HSCN_ADJ_DK(1, false); }
+    if (rsum) { if (NT == 2) HSCN_ADJ_DK(2, true); else HSCN_ADJ_DK(1, true); }
+    else { if (NT == 2) HSCN_ADJ_DK(2, false); else HSCN_ADJ_DK(1, false); }
 #undef HSCN_ADJ_DK
 #undef HSCN_ADJ_D
     HSCN_RETURN_IF_LAUNCH_FAILED();
