@@ -1102,7 +1102,7 @@ int hscn_mincut_dense_ragged_bwd(const void* adj, int adj_elem_bytes, const floa
 // asym[b] |= 1 when the byte adjacency of graph b is not symmetric.  A workgroup compares one 64 x 64 tile (I, J), I <= J,
 // with the transpose of tile (J, I): both are read as rows (coalesced), the second one parked in LDS and read back
 // transposed.  Entries beyond a graph's nodes are zero on both sides.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_adj_asym_u8(const uint8_t* __restrict__ adj, int nmax, int64_t lda, int32_t* __restrict__ asym) {
   __shared__ uint8_t tl[64][80];
   const int T = (nmax + 63) / 64;
