@@ -319,3 +319,44 @@ def test_bgemm_mfma_asymmetric_operands():
         _hip.call("hscn_bgemm_f32", _hip.ptr(Ad), _hip.ptr(Bd), _hip.ptr(C), 2, M, N, Kd, Ad.stride(1), N, N,
                   Ad.stride(0), Kd * N, M * N, ta, _hip.stream())
         assert close(C, want, atol=2e-4, rtol=1e-5), (M, N, Kd, ta)
+
+
+def test_dense_adj_s_entry_and_symmetry_flags():
+    """hscn_dense_adj_s (the A S / A^T S launch of the dense route by itself) against torch.matmul on a ragged byte
+    adjacency, and hscn_dense_adj_asymmetry_u8: 0 for undirected graphs, 1 for a graph with a single one-way edge --
+    also when that edge sits across a 64 x 64 tile boundary or in the last row."""
+    from graph_hscn import _hip
+    from graph_hscn.nn.pool import to_dense_adj_ragged
+    g = torch.Generator().manual_seed(9)
+    sizes = [70, 129, 5, 200]
+    K = 16
+    eis, off = [], 0
+    one_way = {1: (3, 100), 3: (199, 64)}        # graph -> (src, dst) of an extra directed edge
+    for b, n in enumerate(sizes):
+        e = torch.randint(0, n, (2, 3 * n), generator=g)
+        e = torch.cat([e, e.flip(0)], 1)          # undirected
+        if b in one_way:
+            e = torch.cat([e, torch.tensor([[one_way[b][0]], [one_way[b][1]]])], 1)
+        eis.append(e + off)
+        off += n
+    ei = torch.cat(eis, 1).to(DEV)
+    N, B, nmax = off, len(sizes), max(sizes)
+    nptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    gid = torch.repeat_interleave(torch.arange(B, dtype=torch.int32), torch.tensor(sizes)).to(DEV)
+    adj8, asym = to_dense_adj_ragged(ei, nptr, gid, B, nmax, as_bytes=True, symmetry=True)
+    assert asym.cpu().tolist() == [0, 1, 0, 1]
+    S = torch.rand(N, K, generator=g).to(DEV)
+    A = adj8[:, :, :nmax].float()
+    for transA in (0, 1):
+        out = torch.empty(N, K, device=DEV)
+        deg = torch.empty(N, device=DEV)
+        _hip.call("hscn_dense_adj_s", _hip.ptr(adj8), 1, _hip.ptr(S), _hip.ptr(nptr), B, nmax, K, transA, _hip.ptr(out),
+                  _hip.ptr(deg) if not transA else None, _hip.stream())
+        o = 0
+        for b, n in enumerate(sizes):
+            Ab = A[b, :n, :n].t() if transA else A[b, :n, :n]
+            want = Ab.double() @ S[o:o + n].double()
+            assert torch.allclose(out[o:o + n].double(), want, atol=1e-4, rtol=1e-6), (b, transA)
+            if not transA:
+                assert torch.equal(deg[o:o + n], A[b, :n, :n].sum(1))
+            o += n
