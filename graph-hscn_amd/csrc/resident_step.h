@@ -794,10 +794,16 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                   if (p + u < c) {
+#ifndef HSCN_BWD_SEPARATE   // fused multiply-add, as the forward's gather (26.82 -> 26.54 us per step); -DHSCN_BWD_SEPARATE:
+                            // product and sum rounded separately, the launch pair's values
+                    z.x = fmaf(ww[u], vv[u].x, z.x); z.y = fmaf(ww[u], vv[u].y, z.y);
+                    z.z = fmaf(ww[u], vv[u].z, z.z); z.w = fmaf(ww[u], vv[u].w, z.w);
+#else
                     z.x = add_rn(z.x, mul_rn(ww[u], vv[u].x));
                     z.y = add_rn(z.y, mul_rn(ww[u], vv[u].y));
                     z.z = add_rn(z.z, mul_rn(ww[u], vv[u].z));
                     z.w = add_rn(z.w, mul_rn(ww[u], vv[u].w));
+#endif
                   }
                 }
               }
@@ -821,10 +827,15 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               if (p + u < t0) {
+#ifndef HSCN_BWD_SEPARATE
+                z.x = fmaf(ww[u], vv[u].x, z.x); z.y = fmaf(ww[u], vv[u].y, z.y);
+                z.z = fmaf(ww[u], vv[u].z, z.z); z.w = fmaf(ww[u], vv[u].w, z.w);
+#else
                 z.x = add_rn(z.x, mul_rn(ww[u], vv[u].x));
                 z.y = add_rn(z.y, mul_rn(ww[u], vv[u].y));
                 z.z = add_rn(z.z, mul_rn(ww[u], vv[u].z));
                 z.w = add_rn(z.w, mul_rn(ww[u], vv[u].w));
+#endif
               }
             }
           }
