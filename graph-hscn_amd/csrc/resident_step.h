@@ -93,7 +93,7 @@ __host__ __device__ inline StepLayout step_layout(int H, int L, int C, int max_n
   Y.dinv = take(max_n);
   Y.wt = take((size_t)L * (H * H + H));                            // per layer: Wt[k][o] (rows k >= fin zero) | b[H]
   Y.headw = take((size_t)H * H + H + (size_t)C * H + 4 * (size_t)C);  // W1 | b1 | W2 | b2 | target row | g_pred row | loss terms
-  Y.part = take((size_t)2 * (RT_MAX / 64) * H);                    // pool partials, later bias-gradient partials (x2: layer parity)
+  Y.part = take((size_t)3 * (RT_MAX / 64) * H);                    // pool partials, later bias-gradient partials (x3: layer mod 3)
   Y.vec = take(320);
   Y.red = take((size_t)(RT_MAX / 64) * 256);
   // the structure region: two CSRs (rowptr | col | rowptr_t | col_t) or, for low-degree graphs at H = 16, two tables of
@@ -674,7 +674,11 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       const int fin = l == 0 ? F : H;
       off -= H * fin + H;
       const int oW = off, ob = off + H * fin;
-      float* bredw = bred + (it & 1) * NW * H;
+      // bias-gradient partials of the layer of iteration j live in slot j % 3: iteration `it` folds slot it - 1, fills slot
+      // `it` (it = 0 only: the pass below) and -- in its tiles' epilogue -- slot it + 1 for the next layer
+      float* bredw = bred + (it % 3) * NW * H;
+      float* bredn = bred + ((it + 1) % 3) * NW * H;
+      float bsum = 0.f;       // this lane's share of the NEXT layer's bias gradient: column li of the rows it writes
       if (it > 0) lds_barrier();  // G complete; the previous layer's partial tiles and bias partials are in LDS
                                    // (it = 0: nothing was written to LDS since the barrier behind the head)
       if (pend_oW >= 0) {
@@ -691,7 +695,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
         }
         if ((int)threadIdx.x >= RT - H) {
           const int c_ = (int)threadIdx.x - (RT - H);
-          const float* bp = bred + ((it - 1) & 1) * NW * H;
+          const float* bp = bred + ((it - 1) % 3) * NW * H;
           float sb = 0.f;
 #pragma unroll
           for (int w = 0; w < NW; ++w) sb += bp[w * H + c_];
@@ -702,7 +706,8 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
           if (lane == 0) __hip_atomic_fetch_add(fold_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      {   // bias gradient = column sums of G
+      if (it == 0) {   // bias gradient = column sums of G (first backward layer: G is the masked pool gradient; later
+                       // layers' sums were left by the previous layer's tile epilogues, see `bsum`)
         const int slot = lane >> 2, f = (lane & 3) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = wave * 16 + slot; i < n; i += NW * 16) {
@@ -763,7 +768,9 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
             const int row = r0 + lj * 4 + r;
             if (row < n) {
               const int idx = row * H + li;
-              Xl[idx] = Xl[idx] > 0.f ? acc[r] : 0.f;
+              const float gnew = Xl[idx] > 0.f ? acc[r] : 0.f;
+              Xl[idx] = gnew;
+              bsum += gnew;      // column li of G_l: the bias gradient of layer l - 1
             }
           }
         }
@@ -849,6 +856,11 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave * 256 + (lj * 4 + r) * 16 + li] = accw[r];
+      if (l > 0) {     // the wave's column sums of the G it has written (its tiles' rows): fold the four row groups
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lj == 0) bredn[wave * H + li] = bsum;
+      }
       pend_oW = oW; pend_fin = fin; pend_ob = ob;
       Gc = Xl;
       STAMP(16 + 3 * l);
@@ -856,7 +868,7 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     lds_barrier();
     fold_gw(0, pend_oW, pend_fin);
     if (threadIdx.x < H) {
-      const float* bp = bred + ((L - 1) & 1) * NW * H;
+      const float* bp = bred + ((L - 1) % 3) * NW * H;
       float sb = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) sb += bp[w * H + threadIdx.x];
