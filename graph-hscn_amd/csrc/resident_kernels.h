@@ -335,7 +335,9 @@ __device__ void lin_mfma(const float* X, const float* Wt, float* Y, int n, const
 template <int H, typename TS, bool E16 = false>
 __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, const float* X, const float* Wt,
                           const float* bias, float* Y, TS* __restrict__ gout, int n, const Grp& G,
-                          float* pool_part = nullptr) {
+                          float* pool_part = nullptr, float* pos_part = nullptr) {
+  // pos_part (optional, [H] words of this wave, with pool_part): how many of the rows this wave produced are POSITIVE in
+  // each column -- the first backward layer's bias gradient is that count times the pool gradient, so it needs no pass
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int TD = H / 16, KS = H / 4;
   const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
@@ -343,13 +345,16 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
   if (G.w >= ntile) {
     if (pool_part && lj == 0) {
 #pragma unroll
-      for (int ct = 0; ct < TD; ++ct) pool_part[ct * 16 + li] = 0.f;
+      for (int ct = 0; ct < TD; ++ct) {
+        pool_part[ct * 16 + li] = 0.f;
+        if (pos_part) pos_part[ct * 16 + li] = 0.f;
+      }
     }
     return;
   }
-  float ps[TD];
+  float ps[TD], pc[TD];
 #pragma unroll
-  for (int ct = 0; ct < TD; ++ct) ps[ct] = 0.f;
+  for (int ct = 0; ct < TD; ++ct) { ps[ct] = 0.f; pc[ct] = 0.f; }
   float b[TD][KS], bia[TD];
 #pragma unroll
   for (int ct = 0; ct < TD; ++ct) {
@@ -381,6 +386,7 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
           Y[idx] = v;
           if (gout) stf(gout, (size_t)idx, v);
           ps[ct] += v;
+          pc[ct] += v > 0.f ? 1.f : 0.f;
         }
       }
   };
@@ -452,6 +458,12 @@ __device__ void gcn_fused(const int* rowptr, const int* col, const float* dinv, 
       t += __shfl_xor(t, 16, 64);
       t += __shfl_xor(t, 32, 64);
       if (lj == 0) pool_part[ct * 16 + li] = t;
+      if (pos_part) {
+        float c = pc[ct];
+        c += __shfl_xor(c, 16, 64);
+        c += __shfl_xor(c, 32, 64);
+        if (lj == 0) pos_part[ct * 16 + li] = c;
+      }
     }
   }
 }

@@ -185,6 +185,9 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
 #ifndef HSCN_CSR_ELL
 #define HSCN_CSR_ELL 1
 #endif
+#ifndef HSCN_BIAS0_COUNTS
+#define HSCN_BIAS0_COUNTS 1
+#endif
   // ---- prologue: every global input of the graph is requested before anything is consumed ----------------
   STAMP(0);
   constexpr int EPT = 2, XPT = 8;
@@ -451,11 +454,12 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
     STAMP(4 + l);
     // the last layer leaves each wave's share of global_mean_pool behind (column sums out of its accumulators)
     float* pool_w = l == L - 1 ? partp + wave * H : nullptr;
+    float* pos_w = l == L - 1 ? partp + NW * H + wave * H : nullptr;   // (slot 1 of the partials: positive counts)
     if (wave < NC) {
-      if (e16) gcn_fused<H, TS, true>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w);
-      else gcn_fused<H, TS, false>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w);
+      if (e16) gcn_fused<H, TS, true>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w, pos_w);
+      else gcn_fused<H, TS, false>(rowptr, col, dinv, buf(l), wt + l * WL, wt + l * WL + H * H, buf(l + 1), (TS*)nullptr, n, GC, pool_w, pos_w);
     } else if (hand) {
-      if (pool_w && lane < H) pool_w[lane] = 0.f;
+      if (pool_w && lane < H) { pool_w[lane] = 0.f; if (pos_w) pos_w[lane] = 0.f; }
       if (l >= 2) raise(l - 1);
       if (l >= 1) export_rows(buf(l), acts_g + ((size_t)(l - 1) * A.N + n0) * H);
     }
@@ -706,8 +710,12 @@ __device__ __forceinline__ void hscn_step_local(const StepArgs& A, const int g) 
           if (lane == 0) __hip_atomic_fetch_add(fold_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      if (it == 0) {   // bias gradient = column sums of G (first backward layer: G is the masked pool gradient; later
-                       // layers' sums were left by the previous layer's tile epilogues, see `bsum`)
+      if (it == 0 && HSCN_BIAS0_COUNTS) {
+        // first backward layer: G[row][col] = a_L[row][col] > 0 ? gpn[col] : 0, so its column sum is gpn[col] times the
+        // number of positive entries of the column -- which the forward's last layer counted in its epilogue (slot 1)
+        if (lane < H) bredw[wave * H + lane] = (partp + NW * H)[wave * H + lane] * gpn[lane];
+      } else if (it == 0) {   // (-DHSCN_BIAS0_COUNTS=0: the row walk) bias gradient = column sums of G; later
+                       // layers' sums were left by the previous layer's tile epilogues, see `bsum`
         const int slot = lane >> 2, f = (lane & 3) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = wave * 16 + slot; i < n; i += NW * 16) {
