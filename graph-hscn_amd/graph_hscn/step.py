@@ -118,7 +118,15 @@ class ResidentTrainStep:
         # the one-launch step's virtual workgroups also fit beside small graphs' 4-wave workgroups (several per CU)
         per_cu = int(_hip.lib().hscn_resident_train_step_wgs_per_cu(F, H, L, C, meta.max_n, meta.max_ell, meta.max_v,
                                                                     meta.max_evv))
-        self.idle_cus = bool(model.compute_virtual and model.overlap_virtual and V > 0 and 2 * B <= cus * max(per_cu, 1))
+        # ... and, H = 16, at ANY batch size: 2 B workgroups then take several rounds of the chip, local programs first
+        # (block ids [0, B)), so a virtual workgroup's producer has always been dispatched before it; measured against the
+        # launch pair at B = 256 / 512 / 1024: 47.9 / 86.2 / 163 us against 56.5 / 105 / 193 (profiles/r03_large_batches.txt).
+        # HSCN_ONE_LAUNCH_LARGE_B=0 restores the idle-CU rule.
+        import os
+        _lb = os.environ.get("HSCN_ONE_LAUNCH_LARGE_B", "1")     # ("all": H = 32 too -- measurement)
+        large_b = _lb == "all" or (H == 16 and _lb != "0")
+        self.idle_cus = bool(model.compute_virtual and model.overlap_virtual and V > 0 and
+                             (2 * B <= cus * max(per_cu, 1) or large_b))
         self._state = None
         if self.defer:
             self._state = (torch.empty(V + B, **i32), torch.empty(max(E_lv, 1), **i32), torch.empty(V + B, **i32),

@@ -284,6 +284,8 @@ def test_scn_one_launch_step_against_the_launch_pair(name, B, K, H, act, dtype):
                                                   ("pcqm_contact", 120, 16, 32, 3, 1, torch.float32),
                                                   ("pcqm_contact", 256, 16, 16, 3, 1, torch.float16),   # 512 workgroups: CUs shared
                                                   ("pcqm_contact", 400, 16, 16, 2, 1, torch.float32),
+                                                  ("peptides_func", 300, 16, 16, 3, 10, torch.float32),   # 600 workgroups of 16 waves:
+                                                  ("peptides_func", 256, 16, 16, 2, 10, torch.float16),   # several rounds of the chip
                                                   ("peptides_func", 24, 4, 16, 1, 10, torch.float32)])
 def test_one_launch_step_against_the_launch_pair_at_full_occupancy(name, B, K, H, L, C, dtype):
     """The one-launch step with every CU busy (up to 2B = 256 workgroups: B local programs, B virtual-branch
