@@ -124,7 +124,9 @@ class ResidentTrainStep:
         # HSCN_ONE_LAUNCH_LARGE_B=0 restores the idle-CU rule.
         import os
         _lb = os.environ.get("HSCN_ONE_LAUNCH_LARGE_B", "1")     # ("all": H = 32 too -- measurement)
-        large_b = _lb == "all" or (H == 16 and _lb != "0")
+        # (graphs of the 4-wave class, n <= 64, keep the rule: PCQM-Contact at B = 2 048 / 4 096 runs 101 / 183 us as the
+        # launch pair against 116 / 217)
+        large_b = _lb == "all" or (H == 16 and meta.max_n > 64 and _lb != "0")
         self.idle_cus = bool(model.compute_virtual and model.overlap_virtual and V > 0 and
                              (2 * B <= cus * max(per_cu, 1) or large_b))
         self._state = None
