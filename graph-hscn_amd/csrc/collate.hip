@@ -8,43 +8,53 @@
 //
 // grid = (B, 6): block (j, part) handles one array family of graph ids[j].  Every block derives the
 // destination offsets it needs itself -- a prefix sum over the sizes of the j graphs before it, B <= a few
-// thousand 8-byte loads spread over 256 threads -- so there is no scan launch and no inter-block dependency.
+// thousand 8-byte loads spread over 256 threads, all the tables a block needs in ONE pass (slot_ranges) -- so there is
+// no scan launch and no inter-block dependency.
 #include "hscn_common.h"
 
 namespace {
 
 constexpr int CT = 256;
 
-__device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
+// (offset, size) of graph slot j in NT tables of per-graph ranges AT ONCE: one pass over the ids before j (each id is
+// loaded once, its NT range lengths in parallel) and one block reduction for all of them.  (Measured: the launch stays
+// at 6.7 us either way -- cursor -> ids -> ranges -> data is four dependent trips to memory plus the launch itself.)
+template <int NT>
+__device__ __forceinline__ void slot_ranges(const int64_t* const (&p)[NT], const int64_t* __restrict__ ids, int j,
+                                            long long* red /*[NT][CT / 64]*/, long long (&off)[NT], long long (&size)[NT]) {
+  long long acc[NT];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();                      // red is reused between calls
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  long long s = 0;
-#pragma unroll
-  for (int w = 0; w < CT / 64; ++w) s += red[w];
-  return s;
-}
-
-// (offset of graph slot j, size of graph slot j) in the table p of per-graph ranges
-__device__ __forceinline__ void slot_range(const int64_t* __restrict__ p, const int64_t* __restrict__ ids, int j,
-                                           long long* red, long long& off, long long& size) {
-  long long acc = 0;
+  for (int t = 0; t < NT; ++t) acc[t] = 0;
   for (int q = threadIdx.x; q < j; q += CT) {
     const int64_t g = ids[q];
-    acc += p[g + 1] - p[g];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] += p[t][g + 1] - p[t][g];
   }
-  off = block_sum_ll(acc, red);
-  const int64_t g = ids[j];
-  size = p[g + 1] - p[g];
+  const int64_t gj = ids[j];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) size[t] = p[t][gj + 1] - p[t][gj];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    long long v = acc[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[t * (CT / 64) + (threadIdx.x >> 6)] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    long long s_ = 0;
+#pragma unroll
+    for (int w = 0; w < CT / 64; ++w) s_ += red[t * (CT / 64) + w];
+    off[t] = s_;
+  }
 }
 
 __global__ void __launch_bounds__(CT) k_collate_gather(const hscn_hetero_dataset D, const int64_t* __restrict__ ids,
                                                        int B, const hscn_hetero_batch_out O, int32_t* __restrict__ flag,
                                                        const int32_t* __restrict__ cursor,
                                                        const int32_t* __restrict__ cursor_base) {
-  __shared__ long long red[CT / 64];
+  __shared__ long long red[5 * (CT / 64)];
   const int j = blockIdx.x, part = blockIdx.y;
   // batch number `cursor` (- `cursor_base`) of a permutation that lives on the device
   if (cursor) ids += (int64_t)(cursor[0] - (cursor_base ? cursor_base[0] : 0)) * B;
@@ -53,11 +63,27 @@ __global__ void __launch_bounds__(CT) k_collate_gather(const hscn_hetero_dataset
     if (threadIdx.x == 0 && flag) atomicOr(flag, 8);
     return;
   }
+  // every range this part needs, in one pass: [0] local nodes, [1] virtual nodes, [2 ..] edge tables
   long long on = 0, n = 0, ov = 0, nv = 0;
-  const bool need_n = part == 0 || part == 2 || part == 4 || part == 5;
-  const bool need_v = part == 1 || part == 3 || part == 4 || part == 5;
-  if (need_n) slot_range(D.nptr, ids, j, red, on, n);
-  if (need_v) slot_range(D.vptr, ids, j, red, ov, nv);
+  long long oe[3] = {0, 0, 0}, ne[3] = {0, 0, 0};
+  if (part <= 1) {
+    const int64_t* const tb[1] = {part == 0 ? D.nptr : D.vptr};
+    long long o1[1], s1[1];
+    slot_ranges<1>(tb, ids, j, red, o1, s1);
+    if (part == 0) { on = o1[0]; n = s1[0]; } else { ov = o1[0]; nv = s1[0]; }
+  } else if (part <= 4) {
+    const int r = part - 2;
+    const int64_t* const tb[3] = {D.nptr, D.vptr, D.eptr[r]};
+    long long o3[3], s3[3];
+    slot_ranges<3>(tb, ids, j, red, o3, s3);
+    on = o3[0]; n = s3[0]; ov = o3[1]; nv = s3[1]; oe[r] = o3[2]; ne[r] = s3[2];
+  } else {
+    const int64_t* const tb[5] = {D.nptr, D.vptr, D.eptr[0], D.eptr[1], D.eptr[2]};
+    long long o5[5], s5[5];
+    slot_ranges<5>(tb, ids, j, red, o5, s5);
+    on = o5[0]; n = s5[0]; ov = o5[1]; nv = s5[1];
+    for (int r = 0; r < 3; ++r) { oe[r] = o5[2 + r]; ne[r] = s5[2 + r]; }
+  }
   const bool fits_n = on + n <= O.ncap, fits_v = ov + nv <= O.vcap;
   if (part == 0) {                      // local features + batch vector
     if (!fits_n) { if (threadIdx.x == 0 && flag) atomicOr(flag, 8); return; }
@@ -73,24 +99,21 @@ __global__ void __launch_bounds__(CT) k_collate_gather(const hscn_hetero_dataset
     for (long long i = threadIdx.x; i < nv; i += CT) O.batch_virtual[ov + i] = j;
   } else if (part <= 4) {               // relation r = ll, vv, lv: local ids -> batch ids
     const int r = part - 2;
-    long long oe, ne;
-    slot_range(D.eptr[r], ids, j, red, oe, ne);
-    if (oe + ne > O.ecap[r]) { if (threadIdx.x == 0 && flag) atomicOr(flag, 8); return; }
+    if (oe[r] + ne[r] > O.ecap[r]) { if (threadIdx.x == 0 && flag) atomicOr(flag, 8); return; }
     const long long os = r == 1 ? ov : on, od = r == 0 ? on : ov;
     const int64_t e0 = D.eptr[r][g];
     const int32_t* ss = D.src[r] + e0;
     const int32_t* dd = D.dst[r] + e0;
-    int64_t* es = O.ei[r] + oe;
-    int64_t* ed = O.ei[r] + O.ecap[r] + oe;
-    for (long long e = threadIdx.x; e < ne; e += CT) {
+    int64_t* es = O.ei[r] + oe[r];
+    int64_t* ed = O.ei[r] + O.ecap[r] + oe[r];
+    const long long ner = ne[r];
+    for (long long e = threadIdx.x; e < ner; e += CT) {
       es[e] = (int64_t)ss[e] + os;
       ed[e] = (int64_t)dd[e] + od;
     }
   } else {                              // targets + the five segment tables (entry j; the last slot also writes the totals)
     if (D.y && O.y)
       for (int c = threadIdx.x; c < D.C; c += CT) O.y[(size_t)j * D.C + c] = D.y[(size_t)g * D.C + c];
-    long long oe[3], ne[3];
-    for (int r = 0; r < 3; ++r) slot_range(D.eptr[r], ids, j, red, oe[r], ne[r]);
     if (threadIdx.x == 0) {
       O.ptr_local[j] = on;    O.ptr32_local[j] = (int32_t)on;
       O.ptr_virtual[j] = ov;  O.ptr32_virtual[j] = (int32_t)ov;
@@ -111,7 +134,7 @@ __global__ void __launch_bounds__(CT) k_collate_structure(const hscn_hetero_data
                                                           const hscn_hetero_batch_out O, const hscn_structure T,
                                                           int32_t* __restrict__ flag, const int32_t* __restrict__ cursor,
                                                           const int32_t* __restrict__ cursor_base) {
-  __shared__ long long red[CT / 64];
+  __shared__ long long red[2 * (CT / 64)];
   const int j = blockIdx.x, part = blockIdx.y;
   if (cursor) ids += (int64_t)(cursor[0] - (cursor_base ? cursor_base[0] : 0)) * B;
   const int64_t g = ids[j];
@@ -120,10 +143,14 @@ __global__ void __launch_bounds__(CT) k_collate_structure(const hscn_hetero_data
     return;
   }
   long long on = 0, n = 0, ov = 0, nv = 0, oe = 0, ne = 0;
-  if (part <= 1) slot_range(D.nptr, ids, j, red, on, n);
-  if (part >= 2) slot_range(D.vptr, ids, j, red, ov, nv);
   const int r = part <= 1 ? 0 : (part == 2 ? 2 : 1);          // relation order of the dataset: ll, vv, lv
-  slot_range(D.eptr[r], ids, j, red, oe, ne);
+  {
+    const int64_t* const tb[2] = {part <= 1 ? D.nptr : D.vptr, D.eptr[r]};
+    long long o2[2], s2[2];
+    slot_ranges<2>(tb, ids, j, red, o2, s2);
+    if (part <= 1) { on = o2[0]; n = s2[0]; } else { ov = o2[0]; nv = s2[0]; }
+    oe = o2[1]; ne = s2[1];
+  }
   if (on + n > O.ncap || ov + nv > O.vcap || oe + ne > O.ecap[r]) {
     if (threadIdx.x == 0 && flag) atomicOr(flag, 8);
     return;
