@@ -91,6 +91,10 @@ def _oracle_step(m, ob, y, B, loss_fn, dtype, store=None):
     ("peptides_struct", 32, 32, 16, 3, 11, "l1", torch.float32),
     ("pascalvoc_sp", 128, 64, 16, 3, 21, "cross_entropy", torch.float32),
     ("pcqm_contact", 256, 16, 16, 3, 1, "l1", torch.float16),
+    # batches of several rounds of the chip (2 B workgroups > 256 CUs): the one-launch step's default issue form there,
+    # and config 3's GLOBAL batch on one GPU (the strong-scaling leg of bench.py --gpus 8)
+    ("peptides_func", 512, 16, 16, 3, 10, "cross_entropy", torch.float32),
+    ("peptides_struct", 256, 32, 16, 3, 11, "l1", torch.float32),
 ])
 def test_bench_step_against_the_oracle_at_the_stated_size(name, B, K, H, L, C, loss_fn, dtype):
     from graph_hscn.step import ResidentTrainStep
