@@ -558,7 +558,10 @@ int hscn_collate_gather_structure(const hscn_hetero_dataset* dataset, const hscn
  * ------------------------------------------------------------------------- */
 int hscn_resident_train_step_supported(int F, int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv);
 /* workgroups of that launch one CU holds at a time (0 = unsupported): the virtual branch rides as B more workgroups
- * while 2B <= number of CUs x this figure (1 for 16-wave workgroups; up to 4 for the 4-wave workgroups of small graphs) */
+ * while 2B <= number of CUs x this figure (1 for 16-wave workgroups; up to 4 for the 4-wave workgroups of small graphs).
+ * Beyond that the launch is still CORRECT at any B -- block ids [0, B) are the local programs, so every producer is
+ * dispatched before its consumer and no local program waits on anybody -- and, for 16-wave workgroups at H = 16, faster
+ * than the launch pair (the caller's choice: graph_hscn/step.py takes it there). */
 int hscn_resident_train_step_wgs_per_cu(int F, int H, int L, int C, int max_n, int max_ell, int max_v, int max_evv);
 int hscn_resident_train_step(const float* x_local, const int64_t* ei_ll, int64_t E_ll, const int32_t* lptr,
                              const int32_t* eptr_ll, int64_t N, int64_t B, int F, int H, int L, int C, int head_act,
